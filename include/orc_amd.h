@@ -1,0 +1,148 @@
+/* orc_amd.h — C ABI of liborc_amd.so: ORC's per-SIMPLE-iteration hot path on MI355X (gfx950).
+ *
+ * ORC (reidprichard/ORC v0.3.0) has no plugin/FFI layer; the drop-in boundary is its ordinary
+ * `pub fn` surface.  Each entry point below replaces one of those functions and
+ * cites it (file:line into the reference).  A Rust `extern "C"` shim that keeps ORC's own
+ * signatures on top of this header is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every array is caller-owned host memory unless the name
+ *    says `_dev`; the library copies in/out and keeps its own device allocations.
+ *  - fields and matrices are in ORC cell order; indices are 0-based int64 (`usize`).
+ *  - return value: OrcStatus (include/orc_types.h). ORC panics where we return non-zero; the
+ *    shim turns non-zero into panic!(orc_status_string(code)).
+ *  - there is NO CPU fallback: without a HIP device every compute entry returns ORC_ERR_NO_DEVICE.
+ *  - CSR matrices use ORC's pattern: per cell the diagonal plus one entry per interior face,
+ *    columns ascending (what CsrMatrix::from(&CooMatrix) yields at discretization.rs:130,445,471).
+ */
+#ifndef ORC_AMD_H
+#define ORC_AMD_H
+
+#include <stdint.h>
+#include "orc_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct OrcMesh OrcMesh;     /* device-resident SoA image of mesh::Mesh (mesh.rs:181-187) */
+typedef struct OrcSolver OrcSolver; /* device-resident state of one solve_steady call (solver.rs:39-49) */
+
+/* ---------- runtime ---------- */
+int orc_init(int device_ordinal);              /* hipSetDevice + stream; idempotent */
+int orc_device_count(void);                    /* 0 when no HIP device is visible */
+int orc_synchronize(void);                     /* hipStreamSynchronize on the library stream */
+const char *orc_status_string(int status);     /* the reference's panic text for the code */
+const char *orc_last_error(void);              /* detail of the last ORC_ERR_HIP / BAD_ARGUMENT */
+void orc_settings_default(OrcSettings *s);     /* NumericalSettings::default() + MatrixSolverSettings::default(), lib.rs:58-86 */
+
+/* ---------- mesh::Mesh (mesh.rs:140-187) ---------- */
+/* face_c0/face_c1: Face.cell_indices[0], [1] (-1 when the face has one cell, io.rs:332-337);
+ * face_normal: unit normal outward from face_c0 (mesh.rs:216-222); face_zone: index into the
+ * zone arrays; zone_type: OrcFaceConditionType per zone (FaceZone.zone_type, mesh.rs:12-17);
+ * cell_faces: Cell.face_indices, ascending face id (io.rs:404-410). */
+OrcMesh *orc_mesh_create(int64_t n_cells, int64_t n_faces, int32_t n_zones,
+                         const int64_t *face_c0, const int64_t *face_c1, const int32_t *face_zone,
+                         const double *face_area, const double *face_normal /*[3F]*/, const double *face_centroid /*[3F]*/,
+                         const double *cell_centroid /*[3n]*/, const double *cell_volume,
+                         const int64_t *cell_face_ptr /*[n+1]*/, const int64_t *cell_faces,
+                         const int32_t *zone_type, const double *zone_scalar, const double *zone_vector /*[3Z]*/,
+                         int *status);
+/* mesh.get_face_zone(name).zone_type / scalar_value / vector_value = ... (tests.rs:60-76) */
+int orc_mesh_update_zones(OrcMesh *m, const int32_t *zone_type, const double *zone_scalar, const double *zone_vector);
+void orc_mesh_destroy(OrcMesh *m);
+int64_t orc_mesh_n_cells(const OrcMesh *m);
+int64_t orc_mesh_nnz(const OrcMesh *m);
+/* CSR pattern shared by a_di, a_u, a_v, a_w and the pressure-correction matrix */
+int orc_mesh_matrix_pattern(const OrcMesh *m, int64_t *row_ptr /*[n+1]*/, int64_t *col_idx /*[nnz]*/);
+
+/* ---------- linear_algebra::iterative_solve (linear_algebra.rs:144-153) ---------- */
+int orc_iterative_solve(int64_t n, const int64_t *row_ptr, const int64_t *col_idx, const double *values,
+                        const double *b, double *solution_vector /*in/out*/, uint64_t iteration_count,
+                        int method /*OrcSolutionMethod*/, double relaxation_factor, double convergence_threshold,
+                        int preconditioner /*OrcPreconditionMethod*/);
+/* sweeps the Jacobi arm executed in the last orc_iterative_solve (linear_algebra.rs:188-217) */
+int64_t orc_last_jacobi_sweeps(void);
+/* y = A x: the `&CsrMatrix * &DVector` product the reference takes from nalgebra-sparse
+ * (linear_algebra.rs:256,260); row sums accumulate in ascending-column order from 0.0, so y is
+ * bit-identical to the CPU product.  `reps` > 1 repeats the launch (timing); avg_ms may be NULL. */
+int orc_csr_spmv(int64_t n, const int64_t *row_ptr, const int64_t *col_idx, const double *values, const double *x,
+                 double *y, int reps, double *avg_ms);
+
+/* ---------- discretization::* ---------- */
+/* build_momentum_diffusion_matrix (discretization.rs:39-48): values in pattern order + 3 RHS */
+int orc_build_momentum_diffusion_matrix(const OrcMesh *m, int diffusion_scheme, double mu,
+                                        double *a_values /*[nnz]*/, double *b_u, double *b_v, double *b_w);
+/* initialize_momentum_matrix (discretization.rs:450) */
+int orc_initialize_momentum_matrix(const OrcMesh *m, double *a_values /*[nnz]*/);
+/* build_momentum_advection_matrices (discretization.rs:134-152).  a_u/a_v/a_w values are in/out:
+ * their diagonals on entry are what Rhie-Chow reads (frozen-diagonal semantics).
+ * peclet: (avg, min, max) as returned by the reference (:355). */
+int orc_build_momentum_advection_matrices(const OrcMesh *m, double *a_u_values, double *a_v_values, double *a_w_values,
+                                          double *b_u, double *b_v, double *b_w, const double *a_di_values,
+                                          const double *u, const double *v, const double *w, const double *p,
+                                          const OrcSettings *settings, double rho, double peclet[3]);
+/* build_pressure_correction_matrices (discretization.rs:359-370) -> LinearSystem{a,b} */
+int orc_build_pressure_correction_matrices(const OrcMesh *m, const double *u, const double *v, const double *w,
+                                           const double *p, const double *a_u_values, const double *a_v_values,
+                                           const double *a_w_values, const OrcSettings *settings, double rho,
+                                           double *a_values /*[nnz]*/, double *b /*[n]*/);
+
+/* ---------- solver::* ---------- */
+/* calculate_pressure_gradient / calculate_velocity_gradient, Green-Gauss arms (solver.rs:774-802, 874-902),
+ * evaluated for every cell: grad_p[3n], grad_u[9n] (row = velocity component) */
+int orc_calculate_gradients(const OrcMesh *m, const double *u, const double *v, const double *w, const double *p,
+                            const OrcSettings *settings, double *grad_p, double *grad_u);
+/* solve_steady (solver.rs:26-37). report_cb is called every reporting_interval iterations with
+ * what the reference prints (solver.rs:209-216): iteration, mean u/v/w, Peclet avg/min/max,
+ * velocity- and pressure-correction norms, ms/iter.  May be NULL. */
+typedef void (*OrcReportFn)(uint64_t iteration, const double mean_velocity[3], const double peclet[3],
+                            double velocity_correction, double pressure_correction, double ms_per_iter, void *user);
+int orc_solve_steady(OrcMesh *m, double *u, double *v, double *w, double *p, const OrcSettings *settings,
+                     double rho, double mu, uint64_t iteration_count, uint64_t reporting_interval,
+                     OrcReportFn report_cb, void *user);
+
+/* ---------- device-resident solver (what orc_solve_steady is made of) ---------- */
+OrcSolver *orc_solver_create(OrcMesh *m, const OrcSettings *settings, double rho, double mu, int *status); /* solver.rs:39-49 */
+void orc_solver_destroy(OrcSolver *s);
+int orc_solver_set_fields(OrcSolver *s, const double *u, const double *v, const double *w, const double *p);
+int orc_solver_get_fields(OrcSolver *s, double *u, double *v, double *w, double *p);
+/* runs `iterations` SIMPLE iterations (solver.rs:60-222); report, if not NULL, receives 8 doubles per
+ * iteration: u_avg, v_avg, w_avg, peclet_avg, peclet_min, peclet_max, vel_corr, p_corr */
+int orc_solver_iterate(OrcSolver *s, uint64_t iterations, double *report);
+/* individual phases, for the parity tests: matrices come back in pattern order */
+int orc_solver_assemble_momentum(OrcSolver *s, double *a_u, double *a_v, double *a_w, double *b_u, double *b_v, double *b_w, double peclet[3]);
+int orc_solver_assemble_pressure(OrcSolver *s, double *a_p, double *b_p);
+
+/* ---------- measurement hooks (bench.py): HIP-event timed launches of single kernels ---------- */
+/* y = A x with the momentum matrix a_u of the solver, `reps` launches; returns average ms per launch */
+int orc_bench_spmv(OrcSolver *s, int reps, double *avg_ms, double *checksum);
+/* one BiCGSTAB iteration body (linear_algebra.rs:255-268) repeated `reps` times on a_u */
+int orc_bench_bicgstab_iteration(OrcSolver *s, int reps, double *avg_ms);
+/* kernel-level timers accumulated inside orc_solver_iterate when enabled: name/ms pairs */
+int orc_profile_enable(int on);
+int orc_profile_report(char *buf, int64_t buf_len);
+
+/* ---------- synthetic meshes: host-side generator, ORC numbering rules ---------- */
+/* Structured hex channel nx*ny*nz cells on [0,lx]x[0,ly]x[0,lz]: interior faces first, then zones
+ * INLET(x-min) OUTLET(x-max) PERIODIC_-Z PERIODIC_+Z TOP_WALL BOTTOM_WALL — the zone order of
+ * couette_flow_128x64x1.msh; all boundary zones type 3 (wall) like the reference's fixtures.
+ * Call with NULL arrays to get sizes. */
+int orc_hex_channel_sizes(int64_t nx, int64_t ny, int64_t nz, int64_t *n_cells, int64_t *n_faces, int64_t *n_cell_faces);
+int orc_hex_channel_generate(int64_t nx, int64_t ny, int64_t nz, double lx, double ly, double lz,
+                             int64_t *face_c0, int64_t *face_c1, int32_t *face_zone, double *face_area,
+                             double *face_normal, double *face_centroid, double *cell_centroid, double *cell_volume,
+                             int64_t *cell_face_ptr, int64_t *cell_faces);
+/* writes the same mesh as an ASCII TGRID .msh that ORC's read_mesh (io.rs:32) accepts */
+int orc_hex_channel_write_msh(const char *path, int64_t nx, int64_t ny, int64_t nz, double lx, double ly, double lz);
+
+/* ---------- multi-GPU (one process per GPU, RCCL over xGMI) ---------- */
+#define ORC_COMM_ID_BYTES 128
+int orc_comm_get_unique_id(unsigned char id[ORC_COMM_ID_BYTES]);          /* rank 0, then broadcast by the host launcher */
+int orc_comm_init(const unsigned char id[ORC_COMM_ID_BYTES], int rank, int world_size);
+int orc_comm_finalize(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORC_AMD_H */

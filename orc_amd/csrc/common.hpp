@@ -1,0 +1,162 @@
+// common.hpp — runtime plumbing shared by the HIP translation units of liborc_amd.so.
+// gfx950 only: 64-lane wavefronts are hard-coded.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/orc_amd.h"
+
+namespace orc {
+
+constexpr int kWave = 64;          // CDNA wavefront
+constexpr int kBlock = 256;        // 4 waves per workgroup
+constexpr int kMaxGrid = 2048;     // 256 CUs x 8 workgroups: grid-stride above this
+constexpr int kMaxPartials = kMaxGrid;
+
+struct Ctx {
+    bool inited = false;
+    int device = -1;
+    hipStream_t stream = nullptr;
+    std::string last_error;
+    bool profile = false;
+    // multi-GPU (comm.cpp)
+    int rank = 0, world = 1;
+    void *nccl_comm = nullptr;
+};
+Ctx &ctx();
+
+int set_error(int code, const char *fmt, ...);
+
+#define ORC_HIP(call)                                                                                     \
+    do {                                                                                                  \
+        hipError_t e__ = (call);                                                                          \
+        if (e__ != hipSuccess)                                                                            \
+            return orc::set_error(ORC_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+    } while (0)
+
+#define ORC_TRY(call)                 \
+    do {                              \
+        int st__ = (call);            \
+        if (st__ != ORC_OK) return st__; \
+    } while (0)
+
+int ensure_init();
+
+// Device buffer with explicit lifetime (no hipMalloc inside timed loops: see Arena).
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DevBuf &operator=(DevBuf &&o) noexcept {
+        if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+        return *this;
+    }
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr; n = 0;
+    }
+    int alloc(size_t count) {
+        release();
+        n = count;
+        if (count == 0) return ORC_OK;
+        ORC_HIP(hipMalloc((void **)&p, count * sizeof(T)));
+        return ORC_OK;
+    }
+    int ensure(size_t count) { return count <= n ? ORC_OK : alloc(count); }
+    int upload(const T *h, size_t count) {
+        ORC_TRY(ensure(count));
+        if (count) ORC_HIP(hipMemcpyAsync(p, h, count * sizeof(T), hipMemcpyHostToDevice, ctx().stream));
+        ORC_HIP(hipStreamSynchronize(ctx().stream));
+        return ORC_OK;
+    }
+    int download(T *h, size_t count) const {
+        if (count) ORC_HIP(hipMemcpyAsync(h, p, count * sizeof(T), hipMemcpyDeviceToHost, ctx().stream));
+        ORC_HIP(hipStreamSynchronize(ctx().stream));
+        return ORC_OK;
+    }
+    int zero() {
+        if (n) ORC_HIP(hipMemsetAsync(p, 0, n * sizeof(T), ctx().stream));
+        return ORC_OK;
+    }
+};
+
+// Stack arena for per-solve temporaries (AMG hierarchies change size every solve; the SIMPLE
+// loop must not call hipMalloc).  Chunks are kept until destroy; mark()/release() unwind.
+class Arena {
+  public:
+    ~Arena();
+    struct Mark { size_t chunk, off; };
+    Mark mark() const { return {cur_, off_}; }
+    void release(Mark m) { cur_ = m.chunk; off_ = m.off; }
+    int alloc_bytes(size_t bytes, void **out);
+    template <class T>
+    int alloc(size_t count, T **out) { return alloc_bytes(count * sizeof(T), (void **)out); }
+    size_t reserved() const;
+
+  private:
+    struct Chunk { char *p; size_t size; };
+    std::vector<Chunk> chunks_;
+    size_t cur_ = 0, off_ = 0;
+};
+
+inline int grid_for(int64_t work_items, int per_block = kBlock) {
+    int64_t g = (work_items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > kMaxGrid) g = kMaxGrid;
+    return (int)g;
+}
+
+// ---------------- device helpers ----------------
+#ifdef __HIPCC__
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+    return v;
+}
+// Sum over the workgroup (256 threads = 4 waves); result valid in thread 0.
+__device__ __forceinline__ double block_sum(double v, double *lds /*>=4 doubles*/) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) lds[w] = v;
+    __syncthreads();
+    double r = 0.;
+    if (threadIdx.x == 0) {
+        const int nw = (blockDim.x + 63) >> 6;
+        for (int i = 0; i < nw; i++) r += lds[i];
+    }
+    return r;
+}
+__device__ __forceinline__ double block_max(double v, double *lds) {
+    v = wave_max(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) lds[w] = v;
+    __syncthreads();
+    double r = 0.;
+    if (threadIdx.x == 0) {
+        const int nw = (blockDim.x + 63) >> 6;
+        r = lds[0];
+        for (int i = 1; i < nw; i++) r = fmax(r, lds[i]);
+    }
+    return r;
+}
+#endif
+
+}  // namespace orc

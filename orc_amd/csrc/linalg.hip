@@ -1,0 +1,520 @@
+// linalg.hip — SELL-64 SpMV, wave reductions, BiCGSTAB, Jacobi and the iterative_solve driver
+// (SURVEY §2.1 K1-K5).  Reference: src/linear_algebra.rs:144-299.
+//
+// Everything is HBM-bound fp64 (AI ~ 0.13 flop/B): no MFMA, the levers are coalescing (SELL-64),
+// XCD-local x-vector reuse, fused vector updates and no host round-trips inside a solve.
+// Compiled with -ffp-contract=off: rustc never fuses a*b+c, and bit-parity of y = A x with the
+// CPU oracle depends on that.
+#include <algorithm>
+#include <cmath>
+
+#include "linalg_kernels.hpp"
+
+namespace orc {
+
+int comm_allreduce_sum(double *dev, int n);  // comm.cpp; no-op when world == 1
+
+// ------------------------------------------------------------------ reductions
+__global__ __launch_bounds__(1024) void reduce_partials_k(const double *__restrict__ partials, int count, int nq, double *__restrict__ out) {
+    __shared__ double lds[16];
+    for (int q = 0; q < nq; ++q) {
+        double v = 0.;
+        for (int i = threadIdx.x; i < count; i += blockDim.x) v += partials[(size_t)q * count + i];
+        v = wave_sum(v);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double r = 0.;
+            for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r += lds[i];
+            out[q] = r;
+        }
+    }
+}
+
+int reduce_partials(const double *partials, int count, int nq, double *out) {
+    hipLaunchKernelGGL(reduce_partials_k, dim3(1), dim3(1024), 0, ctx().stream, partials, count, nq, out);
+    ORC_HIP(hipGetLastError());
+    if (ctx().world > 1) ORC_TRY(comm_allreduce_sum(out, nq));
+    return ORC_OK;
+}
+
+static inline int spmv_grid(int32_t n_slices) {
+    int64_t g = ((int64_t)n_slices + 3) / 4;  // 4 waves (slices) per workgroup
+    if (g > kMaxGrid) g = kMaxGrid;
+    if (g >= 8) g = (g / 8) * 8;  // multiple of 8 for the XCD-aware walk
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// ------------------------------------------------------------------ SELL build / import / export
+int sell_from_csr_host(int64_t n, const int64_t *row_ptr, const int64_t *col, SellMatrix &out) {
+    if (n < 0) return set_error(ORC_ERR_BAD_ARGUMENT, "negative row count");
+    const int64_t nnz = n > 0 ? row_ptr[n] : 0;
+    const int32_t n_slices = (int32_t)((n + 63) / 64);
+    std::vector<int64_t> slice_ptr((size_t)n_slices + 1, 0);
+    std::vector<int32_t> row_len((size_t)std::max<int64_t>(n, 1));
+    for (int32_t s = 0; s < n_slices; ++s) {
+        int64_t w = 0;
+        for (int64_t r = (int64_t)s * 64; r < std::min<int64_t>(n, (int64_t)s * 64 + 64); ++r) w = std::max(w, row_ptr[r + 1] - row_ptr[r]);
+        slice_ptr[s + 1] = slice_ptr[s] + w * 64;
+    }
+    const int64_t padded = slice_ptr[n_slices];
+    if (padded >= (int64_t)1 << 31) return set_error(ORC_ERR_BAD_ARGUMENT, "matrix too large for 32-bit element offsets (%lld)", (long long)padded);
+    std::vector<int32_t> scol((size_t)std::max<int64_t>(padded, 1), 0), diag((size_t)std::max<int64_t>(n, 1), -1);
+    bool symmetric = true;
+    for (int64_t r = 0; r < n; ++r) {
+        const int64_t b = row_ptr[r], e = row_ptr[r + 1];
+        row_len[r] = (int32_t)(e - b);
+        const int64_t base = slice_ptr[r >> 6] + (r & 63);
+        for (int64_t k = 0; k < e - b; ++k) {
+            const int64_t c = col[b + k];
+            if (c < 0 || c >= n) return set_error(ORC_ERR_BAD_ARGUMENT, "column index out of range");
+            if (k > 0 && col[b + k - 1] >= c) return set_error(ORC_ERR_BAD_ARGUMENT, "CSR columns must be strictly ascending per row");
+            scol[base + k * 64] = (int32_t)c;
+            if (c == r) diag[r] = (int32_t)(base + k * 64);
+            if (symmetric && c != r) {
+                const int64_t *lo = col + row_ptr[c], *hi = col + row_ptr[c + 1];
+                const int64_t *it = std::lower_bound(lo, hi, r);
+                if (it == hi || *it != r) symmetric = false;
+            }
+        }
+        // padding slots point at the row itself (never dereferenced: guarded by row_len)
+        const int64_t width = (slice_ptr[(r >> 6) + 1] - slice_ptr[r >> 6]) >> 6;
+        for (int64_t k = e - b; k < width; ++k) scol[base + k * 64] = (int32_t)r;
+    }
+    out.n = n; out.nnz = nnz; out.padded = padded; out.n_slices = n_slices; out.symmetric = symmetric;
+    ORC_TRY(out.slice_ptr.upload(slice_ptr.data(), slice_ptr.size()));
+    ORC_TRY(out.row_len.upload(row_len.data(), (size_t)n));
+    ORC_TRY(out.col.upload(scol.data(), (size_t)padded));
+    ORC_TRY(out.diag_pos.upload(diag.data(), (size_t)n));
+    ORC_TRY(out.csr_row_ptr.upload(row_ptr, (size_t)n + 1));
+    return ORC_OK;
+}
+
+__global__ void sell_import_k(SellDev P, const int64_t *__restrict__ row_ptr, const double *__restrict__ csr, double *__restrict__ sell) {
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < P.n; r += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t base = P.slice_ptr[r >> 6] + (r & 63), b = row_ptr[r];
+        const int len = P.row_len[r];
+        const int width = (int)((P.slice_ptr[(r >> 6) + 1] - P.slice_ptr[r >> 6]) >> 6);
+        for (int k = 0; k < width; ++k) sell[base + (int64_t)k * 64] = k < len ? csr[b + k] : 0.;
+    }
+}
+__global__ void sell_export_k(SellDev P, const int64_t *__restrict__ row_ptr, const double *__restrict__ sell, double *__restrict__ csr) {
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < P.n; r += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t base = P.slice_ptr[r >> 6] + (r & 63), b = row_ptr[r];
+        const int len = P.row_len[r];
+        for (int k = 0; k < len; ++k) csr[b + k] = sell[base + (int64_t)k * 64];
+    }
+}
+
+int sell_import_values(const SellMatrix &m, const double *csr_vals_dev, double *sell_vals_dev) {
+    if (m.n == 0) return ORC_OK;
+    hipLaunchKernelGGL(sell_import_k, dim3(grid_for(m.n)), dim3(kBlock), 0, ctx().stream, m.dev(), m.csr_row_ptr.p, csr_vals_dev, sell_vals_dev);
+    ORC_HIP(hipGetLastError());
+    return ORC_OK;
+}
+int sell_export_values(const SellMatrix &m, const double *sell_vals_dev, double *csr_vals_dev) {
+    if (m.n == 0) return ORC_OK;
+    hipLaunchKernelGGL(sell_export_k, dim3(grid_for(m.n)), dim3(kBlock), 0, ctx().stream, m.dev(), m.csr_row_ptr.p, sell_vals_dev, csr_vals_dev);
+    ORC_HIP(hipGetLastError());
+    return ORC_OK;
+}
+
+// ------------------------------------------------------------------ vector kernels
+__global__ void fill_k(double *x, double v, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) x[i] = v;
+}
+int vec_fill(double *x, double v, int64_t n) {
+    if (n == 0) return ORC_OK;
+    hipLaunchKernelGGL(fill_k, dim3(grid_for(n)), dim3(kBlock), 0, ctx().stream, x, v, n);
+    ORC_HIP(hipGetLastError());
+    return ORC_OK;
+}
+int vec_copy(double *dst, const double *src, int64_t n) {
+    if (n) ORC_HIP(hipMemcpyAsync(dst, src, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, ctx().stream));
+    return ORC_OK;
+}
+
+// dinv[i] = 1 / A(i,i) through the view; 0 where the diagonal is not stored (the reference's
+// p_inv row is then empty: linear_algebra.rs:160-165)
+__global__ void diag_inverse_k(MatView A, double *__restrict__ dinv) {
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < A.P.n; r += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t d = A.P.diag_pos[r];
+        dinv[r] = d >= 0 ? 1. / view_value(A, r, d) : 0.;
+    }
+}
+// out = 0 + s * b   (p_inv * b as a one-entry-per-row SpMV, linear_algebra.rs:165)
+__global__ void scale_vec_k(const double *__restrict__ s, const double *__restrict__ b, double *__restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = 0. + s[i] * b[i];
+}
+
+// ------------------------------------------------------------------ SpMV epilogues
+struct EpiStore {  // y = A x
+    static constexpr int kReductions = 0;
+    double *y;
+    __device__ __forceinline__ void apply(int64_t row, double acc, double &, double &) const { y[row] = acc; }
+};
+struct EpiStoreSum {  // y = A x ; partial sum(y)          (nu = A p, r_hat_0 . nu : linear_algebra.rs:256-257)
+    static constexpr int kReductions = 1;
+    double *y;
+    __device__ __forceinline__ void apply(int64_t row, double acc, double &r0, double &) const { y[row] = acc; r0 += acc; }
+};
+struct EpiResidual {  // r = b - A x ; p = r ; partial sum(r)  (linear_algebra.rs:250-254)
+    static constexpr int kReductions = 1;
+    const double *b;
+    double *r, *p;
+    __device__ __forceinline__ void apply(int64_t row, double acc, double &r0, double &) const {
+        const double v = b[row] - acc;
+        r[row] = v;
+        if (p) p[row] = v;
+        r0 += v;
+    }
+};
+struct EpiResidualNorm {  // partial sum((b - A x)^2)       (linear_algebra.rs:97, :202)
+    static constexpr int kReductions = 1;
+    const double *b;
+    double *r;  // optional
+    __device__ __forceinline__ void apply(int64_t row, double acc, double &r0, double &) const {
+        const double v = b[row] - acc;
+        if (r) r[row] = v;
+        r0 += v * v;
+    }
+};
+struct EpiTs {  // t = A s ; partials t.s, t.t            (linear_algebra.rs:260-261)
+    static constexpr int kReductions = 2;
+    const double *s;
+    double *t;
+    __device__ __forceinline__ void apply(int64_t row, double acc, double &r0, double &r1) const {
+        t[row] = acc;
+        r0 += acc * s[row];
+        r1 += acc * acc;
+    }
+};
+
+template <class Epi>
+static int launch_spmv(const MatView &A, const double *x, const Epi &epi, double *partials, int *grid_out) {
+    const int g = spmv_grid(A.P.n_slices);
+    if (grid_out) *grid_out = g;
+    if (A.P.n == 0) return ORC_OK;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials);
+    ORC_HIP(hipGetLastError());
+    return ORC_OK;
+}
+
+int spmv_dev(const MatView &A, const double *x, double *y) {
+    EpiStore e{y};
+    return launch_spmv(A, x, e, nullptr, nullptr);
+}
+
+// ------------------------------------------------------------------ BiCGSTAB (linear_algebra.rs:247-269)
+// scal[] layout (device doubles):
+enum { S_RHO0 = 0, S_RHO1 = 1, S_SUM_NU = 2, S_TS = 3, S_TT = 4, S_COUNT = 8 };
+
+// s = r - alpha*nu, alpha = rho / (r_hat_0 . nu)                     (:257, :259)
+__global__ void bicg_s_k(const double *__restrict__ scal, int rho_idx, const double *__restrict__ r, const double *__restrict__ nu,
+                         double *__restrict__ s, int64_t n) {
+    const double alpha = scal[rho_idx] / scal[S_SUM_NU];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) s[i] = r[i] - alpha * nu[i];
+}
+// h = x + alpha p ; x = h + omega s ; r = s - omega t ; partial sum(r)   (:258, :261-263, :265)
+__global__ __launch_bounds__(kBlock) void bicg_xr_k(const double *__restrict__ scal, int rho_idx, double *__restrict__ x,
+                                                    const double *__restrict__ p, const double *__restrict__ s,
+                                                    const double *__restrict__ t, double *__restrict__ r, int64_t n,
+                                                    double *__restrict__ partials) {
+    __shared__ double lds[8];
+    const double alpha = scal[rho_idx] / scal[S_SUM_NU];
+    const double omega = scal[S_TS] / scal[S_TT];
+    double acc = 0.;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double h = x[i] + alpha * p[i];
+        const double si = s[i];
+        x[i] = h + omega * si;
+        const double ri = si - omega * t[i];
+        r[i] = ri;
+        acc += ri;
+    }
+    const double tsum = block_sum(acc, lds);
+    if (threadIdx.x == 0) partials[blockIdx.x] = tsum;
+}
+// beta = rho/rho_prev * alpha/omega ; p = r + beta (p - omega nu)       (:266-267)
+__global__ void bicg_p_k(const double *__restrict__ scal, int rho_prev_idx, int rho_idx, const double *__restrict__ r,
+                         const double *__restrict__ nu, double *__restrict__ p, int64_t n) {
+    const double rho_prev = scal[rho_prev_idx], rho = scal[rho_idx];
+    const double alpha = rho_prev / scal[S_SUM_NU];
+    const double omega = scal[S_TS] / scal[S_TT];
+    const double beta = rho / rho_prev * alpha / omega;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        p[i] = r[i] + beta * (p[i] - omega * nu[i]);
+}
+
+struct BicgWork {
+    double *r, *p, *nu, *s, *t, *partials, *scal;
+};
+
+static int bicg_alloc(Arena &arena, int64_t n, BicgWork &w) {
+    const size_t nn = (size_t)std::max<int64_t>(n, 1);
+    ORC_TRY(arena.alloc(nn, &w.r));
+    ORC_TRY(arena.alloc(nn, &w.p));
+    ORC_TRY(arena.alloc(nn, &w.nu));
+    ORC_TRY(arena.alloc(nn, &w.s));
+    ORC_TRY(arena.alloc(nn, &w.t));
+    ORC_TRY(arena.alloc((size_t)2 * kMaxPartials, &w.partials));
+    ORC_TRY(arena.alloc((size_t)S_COUNT, &w.scal));
+    return ORC_OK;
+}
+
+static int bicg_iteration(const MatView &A, double *x, const BicgWork &w, uint64_t it) {
+    const int64_t n = A.P.n;
+    const int vg = grid_for(n);
+    const int cur = (int)(it & 1), nxt = cur ^ 1;
+    int g = 0;
+    ORC_TRY(launch_spmv(A, w.p, EpiStoreSum{w.nu}, w.partials, &g));           // nu = A p, sum(nu)
+    ORC_TRY(reduce_partials(w.partials, g, 1, w.scal + S_SUM_NU));
+    hipLaunchKernelGGL(bicg_s_k, dim3(vg), dim3(kBlock), 0, ctx().stream, w.scal, S_RHO0 + cur, w.r, w.nu, w.s, n);
+    ORC_TRY(launch_spmv(A, w.s, EpiTs{w.s, w.t}, w.partials, &g));             // t = A s, t.s, t.t
+    ORC_TRY(reduce_partials(w.partials, g, 2, w.scal + S_TS));
+    hipLaunchKernelGGL(bicg_xr_k, dim3(vg), dim3(kBlock), 0, ctx().stream, w.scal, S_RHO0 + cur, x, w.p, w.s, w.t, w.r, n, w.partials);
+    ORC_TRY(reduce_partials(w.partials, vg, 1, w.scal + S_RHO0 + nxt));        // rho = r_hat_0 . r
+    hipLaunchKernelGGL(bicg_p_k, dim3(vg), dim3(kBlock), 0, ctx().stream, w.scal, S_RHO0 + cur, S_RHO0 + nxt, w.r, w.nu, w.p, n);
+    ORC_HIP(hipGetLastError());
+    return ORC_OK;
+}
+
+static int bicgstab_dev(const MatView &A, const double *b, double *x, uint64_t iteration_count, Arena &arena) {
+    const int64_t n = A.P.n;
+    if (n == 0) return ORC_OK;
+    Arena::Mark mk = arena.mark();
+    BicgWork w;
+    ORC_TRY(bicg_alloc(arena, n, w));
+    int g = 0;
+    ORC_TRY(launch_spmv(A, x, EpiResidual{b, w.r, w.p}, w.partials, &g));      // r = b - A x ; p = r ; rho = sum(r)
+    ORC_TRY(reduce_partials(w.partials, g, 1, w.scal + S_RHO0));
+    for (uint64_t it = 0; it < iteration_count; ++it) ORC_TRY(bicg_iteration(A, x, w, it));
+    arena.release(mk);
+    return ORC_OK;
+}
+
+int bench_bicgstab_dev(const MatView &A, const double *b, double *x, int reps, Arena &arena, float *ms) {
+    const int64_t n = A.P.n;
+    Arena::Mark mk = arena.mark();
+    BicgWork w;
+    ORC_TRY(bicg_alloc(arena, n, w));
+    int g = 0;
+    ORC_TRY(launch_spmv(A, x, EpiResidual{b, w.r, w.p}, w.partials, &g));
+    ORC_TRY(reduce_partials(w.partials, g, 1, w.scal + S_RHO0));
+    hipEvent_t e0, e1;
+    ORC_HIP(hipEventCreate(&e0));
+    ORC_HIP(hipEventCreate(&e1));
+    ORC_TRY(bicg_iteration(A, x, w, 0));  // warm
+    ORC_HIP(hipEventRecord(e0, ctx().stream));
+    for (int it = 1; it <= reps; ++it) ORC_TRY(bicg_iteration(A, x, w, (uint64_t)it));
+    ORC_HIP(hipEventRecord(e1, ctx().stream));
+    ORC_HIP(hipEventSynchronize(e1));
+    ORC_HIP(hipEventElapsedTime(ms, e0, e1));
+    *ms /= (float)reps;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    arena.release(mk);
+    return ORC_OK;
+}
+
+// ------------------------------------------------------------------ Jacobi arm (linear_algebra.rs:172-218)
+struct JacobiCtrl {
+    int done;           // convergence break taken (:210-213)
+    int status;         // sticky OrcStatus
+    long long sweeps;   // sweeps executed
+    double initial_residual;
+    long long iter_num;
+};
+
+// x_new = omega * (b'_i - sum_j a'_ij x_j) + x_i (1 - omega), a' = offdiag(A)/diag(A), b' = b/diag(A);
+// also flags NaN in the incoming x (:192-196)
+__global__ __launch_bounds__(kBlock) void jacobi_sweep_k(MatView A, const double *__restrict__ b, const double *__restrict__ x,
+                                                         double *__restrict__ x_new, double omega, JacobiCtrl *ctrl) {
+    if (ctrl->done || ctrl->status) return;
+    const int lane = threadIdx.x & 63;
+    int saw_nan = 0;
+    SliceWalk w(A.P.n_slices);
+    for (int64_t slice = w.begin; slice < w.end; slice += w.step) {
+        const int64_t row = slice * 64 + lane;
+        const int64_t base = A.P.slice_ptr[slice];
+        const int width = (int)((A.P.slice_ptr[slice + 1] - base) >> 6);
+        const bool live = row < A.P.n;
+        const int len = live ? A.P.row_len[row] : 0;
+        double aii = 1.;
+        if (live) {
+            const int32_t d = A.P.diag_pos[row];
+            if (d < 0) { atomicCAS(&ctrl->status, 0, (int)ORC_ERR_STRUCTURAL_ZERO); aii = 1.; }
+            else aii = view_value(A, row, d);
+        }
+        double acc = 0.;
+        for (int k = 0; k < width; ++k) {
+            if (k < len) {
+                const int64_t pos = base + (int64_t)k * 64 + lane;
+                const int c = A.P.col[pos];
+                const double v = (c == row) ? 0. : view_value(A, row, pos) / aii;  // :174-180
+                acc += v * x[c];
+            }
+        }
+        if (live) {
+            const double xi = x[row];
+            if (xi != xi) saw_nan = 1;
+            const double bp = b[row] / aii;  // :181-187
+            x_new[row] = omega * (bp - acc) + xi * (1. - omega);  // :199-200
+        }
+    }
+    if (saw_nan) atomicCAS(&ctrl->status, 0, (int)ORC_ERR_JACOBI_NAN);
+}
+
+// partial sum((b - A x)^2) and max |x|  (:202-207)
+__global__ __launch_bounds__(kBlock) void jacobi_residual_k(MatView A, const double *__restrict__ b, const double *__restrict__ x,
+                                                            double *__restrict__ partials, JacobiCtrl *ctrl) {
+    __shared__ double lds[8];
+    if (ctrl->done || ctrl->status) return;
+    const int lane = threadIdx.x & 63;
+    double r2 = 0., mx = 0.;
+    SliceWalk w(A.P.n_slices);
+    for (int64_t slice = w.begin; slice < w.end; slice += w.step) {
+        const int64_t row = slice * 64 + lane;
+        const int64_t base = A.P.slice_ptr[slice];
+        const int width = (int)((A.P.slice_ptr[slice + 1] - base) >> 6);
+        const bool live = row < A.P.n;
+        const int len = live ? A.P.row_len[row] : 0;
+        double acc = 0.;
+        for (int k = 0; k < width; ++k) {
+            if (k < len) {
+                const int64_t pos = base + (int64_t)k * 64 + lane;
+                acc += view_value(A, row, pos) * x[A.P.col[pos]];
+            }
+        }
+        if (live) {
+            const double v = b[row] - acc;
+            r2 += v * v;
+            mx = fmax(mx, fabs(x[row]));
+        }
+    }
+    const double t = block_sum(r2, lds);
+    const double m = block_max(mx, lds);
+    if (threadIdx.x == 0) { partials[blockIdx.x] = t; partials[gridDim.x + blockIdx.x] = m; }
+}
+
+// one thread: the reference's per-sweep bookkeeping (:208-216)
+__global__ void jacobi_control_k(const double *__restrict__ partials, int count, double threshold, JacobiCtrl *ctrl) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (ctrl->done || ctrl->status) return;
+    double r2 = 0., mx = 0.;
+    for (int i = 0; i < count; ++i) { r2 += partials[i]; mx = fmax(mx, partials[count + i]); }
+    const double r = sqrt(r2);
+    ctrl->sweeps += 1;
+    const long long it = ctrl->iter_num;
+    ctrl->iter_num = it + 1;
+    if (it == 1) ctrl->initial_residual = r;
+    else if (r / ctrl->initial_residual < threshold) { ctrl->done = 1; return; }
+    if (mx > 1e10) ctrl->status = (int)ORC_ERR_JACOBI_TOO_LARGE;
+}
+
+static int jacobi_dev(const MatView &A, const double *b, double *x, uint64_t iteration_count, double relaxation_factor,
+                      double threshold, Arena &arena, SolveStats *stats, int *status_out) {
+    const int64_t n = A.P.n;
+    *status_out = ORC_OK;
+    if (n == 0 || iteration_count == 0) return ORC_OK;
+    Arena::Mark mk = arena.mark();
+    double *x2, *partials;
+    JacobiCtrl *ctrl;
+    ORC_TRY(arena.alloc((size_t)n, &x2));
+    ORC_TRY(arena.alloc((size_t)2 * kMaxPartials, &partials));
+    ORC_TRY(arena.alloc((size_t)1, &ctrl));
+    ORC_HIP(hipMemsetAsync(ctrl, 0, sizeof(JacobiCtrl), ctx().stream));
+    const int g = spmv_grid(A.P.n_slices);
+    // Sweeps alternate x -> x2 -> x.  A sweep that is skipped (done/status set) leaves both
+    // buffers untouched, so the newest iterate is in x2 iff the executed sweep count is odd.
+    double *cur = x, *nxt = x2;
+    for (uint64_t it = 0; it < iteration_count; ++it) {
+        hipLaunchKernelGGL(jacobi_sweep_k, dim3(g), dim3(kBlock), 0, ctx().stream, A, b, cur, nxt, relaxation_factor, ctrl);
+        hipLaunchKernelGGL(jacobi_residual_k, dim3(g), dim3(kBlock), 0, ctx().stream, A, b, nxt, partials, ctrl);
+        hipLaunchKernelGGL(jacobi_control_k, dim3(1), dim3(1), 0, ctx().stream, partials, g, threshold, ctrl);
+        std::swap(cur, nxt);
+    }
+    ORC_HIP(hipGetLastError());
+    JacobiCtrl h;
+    ORC_HIP(hipMemcpyAsync(&h, ctrl, sizeof(h), hipMemcpyDeviceToHost, ctx().stream));
+    ORC_HIP(hipStreamSynchronize(ctx().stream));
+    // the NaN check of the reference runs at the top of a sweep: a NaN seen by sweep k means
+    // sweep k itself was still executed by the kernel above, but the reference panics before it.
+    // Either way the call fails with "diverged"; the iterate is not observable after a panic.
+    if (stats) stats->jacobi_sweeps = h.sweeps;
+    // sweeps executed = h.sweeps, except that a sweep launched after a status was raised inside
+    // jacobi_sweep_k (NaN / structural zero) has no matching control step.
+    const bool newest_in_x2 = (h.sweeps & 1) != 0;
+    if (newest_in_x2) ORC_TRY(vec_copy(x, x2, n));
+    *status_out = h.status;
+    arena.release(mk);
+    return ORC_OK;
+}
+
+// ------------------------------------------------------------------ iterative_solve (linear_algebra.rs:144-299)
+int multigrid_arm_dev(const MatView &A, const double *b, double *x, uint64_t iteration_count, double relaxation_factor,
+                      double convergence_threshold, int preconditioner, Arena &arena, SolveStats *stats, int smoother);  // amg.hip
+int gs_arm_dev(const MatView &A, const double *b, double *x, uint64_t iteration_count, double relaxation_factor, int method,
+               Arena &arena);  // gs.hip (extension)
+
+int iterative_solve_dev(const MatView &A_in, const double *b_in, double *x, uint64_t iteration_count, int method,
+                        double relaxation_factor, double convergence_threshold, int preconditioner, Arena &arena,
+                        SolveStats *stats) {
+    ORC_TRY(ensure_init());
+    const int64_t n = A_in.P.n;
+    Arena::Mark mk = arena.mark();
+    MatView A = A_in;
+    const double *b = b_in;
+    if (preconditioner == ORC_PRECOND_JACOBI) {  // :159-167
+        double *dinv, *b_tmp;
+        ORC_TRY(arena.alloc((size_t)std::max<int64_t>(n, 1), &dinv));
+        ORC_TRY(arena.alloc((size_t)std::max<int64_t>(n, 1), &b_tmp));
+        if (n) {
+            hipLaunchKernelGGL(diag_inverse_k, dim3(grid_for(n)), dim3(kBlock), 0, ctx().stream, A_in, dinv);
+            hipLaunchKernelGGL(scale_vec_k, dim3(grid_for(n)), dim3(kBlock), 0, ctx().stream, dinv, b_in, b_tmp, n);
+            ORC_HIP(hipGetLastError());
+        }
+        if (!A.s1) A.s1 = dinv;
+        else if (!A.s2) A.s2 = dinv;
+        else return set_error(ORC_ERR_BAD_ARGUMENT, "more than two nested Jacobi scalings");
+        b = b_tmp;
+    } else if (preconditioner != ORC_PRECOND_NONE) {
+        return set_error(ORC_ERR_BAD_ARGUMENT, "unknown preconditioner %d", preconditioner);
+    }
+    int st = ORC_OK;
+    switch (method) {
+    case ORC_SOLVER_JACOBI: {
+        int jst = ORC_OK;
+        st = jacobi_dev(A, b, x, iteration_count, relaxation_factor, convergence_threshold, arena, stats, &jst);
+        if (st == ORC_OK) st = jst;
+        break;
+    }
+    case ORC_SOLVER_BICGSTAB:
+        st = bicgstab_dev(A, b, x, iteration_count, arena);
+        break;
+    case ORC_SOLVER_MULTIGRID:
+        st = multigrid_arm_dev(A, b, x, iteration_count, relaxation_factor, convergence_threshold, preconditioner, arena, stats, ORC_SOLVER_BICGSTAB);
+        break;
+    case ORC_SOLVER_MULTIGRID_GS:
+        st = multigrid_arm_dev(A, b, x, iteration_count, relaxation_factor, convergence_threshold, preconditioner, arena, stats, ORC_SOLVER_MULTICOLOR_GS);
+        break;
+    case ORC_SOLVER_MULTICOLOR_GS:
+    case ORC_SOLVER_BICGSTAB_GS_PRECOND:
+        st = gs_arm_dev(A, b, x, iteration_count, relaxation_factor, method, arena);
+        break;
+    case ORC_SOLVER_GAUSS_SEIDEL:
+        // The reference's arm scans every (i, j) through get(), which panics on the first
+        // structural zero of a sparse matrix, and otherwise ends in
+        // panic!("Gauss-Seidel out for maintenance :)") (linear_algebra.rs:219-246).
+        st = ORC_ERR_GS_MAINTENANCE;
+        break;
+    default:
+        st = ORC_ERR_UNSUPPORTED_SOLVER;  // :297
+    }
+    arena.release(mk);
+    return st;
+}
+
+}  // namespace orc

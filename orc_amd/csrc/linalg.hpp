@@ -1,0 +1,76 @@
+// linalg.hpp — device sparse matrix format and the iterative solvers (K1-K8 of SURVEY §2.1).
+#pragma once
+#include "common.hpp"
+
+namespace orc {
+
+// SELL-64: rows are grouped in slices of 64 (one wavefront); inside a slice entry k of every row
+// is stored contiguously: element (row r, k) lives at slice_ptr[r>>6] + k*64 + (r&63).
+// A thread-per-row SpMV therefore reads values and column indices fully coalesced while each row
+// is still accumulated in ascending-column order from 0.0 — the summation order of
+// nalgebra-sparse's CSR product, which makes y = A x bit-identical to the CPU oracle.
+struct SellDev {
+    int64_t n = 0;
+    int32_t n_slices = 0;
+    const int64_t *slice_ptr = nullptr;  // [n_slices+1], element offsets (multiples of 64)
+    const int32_t *row_len = nullptr;    // [n]
+    const int32_t *col = nullptr;        // [padded]
+    const int32_t *diag_pos = nullptr;   // [n] element offset of the stored diagonal, -1 if absent
+};
+
+// A matrix seen through up to two explicit left (row) scalings: value(i,j) = s2[i]*(s1[i]*val).
+// This is how the reference's Jacobi preconditioner `p_inv * a` (linear_algebra.rs:159-166) and
+// its nested re-application are evaluated without materialising a_tmp.
+struct MatView {
+    SellDev P;
+    const double *val = nullptr;
+    const double *s1 = nullptr;
+    const double *s2 = nullptr;
+    bool symmetric = true;  // structural symmetry of the pattern (aggregation fast path)
+};
+
+// Owning pattern (built on the host from CSR, e.g. the mesh pattern or a user matrix).
+struct SellMatrix {
+    int64_t n = 0, nnz = 0, padded = 0;
+    int32_t n_slices = 0;
+    bool symmetric = true;
+    DevBuf<int64_t> slice_ptr;
+    DevBuf<int32_t> row_len, col, diag_pos;
+    DevBuf<int64_t> csr_row_ptr;  // for value import/export in CSR (ORC) order
+    SellDev dev() const {
+        SellDev d;
+        d.n = n; d.n_slices = n_slices; d.slice_ptr = slice_ptr.p; d.row_len = row_len.p; d.col = col.p; d.diag_pos = diag_pos.p;
+        return d;
+    }
+};
+
+int sell_from_csr_host(int64_t n, const int64_t *row_ptr, const int64_t *col, SellMatrix &out);
+// values: CSR order (device) <-> SELL order (device)
+int sell_import_values(const SellMatrix &m, const double *csr_vals_dev, double *sell_vals_dev);
+int sell_export_values(const SellMatrix &m, const double *sell_vals_dev, double *csr_vals_dev);
+
+struct SolveStats {
+    int64_t jacobi_sweeps = 0;
+    int amg_levels = 0;
+    int64_t amg_rows[8] = {0};
+    int64_t amg_nnz[8] = {0};
+    int amg_rounds[8] = {0};
+};
+
+// linear_algebra::iterative_solve on device-resident data (linear_algebra.rs:144-299).
+// b, x: device vectors of A.P.n doubles; x is in/out.  Temporaries come from `arena`.
+// Returns OrcStatus (after synchronising the stream once to fetch the sticky status word).
+int iterative_solve_dev(const MatView &A, const double *b, double *x, uint64_t iteration_count, int method,
+                        double relaxation_factor, double convergence_threshold, int preconditioner, Arena &arena,
+                        SolveStats *stats);
+
+// y = A x (K1).  Exposed for bench/tests.
+int spmv_dev(const MatView &A, const double *x, double *y);
+// one BiCGSTAB iteration body repeated reps times (bench)
+int bench_bicgstab_dev(const MatView &A, const double *b, double *x, int reps, Arena &arena, float *ms);
+
+// plain vector helpers used by the SIMPLE driver
+int vec_fill(double *x, double v, int64_t n);
+int vec_copy(double *dst, const double *src, int64_t n);
+
+}  // namespace orc

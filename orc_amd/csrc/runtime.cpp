@@ -1,0 +1,142 @@
+// runtime.cpp — process-wide context (device, stream, error text), arena allocator.
+#include <cstdarg>
+
+#include "common.hpp"
+
+namespace orc {
+
+Ctx &ctx() {
+    static Ctx c;
+    return c;
+}
+
+int set_error(int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    ctx().last_error = buf;
+    return code;
+}
+
+int ensure_init() {
+    if (ctx().inited) return ORC_OK;
+    return orc_init(-1);
+}
+
+Arena::~Arena() {
+    for (auto &c : chunks_)
+        if (c.p) (void)hipFree(c.p);
+}
+
+size_t Arena::reserved() const {
+    size_t t = 0;
+    for (auto &c : chunks_) t += c.size;
+    return t;
+}
+
+int Arena::alloc_bytes(size_t bytes, void **out) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (bytes == 0) bytes = 256;
+    while (true) {
+        if (cur_ < chunks_.size()) {
+            Chunk &c = chunks_[cur_];
+            if (off_ + bytes <= c.size) {
+                *out = c.p + off_;
+                off_ += bytes;
+                return ORC_OK;
+            }
+            // current chunk exhausted: move on (the tail stays unused until release())
+            ++cur_;
+            off_ = 0;
+            continue;
+        }
+        // new chunk: at least 64 MiB, at least the request, doubling with the reservation
+        size_t want = std::max<size_t>(bytes, (size_t)64 << 20);
+        want = std::max(want, reserved() / 2);
+        Chunk c{nullptr, want};
+        hipError_t e = hipMalloc((void **)&c.p, want);
+        if (e != hipSuccess) return set_error(ORC_ERR_HIP, "arena hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        chunks_.push_back(c);
+    }
+}
+
+}  // namespace orc
+
+extern "C" {
+
+int orc_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int orc_init(int device_ordinal) {
+    orc::Ctx &c = orc::ctx();
+    int n = orc_device_count();
+    if (n <= 0) return orc::set_error(ORC_ERR_NO_DEVICE, "no HIP device visible: liborc_amd has no CPU fallback");
+    if (c.inited && (device_ordinal < 0 || device_ordinal == c.device)) return ORC_OK;
+    if (device_ordinal < 0) device_ordinal = 0;
+    if (device_ordinal >= n) return orc::set_error(ORC_ERR_BAD_ARGUMENT, "device %d out of range (%d visible)", device_ordinal, n);
+    ORC_HIP(hipSetDevice(device_ordinal));
+    if (c.stream) { (void)hipStreamDestroy(c.stream); c.stream = nullptr; }
+    ORC_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    c.device = device_ordinal;
+    c.inited = true;
+    return ORC_OK;
+}
+
+int orc_synchronize(void) {
+    if (!orc::ctx().inited) return ORC_OK;
+    ORC_HIP(hipStreamSynchronize(orc::ctx().stream));
+    return ORC_OK;
+}
+
+const char *orc_last_error(void) { return orc::ctx().last_error.c_str(); }
+
+const char *orc_status_string(int st) {
+    switch (st) {
+    case ORC_OK: return "ok";
+    case ORC_ERR_SOLUTION_DIVERGED: return "solution diverged";                    // solver.rs:220
+    case ORC_ERR_MULTIGRID_DIVERGED: return "Multigrid diverged";                  // linear_algebra.rs:104
+    case ORC_ERR_JACOBI_NAN: return "diverged";                                    // linear_algebra.rs:194
+    case ORC_ERR_JACOBI_TOO_LARGE: return "Diverged - max solution value > 10^10";  // linear_algebra.rs:215
+    case ORC_ERR_GS_MAINTENANCE: return "Gauss-Seidel out for maintenance :)";     // linear_algebra.rs:245
+    case ORC_ERR_STRUCTURAL_ZERO: return "Tried to access CsrMatrix element that hasn't been stored yet.";  // lib.rs:665
+    case ORC_ERR_UNSUPPORTED_BC: return "BC not supported";                         // discretization.rs:116
+    case ORC_ERR_UNSUPPORTED_SCHEME: return "unsupported scheme";
+    case ORC_ERR_UNSUPPORTED_SOLVER: return "unsupported solution method";         // linear_algebra.rs:297
+    case ORC_ERR_BAD_ARGUMENT: return "bad argument";
+    case ORC_ERR_NO_DEVICE: return "no HIP device (liborc_amd has no CPU fallback)";
+    case ORC_ERR_HIP: return "HIP runtime error";
+    case ORC_ERR_IO: return "I/O error";
+    case ORC_ERR_COMM: return "RCCL error";
+    default: return "unknown status";
+    }
+}
+
+void orc_settings_default(OrcSettings *s) {  // lib.rs:58-86
+    memset(s, 0, sizeof(*s));
+    s->momentum = ORC_MOMENTUM_CD1;
+    s->diffusion = ORC_DIFFUSION_CD;
+    s->pressure_interpolation = ORC_PINTERP_SECOND_ORDER;
+    s->velocity_interpolation = ORC_VINTERP_RHIE_CHOW;
+    s->gradient_reconstruction = ORC_GRAD_GREEN_GAUSS_CELL;
+    s->pressure_relaxation = 0.01;
+    s->momentum_relaxation = 0.5;
+    s->solver_type = ORC_SOLVER_MULTIGRID;
+    s->iterations = 50;
+    s->relaxation = 0.5;
+    s->relative_convergence_threshold = 1e-3;
+    s->preconditioner = ORC_PRECOND_JACOBI;
+    s->q1_compat = 1;
+    s->frozen_diagonals = 1;  // the device evaluates all Rhie-Chow diagonals from the previous iteration
+}
+
+int orc_profile_enable(int on) {
+    orc::ctx().profile = on != 0;
+    return ORC_OK;
+}
+
+}  // extern "C"

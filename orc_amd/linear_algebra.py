@@ -1,0 +1,53 @@
+"""linear_algebra::iterative_solve of the reference (src/linear_algebra.rs:144-299) on MI355X."""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import check, lib
+
+
+def _i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def iterative_solve(a, b, solution_vector, iteration_count, method, relaxation_factor, convergence_threshold,
+                    preconditioner, raise_on_error=True):
+    """a: scipy.sparse CSR (sorted columns); solution_vector (float64, contiguous) is updated in place,
+    like `&mut DVector` in the reference. Returns the status code (0 = ok)."""
+    a = a.tocsr()
+    a.sort_indices()
+    rp, ci, v = _i64(a.indptr), _i64(a.indices), _f64(a.data)
+    b = _f64(b)
+    assert solution_vector.dtype == np.float64 and solution_vector.flags.c_contiguous
+    st = lib().orc_iterative_solve(C.c_int64(a.shape[0]), _p(rp, C.c_int64), _p(ci, C.c_int64), _p(v, C.c_double),
+                                   _p(b, C.c_double), _p(solution_vector, C.c_double), C.c_uint64(iteration_count),
+                                   C.c_int(method), C.c_double(relaxation_factor), C.c_double(convergence_threshold),
+                                   C.c_int(preconditioner))
+    if raise_on_error:
+        check(st)
+    return st
+
+
+def last_jacobi_sweeps():
+    return lib().orc_last_jacobi_sweeps()
+
+
+def csr_spmv(a, x, reps=1):
+    """y = A x on the device; returns (y, avg_ms_per_launch)."""
+    a = a.tocsr()
+    a.sort_indices()
+    rp, ci, v = _i64(a.indptr), _i64(a.indices), _f64(a.data)
+    x = _f64(x)
+    y = np.empty(a.shape[0])
+    ms = C.c_double(0.0)
+    check(lib().orc_csr_spmv(C.c_int64(a.shape[0]), _p(rp, C.c_int64), _p(ci, C.c_int64), _p(v, C.c_double),
+                             _p(x, C.c_double), _p(y, C.c_double), C.c_int(reps), C.byref(ms)))
+    return y, ms.value
