@@ -61,6 +61,9 @@ int orc_iterative_solve(int64_t n, const int64_t *row_ptr, const int64_t *col_id
                         const double *b, double *solution_vector /*in/out*/, uint64_t iteration_count,
                         int method /*OrcSolutionMethod*/, double relaxation_factor, double convergence_threshold,
                         int preconditioner /*OrcPreconditionMethod*/);
+/* Process-wide default of OrcSettings.breakdown_guard for orc_iterative_solve (whose signature has no
+ * settings argument, like the reference's).  1 (default) = guard on; 0 = NaN like the reference. */
+int orc_set_breakdown_guard(int on);
 /* sweeps the Jacobi arm executed in the last orc_iterative_solve (linear_algebra.rs:188-217) */
 int64_t orc_last_jacobi_sweeps(void);
 /* y = A x: the `&CsrMatrix * &DVector` product the reference takes from nalgebra-sparse

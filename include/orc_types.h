@@ -127,7 +127,10 @@ typedef struct OrcSettings {
     double relative_convergence_threshold; /* default 1e-3 (lib.rs:82) */
     int32_t frozen_diagonals;        /* 0 = reference's in-place (order dependent) diagonal reads — oracle only;
                                         1 = all Rhie-Chow reads see last iteration's diagonals (what the device computes) */
-    int32_t reserved;
+    int32_t breakdown_guard;         /* new-build extension, default 1: BiCGSTAB stops updating x when a denominator of its
+                                        recurrences (rho, r_hat.nu, t.t, omega) is exactly 0 or non-finite — the only cases
+                                        in which the reference (no guard, linear_algebra.rs:255-268) yields NaN and panics
+                                        "solution diverged".  0 = reference behaviour (NaN propagates). */
 } OrcSettings;
 
 #ifdef __cplusplus

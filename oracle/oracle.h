@@ -80,6 +80,7 @@ OrCsr *or_transpose(const OrCsr *a);
 double or_dot(const double *a, const double *b, int64_t n);
 double or_norm(const double *a, int64_t n);
 double or_sum(const double *a, int64_t n);
+void or_set_dot_mode(int mode); /* diagnostic: 1 = pairwise association (tests only) */
 
 /* ---- mesh_io.c ---- */
 OrMesh *or_read_mesh(const char *path);  /* io.rs:32-515 */

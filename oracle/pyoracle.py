@@ -28,7 +28,7 @@ class Settings(C.Structure):
         ("solver_type", C.c_int32), ("preconditioner", C.c_int32), ("q1_compat", C.c_int32),
         ("iterations", C.c_uint64), ("momentum_relaxation", C.c_double), ("pressure_relaxation", C.c_double),
         ("relaxation", C.c_double), ("relative_convergence_threshold", C.c_double),
-        ("frozen_diagonals", C.c_int32), ("reserved", C.c_int32),
+        ("frozen_diagonals", C.c_int32), ("breakdown_guard", C.c_int32),
     ]
 
 
@@ -215,6 +215,11 @@ def iterative_solve(a, b, x, iteration_count, method, relaxation_factor, converg
     return lib().or_iterative_solve(a.ptr, _dp(b), _dp(x), C.c_uint64(iteration_count), C.c_int(method),
                                     C.c_double(relaxation_factor), C.c_double(convergence_threshold),
                                     C.c_int(preconditioner))
+
+
+def set_dot_mode(mode):
+    """diagnostic: 1 = pairwise association of every dot/norm (measures a run's sensitivity to it)"""
+    lib().or_set_dot_mode(C.c_int(mode))
 
 
 def status_string(st):

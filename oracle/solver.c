@@ -25,6 +25,7 @@ void or_settings_default(OrcSettings *s) { /* lib.rs:58-86 */
     s->preconditioner = ORC_PRECOND_JACOBI;
     s->q1_compat = 1;
     s->frozen_diagonals = 0;
+    s->breakdown_guard = 0; /* the oracle IS the reference: no guard */
 }
 
 const char *or_status_string(int st) {

@@ -179,7 +179,23 @@ OrCsr *or_transpose(const OrCsr *a) {
     return t;
 }
 
+/* Diagnostic switch (tests only): 1 = pairwise (tree) association instead of nalgebra's.  Used to
+ * measure how sensitive a reference run is to the association of its dot products, which is the
+ * only freedom a parallel reduction takes. */
+static int g_dot_mode = 0;
+void or_set_dot_mode(int mode) { g_dot_mode = mode; }
+static double dot_pairwise(const double *a, const double *b, int64_t n) {
+    if (n <= 8) {
+        double s = 0.;
+        for (int64_t i = 0; i < n; i++) s += a[i] * b[i];
+        return s;
+    }
+    int64_t h = n / 2;
+    return dot_pairwise(a, b, h) + dot_pairwise(a + h, b + h, n - h);
+}
+
 double or_dot(const double *a, const double *b, int64_t n) {
+    if (g_dot_mode == 1) return dot_pairwise(a, b, n);
     double res = 0.;
     double acc0 = 0., acc1 = 0., acc2 = 0., acc3 = 0., acc4 = 0., acc5 = 0., acc6 = 0., acc7 = 0.;
     int64_t i = 0;

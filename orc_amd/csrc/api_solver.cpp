@@ -1,0 +1,321 @@
+// api_solver.cpp — C ABI for mesh::Mesh, discretization::* and solver::solve_steady.
+#include <algorithm>
+#include <chrono>
+#include <memory>
+
+#include "assembly.hpp"
+
+using namespace orc;
+
+namespace {
+
+int upload_csr_values(OrcMesh &m, const double *host_vals, DevBuf<double> &sell, DevBuf<double> &tmp) {
+    ORC_TRY(tmp.upload(host_vals, (size_t)m.pat.nnz));
+    return sell_import_values(m.pat, tmp.p, sell.p);
+}
+
+int download_csr_values(OrcMesh &m, const DevBuf<double> &sell, double *host_vals, DevBuf<double> &tmp) {
+    ORC_TRY(tmp.ensure((size_t)m.pat.nnz));
+    ORC_TRY(sell_export_values(m.pat, sell.p, tmp.p));
+    return tmp.download(host_vals, (size_t)m.pat.nnz);
+}
+
+}  // namespace
+
+extern "C" {
+
+OrcMesh *orc_mesh_create(int64_t n_cells, int64_t n_faces, int32_t n_zones, const int64_t *face_c0, const int64_t *face_c1,
+                         const int32_t *face_zone, const double *face_area, const double *face_normal, const double *face_centroid,
+                         const double *cell_centroid, const double *cell_volume, const int64_t *cell_face_ptr,
+                         const int64_t *cell_faces, const int32_t *zone_type, const double *zone_scalar, const double *zone_vector,
+                         int *status) {
+    int st = ensure_init();
+    OrcMesh *m = nullptr;
+    if (st == ORC_OK) {
+        m = new OrcMesh();
+        st = mesh_upload(*m, n_cells, n_faces, n_zones, face_c0, face_c1, face_zone, face_area, face_normal, face_centroid,
+                         cell_centroid, cell_volume, cell_face_ptr, cell_faces, zone_type, zone_scalar, zone_vector);
+        if (st != ORC_OK) { delete m; m = nullptr; }
+    }
+    if (status) *status = st;
+    return m;
+}
+
+int orc_mesh_update_zones(OrcMesh *m, const int32_t *zone_type, const double *zone_scalar, const double *zone_vector) {
+    if (!m) return set_error(ORC_ERR_BAD_ARGUMENT, "null mesh");
+    ORC_TRY(m->ztype.upload(zone_type, (size_t)m->n_zones));
+    ORC_TRY(m->zscal.upload(zone_scalar, (size_t)m->n_zones));
+    ORC_TRY(m->zvec.upload(zone_vector, (size_t)3 * m->n_zones));
+    return ORC_OK;
+}
+
+void orc_mesh_destroy(OrcMesh *m) { delete m; }
+int64_t orc_mesh_n_cells(const OrcMesh *m) { return m ? m->n_cells : 0; }
+int64_t orc_mesh_nnz(const OrcMesh *m) { return m ? m->pat.nnz : 0; }
+
+int orc_mesh_matrix_pattern(const OrcMesh *m, int64_t *row_ptr, int64_t *col_idx) {
+    if (!m) return set_error(ORC_ERR_BAD_ARGUMENT, "null mesh");
+    std::copy(m->h_row_ptr.begin(), m->h_row_ptr.end(), row_ptr);
+    std::copy(m->h_col.begin(), m->h_col.end(), col_idx);
+    return ORC_OK;
+}
+
+// ---------------------------------------------------------------- device-resident solver
+OrcSolver *orc_solver_create(OrcMesh *m, const OrcSettings *settings, double rho, double mu, int *status) {
+    int st = ORC_OK;
+    OrcSolver *s = nullptr;
+    if (!m || !settings) st = set_error(ORC_ERR_BAD_ARGUMENT, "null argument");
+    if (st == ORC_OK) {
+        s = new OrcSolver();
+        st = solver_init(s->st, m, settings, rho, mu);
+        if (st != ORC_OK) { delete s; s = nullptr; }
+    }
+    if (status) *status = st;
+    return s;
+}
+
+void orc_solver_destroy(OrcSolver *s) { delete s; }
+
+int orc_solver_set_fields(OrcSolver *s, const double *u, const double *v, const double *w, const double *p) {
+    if (!s) return set_error(ORC_ERR_BAD_ARGUMENT, "null solver");
+    const size_t n = (size_t)s->st.n;
+    ORC_TRY(s->st.u.upload(u, n));
+    ORC_TRY(s->st.v.upload(v, n));
+    ORC_TRY(s->st.w.upload(w, n));
+    ORC_TRY(s->st.p.upload(p, n));
+    return ORC_OK;
+}
+
+int orc_solver_get_fields(OrcSolver *s, double *u, double *v, double *w, double *p) {
+    if (!s) return set_error(ORC_ERR_BAD_ARGUMENT, "null solver");
+    const size_t n = (size_t)s->st.n;
+    ORC_TRY(s->st.u.download(u, n));
+    ORC_TRY(s->st.v.download(v, n));
+    ORC_TRY(s->st.w.download(w, n));
+    ORC_TRY(s->st.p.download(p, n));
+    return ORC_OK;
+}
+
+int orc_solver_iterate(OrcSolver *s, uint64_t iterations, double *report) {
+    if (!s) return set_error(ORC_ERR_BAD_ARGUMENT, "null solver");
+    return solver_iterate(s->st, iterations, report);
+}
+
+int orc_solver_assemble_momentum(OrcSolver *s, double *a_u, double *a_v, double *a_w, double *b_u, double *b_v, double *b_w,
+                                 double peclet[3]) {
+    if (!s) return set_error(ORC_ERR_BAD_ARGUMENT, "null solver");
+    SolverState &t = s->st;
+    const bool tvd = t.settings.momentum >= ORC_MOMENTUM_TVD_LUD;
+    ORC_TRY(k_gradients(t, tvd));
+    ORC_TRY(k_face_flux(t, true));
+    double pe[3];
+    ORC_TRY(k_momentum(t, pe));
+    if (peclet) { peclet[0] = pe[0]; peclet[1] = pe[1]; peclet[2] = pe[2]; }
+    DevBuf<double> tmp;
+    const size_t n = (size_t)t.n;
+    if (a_u) ORC_TRY(download_csr_values(*t.mesh, t.a_u, a_u, tmp));
+    if (a_v) ORC_TRY(download_csr_values(*t.mesh, t.a_v, a_v, tmp));
+    if (a_w) ORC_TRY(download_csr_values(*t.mesh, t.a_w, a_w, tmp));
+    if (b_u) ORC_TRY(t.b_u.download(b_u, n));
+    if (b_v) ORC_TRY(t.b_v.download(b_v, n));
+    if (b_w) ORC_TRY(t.b_w.download(b_w, n));
+    return fetch_status(t);
+}
+
+int orc_solver_assemble_pressure(OrcSolver *s, double *a_p, double *b_p) {
+    if (!s) return set_error(ORC_ERR_BAD_ARGUMENT, "null solver");
+    SolverState &t = s->st;
+    ORC_TRY(k_gradients(t, false));
+    ORC_TRY(k_pressure_correction(t));
+    DevBuf<double> tmp;
+    if (a_p) ORC_TRY(download_csr_values(*t.mesh, t.a_p, a_p, tmp));
+    if (b_p) ORC_TRY(t.b_p.download(b_p, (size_t)t.n));
+    return fetch_status(t);
+}
+
+// ---------------------------------------------------------------- discretization::* with host arrays
+int orc_build_momentum_diffusion_matrix(const OrcMesh *m, int diffusion_scheme, double mu, double *a_values, double *b_u,
+                                        double *b_v, double *b_w) {
+    if (!m) return set_error(ORC_ERR_BAD_ARGUMENT, "null mesh");
+    OrcSettings st;
+    orc_settings_default(&st);
+    st.diffusion = diffusion_scheme;
+    auto s = std::make_unique<OrcSolver>();
+    ORC_TRY(solver_init(s->st, const_cast<OrcMesh *>(m), &st, 1.0, mu));
+    DevBuf<double> tmp;
+    ORC_TRY(download_csr_values(*s->st.mesh, s->st.a_di, a_values, tmp));
+    const size_t n = (size_t)m->n_cells;
+    ORC_TRY(s->st.b_u_di.download(b_u, n));
+    ORC_TRY(s->st.b_v_di.download(b_v, n));
+    ORC_TRY(s->st.b_w_di.download(b_w, n));
+    return ORC_OK;
+}
+
+int orc_initialize_momentum_matrix(const OrcMesh *m, double *a_values) {
+    if (!m) return set_error(ORC_ERR_BAD_ARGUMENT, "null mesh");
+    OrcSettings st;
+    orc_settings_default(&st);
+    auto s = std::make_unique<OrcSolver>();
+    ORC_TRY(solver_init(s->st, const_cast<OrcMesh *>(m), &st, 1.0, 1.0));
+    DevBuf<double> tmp;
+    return download_csr_values(*s->st.mesh, s->st.a_u, a_values, tmp);
+}
+
+int orc_build_momentum_advection_matrices(const OrcMesh *m, double *a_u_values, double *a_v_values, double *a_w_values, double *b_u,
+                                          double *b_v, double *b_w, const double *a_di_values, const double *u, const double *v,
+                                          const double *w, const double *p, const OrcSettings *settings, double rho,
+                                          double peclet[3]) {
+    if (!m || !settings) return set_error(ORC_ERR_BAD_ARGUMENT, "null argument");
+    auto s = std::make_unique<OrcSolver>();
+    SolverState &t = s->st;
+    ORC_TRY(solver_init(t, const_cast<OrcMesh *>(m), settings, rho, 1.0));
+    DevBuf<double> tmp;
+    // a_di, and the incoming a_u/a_v/a_w whose diagonals Rhie-Chow reads (solver.rs:1068-1081)
+    ORC_TRY(upload_csr_values(*t.mesh, a_di_values, t.a_di, tmp));
+    ORC_TRY(upload_csr_values(*t.mesh, a_u_values, t.a_u, tmp));
+    ORC_TRY(upload_csr_values(*t.mesh, a_v_values, t.a_v, tmp));
+    ORC_TRY(upload_csr_values(*t.mesh, a_w_values, t.a_w, tmp));
+    std::vector<double> d((size_t)t.n);
+    const double *mats[3] = {a_u_values, a_v_values, a_w_values};
+    DevBuf<double> *diags[3] = {&t.du, &t.dv, &t.dw};
+    for (int k = 0; k < 3; ++k) {
+        for (int64_t c = 0; c < t.n; ++c) {
+            const int64_t *row = m->h_col.data() + m->h_row_ptr[(size_t)c];
+            const int64_t len = m->h_row_ptr[(size_t)c + 1] - m->h_row_ptr[(size_t)c];
+            d[(size_t)c] = mats[k][m->h_row_ptr[(size_t)c] + (std::lower_bound(row, row + len, c) - row)];
+        }
+        ORC_TRY(diags[k]->upload(d.data(), (size_t)t.n));
+    }
+    // the diffusion RHS is added by the caller in the reference (solver.rs:80-82): return b without it
+    ORC_TRY(t.b_u_di.zero()); ORC_TRY(t.b_v_di.zero()); ORC_TRY(t.b_w_di.zero());
+    ORC_TRY(orc_solver_set_fields(s.get(), u, v, w, p));
+    return orc_solver_assemble_momentum(s.get(), a_u_values, a_v_values, a_w_values, b_u, b_v, b_w, peclet);
+}
+
+int orc_build_pressure_correction_matrices(const OrcMesh *m, const double *u, const double *v, const double *w, const double *p,
+                                           const double *a_u_values, const double *a_v_values, const double *a_w_values,
+                                           const OrcSettings *settings, double rho, double *a_values, double *b) {
+    if (!m || !settings) return set_error(ORC_ERR_BAD_ARGUMENT, "null argument");
+    auto s = std::make_unique<OrcSolver>();
+    SolverState &t = s->st;
+    ORC_TRY(solver_init(t, const_cast<OrcMesh *>(m), settings, rho, 1.0));
+    std::vector<double> d((size_t)t.n);
+    const double *mats[3] = {a_u_values, a_v_values, a_w_values};
+    DevBuf<double> *diags[3] = {&t.du, &t.dv, &t.dw};
+    for (int k = 0; k < 3; ++k) {
+        for (int64_t c = 0; c < t.n; ++c) {
+            const int64_t *row = m->h_col.data() + m->h_row_ptr[(size_t)c];
+            const int64_t len = m->h_row_ptr[(size_t)c + 1] - m->h_row_ptr[(size_t)c];
+            d[(size_t)c] = mats[k][m->h_row_ptr[(size_t)c] + (std::lower_bound(row, row + len, c) - row)];
+        }
+        ORC_TRY(diags[k]->upload(d.data(), (size_t)t.n));
+    }
+    ORC_TRY(orc_solver_set_fields(s.get(), u, v, w, p));
+    return orc_solver_assemble_pressure(s.get(), a_values, b);
+}
+
+int orc_calculate_gradients(const OrcMesh *m, const double *u, const double *v, const double *w, const double *p,
+                            const OrcSettings *settings, double *grad_p, double *grad_u) {
+    if (!m || !settings) return set_error(ORC_ERR_BAD_ARGUMENT, "null argument");
+    auto s = std::make_unique<OrcSolver>();
+    SolverState &t = s->st;
+    ORC_TRY(solver_init(t, const_cast<OrcMesh *>(m), settings, 1.0, 1.0));
+    ORC_TRY(orc_solver_set_fields(s.get(), u, v, w, p));
+    ORC_TRY(k_gradients(t, grad_u != nullptr));
+    const size_t n = (size_t)t.n;
+    if (grad_p) {
+        std::vector<double> g(3 * n);
+        ORC_TRY(t.gp.download(g.data(), 3 * n));
+        for (size_t c = 0; c < n; ++c)
+            for (int k = 0; k < 3; ++k) grad_p[3 * c + k] = g[k * n + c];
+    }
+    if (grad_u) {
+        std::vector<double> g(9 * n);
+        ORC_TRY(t.gu.download(g.data(), 9 * n));
+        for (size_t c = 0; c < n; ++c)
+            for (int k = 0; k < 9; ++k) grad_u[9 * c + k] = g[k * n + c];
+    }
+    return fetch_status(t);
+}
+
+// ---------------------------------------------------------------- solver::solve_steady (solver.rs:26-244)
+int orc_solve_steady(OrcMesh *m, double *u, double *v, double *w, double *p, const OrcSettings *settings, double rho, double mu,
+                     uint64_t iteration_count, uint64_t reporting_interval, OrcReportFn report_cb, void *user) {
+    if (!m || !settings || !u || !v || !w || !p) return set_error(ORC_ERR_BAD_ARGUMENT, "null argument");
+    int st = ORC_OK;
+    OrcSolver *s = orc_solver_create(m, settings, rho, mu, &st);
+    if (!s) return st;
+    std::unique_ptr<OrcSolver> guard(s);
+    ORC_TRY(orc_solver_set_fields(s, u, v, w, p));
+    auto start = std::chrono::steady_clock::now();
+    for (uint64_t it = 1; it <= iteration_count && st == ORC_OK; ++it) {
+        double rep[8];
+        const bool want = report_cb && reporting_interval > 0 && it % reporting_interval == 0;
+        st = solver_iterate(s->st, 1, want ? rep : nullptr);
+        if (want && st == ORC_OK) {  // solver.rs:209-216
+            auto now = std::chrono::steady_clock::now();
+            double ms = std::chrono::duration<double, std::milli>(now - start).count() / (double)reporting_interval;
+            start = now;
+            report_cb(it, rep, rep + 3, rep[6], rep[7], ms, user);
+        }
+    }
+    int st2 = orc_solver_get_fields(s, u, v, w, p);  // fields are mutated in place up to a panic
+    return st != ORC_OK ? st : st2;
+}
+
+int orc_bench_spmv(OrcSolver *s, int reps, double *avg_ms, double *checksum) {
+    if (!s) return set_error(ORC_ERR_BAD_ARGUMENT, "null solver");
+    SolverState &t = s->st;
+    MatView A;
+    A.P = t.mesh->pat.dev();
+    A.val = t.a_u.p;
+    Arena::Mark mk = t.arena.mark();
+    double *y;
+    ORC_TRY(t.arena.alloc((size_t)t.n, &y));
+    hipEvent_t e0, e1;
+    ORC_HIP(hipEventCreate(&e0));
+    ORC_HIP(hipEventCreate(&e1));
+    ORC_TRY(spmv_dev(A, t.u.p, y));
+    ORC_HIP(hipEventRecord(e0, ctx().stream));
+    for (int i = 0; i < reps; ++i) ORC_TRY(spmv_dev(A, t.u.p, y));
+    ORC_HIP(hipEventRecord(e1, ctx().stream));
+    ORC_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    ORC_HIP(hipEventElapsedTime(&ms, e0, e1));
+    if (avg_ms) *avg_ms = (double)ms / std::max(reps, 1);
+    if (checksum) {
+        std::vector<double> h((size_t)t.n);
+        ORC_HIP(hipMemcpy(h.data(), y, sizeof(double) * (size_t)t.n, hipMemcpyDeviceToHost));
+        double c = 0.;
+        for (double x : h) c += x;
+        *checksum = c;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    t.arena.release(mk);
+    return ORC_OK;
+}
+
+int orc_bench_bicgstab_iteration(OrcSolver *s, int reps, double *avg_ms) {
+    if (!s) return set_error(ORC_ERR_BAD_ARGUMENT, "null solver");
+    SolverState &t = s->st;
+    MatView A;
+    A.P = t.mesh->pat.dev();
+    A.val = t.a_u.p;
+    Arena::Mark mk = t.arena.mark();
+    double *x;
+    ORC_TRY(t.arena.alloc((size_t)t.n, &x));
+    ORC_TRY(vec_copy(x, t.u.p, t.n));
+    float ms = 0.f;
+    ORC_TRY(bench_bicgstab_dev(A, t.b_u.p, x, reps, t.arena, &ms));
+    if (avg_ms) *avg_ms = ms;
+    t.arena.release(mk);
+    return ORC_OK;
+}
+
+int orc_profile_report(char *buf, int64_t buf_len) {
+    if (buf && buf_len > 0) buf[0] = 0;
+    return ORC_OK;
+}
+
+}  // extern "C"

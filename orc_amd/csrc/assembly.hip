@@ -1,0 +1,733 @@
+// assembly.hip — face-loop assembly of the SIMPLE iteration on the device.
+// Reference: src/discretization.rs (all), src/solver.rs:774-802, 874-902, 952-1227.
+//
+// The reference walks cells, and inside each (cell, face) visit recomputes two or four
+// Green-Gauss pressure gradients (solver.rs:1082-1084, 1139-1140).  p, u, v, w are immutable
+// during an assembly, so here every gradient is evaluated once per cell (K9), every face flux and
+// face pressure once per face (K10 — the two sides of a face see exactly opposite fluxes once the
+// Rhie-Chow diagonals are frozen), and the cell kernel (K11/K12) only gathers.
+// The cell kernels visit a cell's faces in ascending face id and use the reference's operator
+// order, so with -ffp-contract=off every assembled coefficient is bit-identical to the CPU
+// oracle in frozen-diagonal mode.  All kernels are HBM-bound gathers; no atomics are needed
+// because each thread owns its matrix row.
+#include <algorithm>
+#include <cmath>
+
+#include "assembly.hpp"
+#include "linalg_kernels.hpp"
+
+namespace orc {
+
+int comm_allreduce_sum(double *dev, int n);
+
+struct V3 {
+    double x, y, z;
+};
+__device__ __forceinline__ V3 mk(double x, double y, double z) { return {x, y, z}; }
+__device__ __forceinline__ V3 vadd(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 vsub(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 vneg(V3 a) { return {-a.x, -a.y, -a.z}; }
+__device__ __forceinline__ V3 vmuls(V3 a, double s) { return {a.x * s, a.y * s, a.z * s}; }   // Vector * Float (lib.rs:479-492)
+__device__ __forceinline__ V3 vdivs(V3 a, double s) { return {a.x / s, a.y / s, a.z / s}; }
+__device__ __forceinline__ V3 vadds(V3 a, double s) { return {a.x + s, a.y + s, a.z + s}; }
+__device__ __forceinline__ double vdot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ double vnorm(V3 a) { return sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
+// Float * Vector (lib.rs:540-548): z := rhs.y * self when q1
+__device__ __forceinline__ V3 smulv(double s, V3 a, int q1) { return {a.x * s, a.y * s, (q1 ? a.y : a.z) * s}; }
+
+__device__ __forceinline__ V3 face_normal(const MeshDev &M, int f) { return mk(M.nx[f], M.ny[f], M.nz[f]); }
+__device__ __forceinline__ V3 cell_centroid(const MeshDev &M, int c) { return mk(M.ccx[c], M.ccy[c], M.ccz[c]); }
+__device__ __forceinline__ V3 face_centroid(const MeshDev &M, int f) { return mk(M.fcx[f], M.fcy[f], M.fcz[f]); }
+__device__ __forceinline__ V3 zone_vec(const MeshDev &M, int z) { return mk(M.zvec[3 * z], M.zvec[3 * z + 1], M.zvec[3 * z + 2]); }
+
+__device__ __forceinline__ void raise(int *status, int code) { atomicCAS(status, 0, code); }
+
+#define GRID_STRIDE(i, n) for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (int64_t)gridDim.x * blockDim.x)
+
+// ------------------------------------------------------------------ K14: diffusion matrix (once)
+// discretization.rs:39-131
+__global__ void diffusion_k(MeshDev M, SellDev P, double mu, double *__restrict__ a_di, double *__restrict__ b_u,
+                            double *__restrict__ b_v, double *__restrict__ b_w, int *status) {
+    GRID_STRIDE(c, M.n_cells) {
+        const V3 cc = cell_centroid(M, (int)c);
+        double a_p = 0., bu = 0., bv = 0., bw = 0.;
+        for (int q = M.cfp[c]; q < M.cfp[c + 1]; ++q) {
+            const int f = M.cf[q];
+            const int z = M.fzone[f];
+            const int zt = M.ztype[z];
+            double d_i = 0.;
+            if (zt == ORC_BC_WALL || zt == ORC_BC_VELOCITY_INLET) {  // :70-79
+                d_i = mu * M.area[f] / vnorm(vsub(face_centroid(M, f), cc));
+                const V3 sc = vmuls(zone_vec(M, z), d_i);
+                bu += sc.x; bv += sc.y; bw += sc.z;
+            } else if (zt == ORC_BC_PRESSURE_INLET || zt == ORC_BC_PRESSURE_OUTLET || zt == ORC_BC_SYMMETRY) {  // :80-88
+                d_i = 0.;
+            } else if (zt == ORC_BC_INTERIOR) {  // :89-113
+                const int nb = (M.c0[f] == c) ? M.c1[f] : M.c0[f];
+                d_i = mu * M.area[f] / vnorm(vsub(cell_centroid(M, nb), cc));
+                a_di[M.cfpos[q]] = -d_i;  // :125
+            } else {
+                raise(status, ORC_ERR_UNSUPPORTED_BC);  // :114-117
+            }
+            a_p += d_i;
+        }
+        a_di[P.diag_pos[c]] = a_p;  // :128
+        b_u[c] = bu; b_v[c] = bv; b_w[c] = bw;
+    }
+}
+
+// discretization.rs:450-472
+__global__ void init_momentum_k(MeshDev M, SellDev P, double *__restrict__ a) {
+    GRID_STRIDE(c, M.n_cells) {
+        a[P.diag_pos[c]] = 1.;
+        const double nf = (double)(M.cfp[c + 1] - M.cfp[c]);
+        for (int q = M.cfp[c]; q < M.cfp[c + 1]; ++q)
+            if (M.cfpos[q] >= 0) a[M.cfpos[q]] = -1. / nf;
+    }
+}
+
+__global__ void extract_diag_k(SellDev P, const double *__restrict__ a, double *__restrict__ d) {
+    GRID_STRIDE(c, P.n) d[c] = a[P.diag_pos[c]];
+}
+
+// ------------------------------------------------------------------ K9: Green-Gauss gradients
+// get_face_pressure with PressureInterpolation::Linear (solver.rs:1114-1128)
+__device__ __forceinline__ double face_pressure_linear(const MeshDev &M, const double *__restrict__ p, int f, int zt, int z) {
+    if (zt == ORC_BC_INTERIOR) return (p[M.c0[f]] + p[M.c1[f]]) * 0.5;
+    if (zt == ORC_BC_PRESSURE_INLET || zt == ORC_BC_PRESSURE_OUTLET) return M.zscal[z];
+    return p[M.c0[f]];  // Symmetry | Wall | VelocityInlet
+}
+
+__device__ __forceinline__ bool bc_supported(int zt) {
+    return zt == ORC_BC_INTERIOR || zt == ORC_BC_WALL || zt == ORC_BC_SYMMETRY || zt == ORC_BC_VELOCITY_INLET ||
+           zt == ORC_BC_PRESSURE_INLET || zt == ORC_BC_PRESSURE_OUTLET;
+}
+
+// calculate_pressure_gradient, GreenGauss(CellBased) (solver.rs:883-900); returns (gx, gy, gy) under Q1
+__global__ void grad_p_k(MeshDev M, const double *__restrict__ p, double *__restrict__ gp, int q1, int *status) {
+    const int64_t n = M.n_cells;
+    GRID_STRIDE(c, n) {
+        const double vol = M.vol[c];
+        V3 acc = mk(0., 0., 0.);
+        for (int q = M.cfp[c]; q < M.cfp[c + 1]; ++q) {
+            const int f = M.cf[q];
+            const int z = M.fzone[f];
+            const int zt = M.ztype[z];
+            if (!bc_supported(zt)) { raise(status, ORC_ERR_UNSUPPORTED_BC); continue; }  // solver.rs:1148
+            const double fv = face_pressure_linear(M, p, f, zt, z);
+            V3 nrm = face_normal(M, f);
+            if (M.c0[f] != c) nrm = vneg(nrm);
+            acc = vadd(acc, smulv(fv * (M.area[f] / vol), nrm, q1));  // :896-898
+        }
+        gp[c] = acc.x; gp[n + c] = acc.y; gp[2 * n + c] = acc.z;
+    }
+}
+
+// get_face_velocity(…, Linear) (solver.rs:952-987)
+__device__ __forceinline__ V3 face_velocity_linear(const MeshDev &M, const double *__restrict__ u, const double *__restrict__ v,
+                                                   const double *__restrict__ w, int f, int zt, int z) {
+    const int a = M.c0[f];
+    if (zt == ORC_BC_WALL || zt == ORC_BC_VELOCITY_INLET) return zone_vec(M, z);
+    if (zt == ORC_BC_INTERIOR) {
+        const int b = M.c1[f];
+        return vdivs(vadd(mk(u[a], v[a], w[a]), mk(u[b], v[b], w[b])), 2.);
+    }
+    return mk(u[a], v[a], w[a]);
+}
+
+// calculate_velocity_gradient, GreenGauss arm (solver.rs:784-801): row = velocity component
+__global__ void grad_u_k(MeshDev M, const double *__restrict__ u, const double *__restrict__ v, const double *__restrict__ w,
+                         double *__restrict__ gu, int *status) {
+    const int64_t n = M.n_cells;
+    GRID_STRIDE(c, n) {
+        const double vol = M.vol[c];
+        V3 tx = mk(0., 0., 0.), ty = tx, tz = tx;
+        for (int q = M.cfp[c]; q < M.cfp[c + 1]; ++q) {
+            const int f = M.cf[q];
+            const int z = M.fzone[f];
+            const int zt = M.ztype[z];
+            if (!bc_supported(zt)) { raise(status, ORC_ERR_UNSUPPORTED_BC); continue; }  // solver.rs:1001
+            const V3 fv = face_velocity_linear(M, u, v, w, f, zt, z);
+            V3 nrm = face_normal(M, f);
+            if (M.c0[f] != c) nrm = vneg(nrm);
+            const V3 nn = vmuls(nrm, M.area[f] / vol);  // :799
+            tx = vadd(tx, mk(fv.x * nn.x, fv.x * nn.y, fv.x * nn.z));  // outer (lib.rs:275-293)
+            ty = vadd(ty, mk(fv.y * nn.x, fv.y * nn.y, fv.y * nn.z));
+            tz = vadd(tz, mk(fv.z * nn.x, fv.z * nn.y, fv.z * nn.z));
+        }
+        gu[0 * n + c] = tx.x; gu[1 * n + c] = tx.y; gu[2 * n + c] = tx.z;
+        gu[3 * n + c] = ty.x; gu[4 * n + c] = ty.y; gu[5 * n + c] = ty.z;
+        gu[6 * n + c] = tz.x; gu[7 * n + c] = tz.y; gu[8 * n + c] = tz.z;
+    }
+}
+
+// ------------------------------------------------------------------ K10: face flux / face pressure
+struct FaceArgs {
+    const double *u, *v, *w, *p, *gp, *du, *dv, *dw;
+    int vinterp, pinterp, q1;
+    double rho;
+};
+
+// get_face_flux seen from cell_indices[0] (solver.rs:1007-1102); the other side is the exact negative
+__device__ __forceinline__ double face_flux_c0(const MeshDev &M, const FaceArgs &A, int f, int zt, int z, int *status) {
+    const int i = M.c0[f];
+    const V3 n = face_normal(M, f);
+    if (zt == ORC_BC_WALL || zt == ORC_BC_SYMMETRY) return 0.;  // :1026
+    if (zt == ORC_BC_VELOCITY_INLET) return vdot(n, zone_vec(M, z));  // :1027-1039
+    if (zt == ORC_BC_PRESSURE_INLET || zt == ORC_BC_PRESSURE_OUTLET) return vdot(n, mk(A.u[i], A.v[i], A.w[i]));
+    if (zt != ORC_BC_INTERIOR) { raise(status, ORC_ERR_UNSUPPORTED_BC); return 0.; }  // :1100
+    const int j = M.c1[f];
+    const V3 vel_i = mk(A.u[i], A.v[i], A.w[i]), vel_j = mk(A.u[j], A.v[j], A.w[j]);
+    if (A.vinterp == ORC_VINTERP_LINEAR) return vdot(n, vdivs(vadd(vel_i, vel_j), 2.));  // :987
+    if (A.vinterp == ORC_VINTERP_LINEAR_WEIGHTED) {  // :988-992
+        const V3 fc = face_centroid(M, f);
+        const double dx0 = vnorm(vsub(cell_centroid(M, i), fc)), dx1 = vnorm(vsub(cell_centroid(M, j), fc));
+        return vdot(n, vadd(vel_i, vdivs(vmuls(vsub(vel_j, vel_i), dx0), dx0 + dx1)));
+    }
+    // Rhie-Chow (:1051-1095)
+    const int64_t nc = M.n_cells;
+    const V3 ccv = vsub(cell_centroid(M, j), cell_centroid(M, i));
+    const double a_i = vnorm(mk(A.du[i] * n.x, A.dv[i] * n.y, A.dw[i] * n.z));  // discretization.rs:14-23
+    const double a_j = vnorm(mk(A.du[j] * n.x, A.dv[j] * n.y, A.dw[j] * n.z));
+    const V3 g_i = mk(A.gp[i], A.gp[nc + i], A.gp[2 * nc + i]), g_j = mk(A.gp[j], A.gp[nc + j], A.gp[2 * nc + j]);
+    const double vol_i = M.vol[i], vol_j = M.vol[j];
+    const double len = vnorm(ccv);
+    const double term_1 = vdot(vadd(vel_i, vel_j), n);
+    const double term_2 = (vol_i / a_i + vol_j / a_j) * (A.p[i] - A.p[j]) / len;
+    const V3 unit = mk(ccv.x / len, ccv.y / len, ccv.z / len);
+    const double term_3 = vdot(vadd(smulv(vol_i / a_i, g_i, A.q1), smulv(vol_j / a_j, g_j, A.q1)), unit);
+    return 0.5 * (term_1 + term_2 - term_3);
+}
+
+// get_face_pressure (solver.rs:1104-1150)
+__device__ __forceinline__ double face_pressure(const MeshDev &M, const FaceArgs &A, int f, int zt, int z) {
+    if (zt != ORC_BC_INTERIOR) return face_pressure_linear(M, A.p, f, zt, z);
+    const int c0 = M.c0[f], c1 = M.c1[f];
+    const double p0 = A.p[c0], p1 = A.p[c1];
+    if (A.pinterp == ORC_PINTERP_LINEAR) return (p0 + p1) * 0.5;
+    const V3 fc = face_centroid(M, f);
+    if (A.pinterp == ORC_PINTERP_LINEAR_WEIGHTED) {  // :1129-1133
+        const double x0 = vnorm(vsub(cell_centroid(M, c0), fc)), x1 = vnorm(vsub(cell_centroid(M, c1), fc));
+        return p0 + (p1 - p0) * x0 / (x0 + x1);
+    }
+    // SecondOrder (:1138-1144)
+    const int64_t nc = M.n_cells;
+    const V3 g0 = mk(A.gp[c0], A.gp[nc + c0], A.gp[2 * nc + c0]), g1 = mk(A.gp[c1], A.gp[nc + c1], A.gp[2 * nc + c1]);
+    const V3 r0 = vsub(fc, cell_centroid(M, c0)), r1 = vsub(fc, cell_centroid(M, c1));
+    return 0.5 * ((p0 + p1) + (vdot(g0, r0) + vdot(g1, r1)));
+}
+
+// MODE 0: momentum phase (flux + face pressure); MODE 1: pressure-correction phase (flux + coefficient)
+template <int MODE>
+__global__ void face_k(MeshDev M, FaceArgs A, double *__restrict__ flux, double *__restrict__ pf, double *__restrict__ coef, int *status) {
+    GRID_STRIDE(f, M.n_faces) {
+        const int z = M.fzone[f];
+        const int zt = M.ztype[z];
+        flux[f] = face_flux_c0(M, A, (int)f, zt, z, status);
+        if (MODE == 0) {
+            pf[f] = bc_supported(zt) ? face_pressure(M, A, (int)f, zt, z) : 0.;
+        } else {
+            // discretization.rs:401-436: rho * A^2 / a~ ; a~ from the (sign-insensitive) inward normal
+            const V3 n = face_normal(M, (int)f);
+            const int i = M.c0[f], j = M.c1[f];
+            const double ar = M.area[f];
+            if (j >= 0) {
+                const double a_int = 0.5 * vnorm(mk((A.du[i] + A.du[j]) * -n.x, (A.dv[i] + A.dv[j]) * -n.y, (A.dw[i] + A.dw[j]) * -n.z));
+                coef[f] = A.rho * (ar * ar) / a_int;
+            } else {
+                const double a_ii = vnorm(mk(A.du[i] * -n.x, A.dv[i] * -n.y, A.dw[i] * -n.z));
+                coef[f] = A.rho * (ar * ar) / a_ii;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ K11: momentum matrices
+__device__ __forceinline__ double psi_eval(int momentum, double r) {  // lib.rs:107-118
+    switch (momentum) {
+    case ORC_MOMENTUM_TVD_UD: return 0.;
+    case ORC_MOMENTUM_TVD_CD1: return 1.;
+    case ORC_MOMENTUM_TVD_LUD: return r;
+    case ORC_MOMENTUM_TVD_QUICK: return (3. + r) / 4.;
+    default: {  // UMIST; f64::min / max ignore NaN like fmin / fmax
+        double acc = INFINITY;
+        acc = fmin(acc, 2. * r);
+        acc = fmin(acc, (1. + 3. * r) / 4.);
+        acc = fmin(acc, (3. + r) / 4.);
+        acc = fmin(acc, 2.);
+        return fmax(0., acc);
+    }
+    }
+}
+
+struct MomentumArgs {
+    const double *u, *v, *w, *gu, *flux, *pf, *a_di, *b_u_di, *b_v_di, *b_w_di;
+    double *a_u, *a_v, *a_w, *b_u, *b_v, *b_w, *du, *dv, *dw;
+    int momentum, q1;
+    double rho;
+};
+
+// discretization.rs:134-356, one thread per cell (= per matrix row)
+__global__ __launch_bounds__(kBlock) void momentum_k(MeshDev M, SellDev P, MomentumArgs A, double *__restrict__ partials) {
+    __shared__ double lds[8];
+    const int64_t n = M.n_cells;
+    double pe_sum = 0., pe_min = INFINITY, pe_max = -INFINITY;
+    const bool tvd = A.momentum >= ORC_MOMENTUM_TVD_LUD;
+    GRID_STRIDE(c, n) {
+        V3 s_u = mk(0., 0., 0.);  // get_momentum_source_term (solver.rs:698-701)
+        const int dpos = P.diag_pos[c];
+        const double a_ii_di = A.a_di[dpos];  // :176
+        V3 a_p = mk(0., 0., 0.);
+        const V3 vel = mk(A.u[c], A.v[c], A.w[c]);
+        for (int q = M.cfp[c]; q < M.cfp[c + 1]; ++q) {
+            const int f = M.cf[q];
+            const bool side0 = M.c0[f] == c;
+            V3 n_out = face_normal(M, f);
+            if (!side0) n_out = vneg(n_out);
+            const double face_flux = side0 ? A.flux[f] : -A.flux[f];
+            const double ar = M.area[f];
+            const double f_i = face_flux * ar * A.rho;  // :202
+            const double face_pressure = A.pf[f];
+            const int c1 = M.c1[f];
+            const int nb = c1 < 0 ? -1 : (side0 ? c1 : M.c0[f]);
+            V3 a_nb;
+            if (A.momentum == ORC_MOMENTUM_UD || (tvd && nb < 0)) {
+                a_nb = smulv(fmin(f_i, 0.), mk(1., 1., 1.), A.q1);  // :226, :238
+            } else if (A.momentum == ORC_MOMENTUM_CD1) {
+                a_nb = vdivs(smulv(f_i, mk(1., 1., 1.), A.q1), 2.);  // :231
+            } else {
+                const int down = f_i > 0. ? nb : (int)c;  // :244-248
+                const V3 dvel = mk(A.u[down], A.v[down], A.w[down]);
+                const V3 dv = vsub(dvel, vel);
+                if (vnorm(dv) == 0.) {
+                    a_nb = vdivs(smulv(f_i, mk(1., 1., 1.), A.q1), 2.);  // :264
+                } else {
+                    const V3 r_pa = vsub(cell_centroid(M, nb), cell_centroid(M, (int)c));
+                    const V3 gx = mk(A.gu[c], A.gu[n + c], A.gu[2 * n + c]);
+                    const V3 gy = mk(A.gu[3 * n + c], A.gu[4 * n + c], A.gu[5 * n + c]);
+                    const V3 gz = mk(A.gu[6 * n + c], A.gu[7 * n + c], A.gu[8 * n + c]);
+                    const V3 inner = mk(vdot(gx, r_pa), vdot(gy, r_pa), vdot(gz, r_pa));  // lib.rs:584-590
+                    const V3 two = smulv(2., inner, A.q1);                                   // :276
+                    const V3 r = vadds(mk(two.x / dv.x, two.y / dv.y, two.z / dv.z), -1.);  // :277-278
+                    const V3 ps = mk(psi_eval(A.momentum, r.x), psi_eval(A.momentum, r.y), psi_eval(A.momentum, r.z));
+                    a_nb = vdivs(smulv(f_i, ps, A.q1), 2.);  // :279-283
+                }
+            }
+            a_p = vadd(a_p, vadds(vneg(a_nb), f_i));                           // :290
+            s_u = vadd(s_u, vmuls(vmuls(vneg(n_out), face_pressure), ar));     // :291
+            if (nb < 0) {  // :294-307
+                const int z = M.fzone[f];
+                const int zt = M.ztype[z];
+                if (zt == ORC_BC_WALL || zt == ORC_BC_VELOCITY_INLET) {
+                    const V3 vv = zone_vec(M, z);
+                    s_u = vadd(s_u, mk((a_nb.x - f_i) * vv.x, (a_nb.y - f_i) * vv.y, (a_nb.z - f_i) * vv.z));
+                } else {
+                    s_u = vadd(s_u, mk(0., 0., 0.));
+                }
+            } else {  // :308-324
+                const int pos = M.cfpos[q];
+                const double a_ij_di = A.a_di[pos];
+                A.a_u[pos] = a_nb.x + a_ij_di;
+                A.a_v[pos] = a_nb.y + a_ij_di;
+                A.a_w[pos] = a_nb.z + a_ij_di;
+            }
+        }
+        const V3 total = vadd(vadd(s_u, mk(0., 0., 0.)), mk(0., 0., 0.));  // :326
+        A.b_u[c] = total.x + A.b_u_di[c];                                   // :327-329 then solver.rs:80-82
+        A.b_v[c] = total.y + A.b_v_di[c];
+        A.b_w[c] = total.z + A.b_w_di[c];
+        const double px = a_p.x / a_ii_di, py = a_p.y / a_ii_di, pz = a_p.z / a_ii_di;  // :331-333
+        pe_max = fmax(pe_max, fmax(px, fmax(py, pz)));
+        pe_min = fmin(pe_min, fmin(px, fmin(py, pz)));
+        pe_sum += (((0. + px) + py) + pz) / 3.;  // :338
+        const double d_u = a_p.x + a_ii_di, d_v = a_p.y + a_ii_di, d_w = a_p.z + a_ii_di;  // :340-351
+        A.a_u[dpos] = d_u; A.a_v[dpos] = d_v; A.a_w[dpos] = d_w;
+        A.du[c] = d_u; A.dv[c] = d_v; A.dw[c] = d_w;
+    }
+    const double t = block_sum(pe_sum, lds);
+    const double mn = -block_max(-pe_min, lds);
+    const double mx = block_max(pe_max, lds);
+    if (threadIdx.x == 0) {
+        partials[blockIdx.x] = t;
+        partials[gridDim.x + blockIdx.x] = mn;
+        partials[2 * gridDim.x + blockIdx.x] = mx;
+    }
+}
+
+// ------------------------------------------------------------------ K12: pressure-correction system
+// discretization.rs:359-448 with the fixed pattern (no COO build / sort per iteration)
+__global__ void pressure_k(MeshDev M, SellDev P, const double *__restrict__ flux, const double *__restrict__ coef, double rho,
+                           double *__restrict__ a_p_mat, double *__restrict__ b_p) {
+    GRID_STRIDE(c, M.n_cells) {
+        double a_p = 0., b = 0.;
+        for (int q = M.cfp[c]; q < M.cfp[c + 1]; ++q) {
+            const int f = M.cf[q];
+            const double out_flux = (M.c0[f] == c) ? flux[f] : -flux[f];
+            b += rho * (-out_flux) * M.area[f];  // :399
+            const double a_nb = coef[f];
+            const int pos = M.cfpos[q];
+            if (pos >= 0) {
+                a_p_mat[pos] = -a_nb;  // :423
+                a_p += a_nb;
+            } else {
+                a_p += a_nb / 2.;  // :435
+            }
+        }
+        a_p_mat[P.diag_pos[c]] = a_p;  // :438
+        b_p[c] = b;
+    }
+}
+
+// ------------------------------------------------------------------ K13: velocity / pressure correction
+// solver.rs:1170-1227 fused with the report sums of solver.rs:206-208
+__global__ __launch_bounds__(kBlock) void correction_k(MeshDev M, const double *__restrict__ du, const double *__restrict__ dv,
+                                                       const double *__restrict__ dw, const double *__restrict__ pp,
+                                                       double *__restrict__ u, double *__restrict__ v, double *__restrict__ w,
+                                                       double *__restrict__ p, double alpha_p, double alpha_u,
+                                                       double *__restrict__ partials, int *status) {
+    __shared__ double lds[8];
+    double s_pp = 0., s_corr = 0., s_u = 0., s_v = 0., s_w = 0.;
+    GRID_STRIDE(c, M.n_cells) {
+        const double ppc = pp[c];
+        p[c] += alpha_p * ppc;  // :1186
+        V3 acc = mk(0., 0., 0.);
+        const double iu = du[c], iv = dv[c], iw = dw[c];
+        for (int q = M.cfp[c]; q < M.cfp[c + 1]; ++q) {
+            const int f = M.cf[q];
+            const int zt = M.ztype[M.fzone[f]];
+            V3 n = face_normal(M, f);
+            const bool side0 = M.c0[f] == c;
+            if (!side0) n = vneg(n);
+            double pp_nb;
+            if (zt == ORC_BC_INTERIOR) pp_nb = pp[side0 ? M.c1[f] : M.c0[f]];
+            else if (zt == ORC_BC_PRESSURE_INLET || zt == ORC_BC_PRESSURE_OUTLET) pp_nb = 0.;
+            else if (zt == ORC_BC_WALL || zt == ORC_BC_SYMMETRY || zt == ORC_BC_VELOCITY_INLET) pp_nb = ppc;
+            else { raise(status, ORC_ERR_UNSUPPORTED_BC); pp_nb = ppc; }  // :1209-1212
+            const V3 scaled = mk(n.x / iu, n.y / iv, n.z / iw);
+            acc = vadd(acc, vmuls(vmuls(scaled, ppc - pp_nb), M.area[f]));  // :1219
+        }
+        const double un = u[c] + acc.x * alpha_u, vn = v[c] + acc.y * alpha_u, wn = w[c] + acc.z * alpha_u;  // :1221-1223
+        u[c] = un; v[c] = vn; w[c] = wn;
+        const double nn = vnorm(acc);
+        s_corr += nn * nn;  // :1224
+        s_pp += ppc * ppc;
+        s_u += un; s_v += vn; s_w += wn;
+    }
+    const double t0 = block_sum(s_pp, lds), t1 = block_sum(s_corr, lds), t2 = block_sum(s_u, lds), t3 = block_sum(s_v, lds),
+                 t4 = block_sum(s_w, lds);
+    if (threadIdx.x == 0) {
+        const int g = gridDim.x;
+        partials[blockIdx.x] = t0; partials[g + blockIdx.x] = t1; partials[2 * g + blockIdx.x] = t2;
+        partials[3 * g + blockIdx.x] = t3; partials[4 * g + blockIdx.x] = t4;
+    }
+}
+
+__global__ void reduce_minmax_k(const double *__restrict__ partials, int count, double *__restrict__ out) {
+    // out[0] = sum(partials[0..count)), out[1] = min(partials[count..2count)), out[2] = max(partials[2count..3count))
+    if (threadIdx.x != 0) return;
+    double s = 0., mn = INFINITY, mx = -INFINITY;
+    for (int i = 0; i < count; ++i) { s += partials[i]; mn = fmin(mn, partials[count + i]); mx = fmax(mx, partials[2 * count + i]); }
+    out[0] = s; out[1] = mn; out[2] = mx;
+}
+
+}  // namespace orc
+
+// ====================================================================== host side
+orc::MeshDev OrcMesh::dev() const {
+    orc::MeshDev d;
+    d.n_cells = n_cells; d.n_faces = n_faces; d.n_zones = n_zones;
+    d.c0 = c0.p; d.c1 = c1.p; d.fzone = fzone.p; d.area = area.p; d.nx = nx.p; d.ny = ny.p; d.nz = nz.p;
+    d.fcx = fcx.p; d.fcy = fcy.p; d.fcz = fcz.p; d.ccx = ccx.p; d.ccy = ccy.p; d.ccz = ccz.p; d.vol = vol.p;
+    d.cfp = cfp.p; d.cf = cf.p; d.cfpos = cfpos.p; d.ztype = ztype.p; d.zscal = zscal.p; d.zvec = zvec.p;
+    return d;
+}
+
+namespace orc {
+
+template <class T, class S>
+static int upload_as(DevBuf<T> &dst, const S *src, size_t n, size_t stride = 1, size_t off = 0) {
+    std::vector<T> tmp(std::max<size_t>(n, 1));
+    for (size_t i = 0; i < n; ++i) tmp[i] = (T)src[i * stride + off];
+    return dst.upload(tmp.data(), n);
+}
+
+int mesh_upload(OrcMesh &m, int64_t n_cells, int64_t n_faces, int32_t n_zones, const int64_t *face_c0, const int64_t *face_c1,
+                const int32_t *face_zone, const double *face_area, const double *face_normal, const double *face_centroid,
+                const double *cell_centroid, const double *cell_volume, const int64_t *cell_face_ptr, const int64_t *cell_faces,
+                const int32_t *zone_type, const double *zone_scalar, const double *zone_vector) {
+    if (n_cells < 1 || n_faces < 1 || n_zones < 1) return set_error(ORC_ERR_BAD_ARGUMENT, "empty mesh");
+    if (n_faces >= ((int64_t)1 << 31) || n_cells >= ((int64_t)1 << 31)) return set_error(ORC_ERR_BAD_ARGUMENT, "mesh too large for 32-bit device indices");
+    const int64_t ncf = cell_face_ptr[n_cells];
+    if (ncf >= ((int64_t)1 << 31)) return set_error(ORC_ERR_BAD_ARGUMENT, "mesh too large for 32-bit device indices");
+    for (int64_t f = 0; f < n_faces; ++f) {
+        if (face_c0[f] < 0 || face_c0[f] >= n_cells || face_c1[f] >= n_cells || face_zone[f] < 0 || face_zone[f] >= n_zones)
+            return set_error(ORC_ERR_BAD_ARGUMENT, "face %lld: index out of range", (long long)f);
+    }
+    m.n_cells = n_cells; m.n_faces = n_faces; m.n_zones = n_zones; m.n_cell_faces = ncf;
+    // matrix pattern: diagonal + one entry per interior face, ascending columns
+    // (CsrMatrix::from(&CooMatrix) at discretization.rs:130,445,471)
+    m.h_row_ptr.assign((size_t)n_cells + 1, 0);
+    std::vector<int64_t> nbr((size_t)ncf);
+    for (int64_t c = 0; c < n_cells; ++c) {
+        int64_t cnt = 1;
+        for (int64_t q = cell_face_ptr[c]; q < cell_face_ptr[c + 1]; ++q) {
+            const int64_t f = cell_faces[q];
+            if (f < 0 || f >= n_faces) return set_error(ORC_ERR_BAD_ARGUMENT, "cell %lld: face index out of range", (long long)c);
+            int64_t nb = -1;
+            if (face_c1[f] >= 0) nb = face_c0[f] == c ? face_c1[f] : face_c0[f];
+            nbr[(size_t)q] = nb;
+            if (nb >= 0) cnt++;
+        }
+        m.h_row_ptr[(size_t)c + 1] = m.h_row_ptr[(size_t)c] + cnt;
+    }
+    m.h_col.assign((size_t)m.h_row_ptr[(size_t)n_cells], 0);
+    for (int64_t c = 0; c < n_cells; ++c) {
+        int64_t *row = m.h_col.data() + m.h_row_ptr[(size_t)c];
+        int64_t k = 0;
+        row[k++] = c;
+        for (int64_t q = cell_face_ptr[c]; q < cell_face_ptr[c + 1]; ++q)
+            if (nbr[(size_t)q] >= 0) row[k++] = nbr[(size_t)q];
+        std::sort(row, row + k);
+        // two cells sharing two faces would give duplicate columns (summed by the reference's
+        // COO->CSR); not supported by the fixed-pattern assembly
+        for (int64_t t = 1; t < k; ++t)
+            if (row[t] == row[t - 1]) return set_error(ORC_ERR_BAD_ARGUMENT, "cells %lld and %lld share more than one face", (long long)c, (long long)row[t]);
+    }
+    ORC_TRY(sell_from_csr_host(n_cells, m.h_row_ptr.data(), m.h_col.data(), m.pat));
+    // SELL offsets of the neighbour entries
+    std::vector<int32_t> cfpos((size_t)ncf, -1);
+    {
+        std::vector<int64_t> slice_ptr((size_t)m.pat.n_slices + 1);
+        ORC_TRY(m.pat.slice_ptr.download(slice_ptr.data(), slice_ptr.size()));
+        for (int64_t c = 0; c < n_cells; ++c) {
+            const int64_t *row = m.h_col.data() + m.h_row_ptr[(size_t)c];
+            const int64_t len = m.h_row_ptr[(size_t)c + 1] - m.h_row_ptr[(size_t)c];
+            const int64_t base = slice_ptr[(size_t)(c >> 6)] + (c & 63);
+            for (int64_t q = cell_face_ptr[c]; q < cell_face_ptr[c + 1]; ++q) {
+                if (nbr[(size_t)q] < 0) continue;
+                const int64_t k = std::lower_bound(row, row + len, nbr[(size_t)q]) - row;
+                cfpos[(size_t)q] = (int32_t)(base + k * 64);
+            }
+        }
+    }
+    ORC_TRY(upload_as(m.c0, face_c0, (size_t)n_faces));
+    ORC_TRY(upload_as(m.c1, face_c1, (size_t)n_faces));
+    ORC_TRY(m.fzone.upload(face_zone, (size_t)n_faces));
+    ORC_TRY(m.area.upload(face_area, (size_t)n_faces));
+    ORC_TRY(upload_as(m.nx, face_normal, (size_t)n_faces, 3, 0));
+    ORC_TRY(upload_as(m.ny, face_normal, (size_t)n_faces, 3, 1));
+    ORC_TRY(upload_as(m.nz, face_normal, (size_t)n_faces, 3, 2));
+    ORC_TRY(upload_as(m.fcx, face_centroid, (size_t)n_faces, 3, 0));
+    ORC_TRY(upload_as(m.fcy, face_centroid, (size_t)n_faces, 3, 1));
+    ORC_TRY(upload_as(m.fcz, face_centroid, (size_t)n_faces, 3, 2));
+    ORC_TRY(upload_as(m.ccx, cell_centroid, (size_t)n_cells, 3, 0));
+    ORC_TRY(upload_as(m.ccy, cell_centroid, (size_t)n_cells, 3, 1));
+    ORC_TRY(upload_as(m.ccz, cell_centroid, (size_t)n_cells, 3, 2));
+    ORC_TRY(m.vol.upload(cell_volume, (size_t)n_cells));
+    ORC_TRY(upload_as(m.cfp, cell_face_ptr, (size_t)n_cells + 1));
+    ORC_TRY(upload_as(m.cf, cell_faces, (size_t)ncf));
+    ORC_TRY(m.cfpos.upload(cfpos.data(), (size_t)ncf));
+    ORC_TRY(m.ztype.upload(zone_type, (size_t)n_zones));
+    ORC_TRY(m.zscal.upload(zone_scalar, (size_t)n_zones));
+    ORC_TRY(m.zvec.upload(zone_vector, (size_t)3 * n_zones));
+    return ORC_OK;
+}
+
+static bool is_tvd(int momentum) { return momentum >= ORC_MOMENTUM_TVD_LUD && momentum <= ORC_MOMENTUM_TVD_CD1; }
+
+static int validate_settings(const OrcSettings &s) {
+    if (!(s.momentum == ORC_MOMENTUM_UD || s.momentum == ORC_MOMENTUM_CD1 || is_tvd(s.momentum)))
+        return set_error(ORC_ERR_UNSUPPORTED_SCHEME, "unsupported momentum scheme");  // discretization.rs:287
+    if (s.diffusion != ORC_DIFFUSION_CD) return set_error(ORC_ERR_UNSUPPORTED_SCHEME, "unsupported diffusion scheme");  // :50
+    if (s.gradient_reconstruction != ORC_GRAD_GREEN_GAUSS_CELL)
+        return set_error(ORC_ERR_UNSUPPORTED_SCHEME, "unsupported gradient scheme (Green-Gauss cell-based only)");  // solver.rs:870,901,948
+    if (!(s.pressure_interpolation == ORC_PINTERP_LINEAR || s.pressure_interpolation == ORC_PINTERP_LINEAR_WEIGHTED ||
+          s.pressure_interpolation == ORC_PINTERP_SECOND_ORDER))
+        return set_error(ORC_ERR_UNSUPPORTED_SCHEME, "unsupported pressure interpolation");  // solver.rs:1136,1145
+    if (!(s.velocity_interpolation == ORC_VINTERP_LINEAR || s.velocity_interpolation == ORC_VINTERP_LINEAR_WEIGHTED ||
+          s.velocity_interpolation == ORC_VINTERP_RHIE_CHOW))
+        return set_error(ORC_ERR_UNSUPPORTED_SCHEME, "unsupported velocity interpolation");  // solver.rs:994,1097
+    return ORC_OK;
+}
+
+int fetch_status(SolverState &s) {
+    int h = 0;
+    ORC_HIP(hipMemcpyAsync(&h, s.dev_status.p, sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
+    ORC_HIP(hipStreamSynchronize(ctx().stream));
+    return h;
+}
+
+int k_diffusion(SolverState &s) {
+    OrcMesh &m = *s.mesh;
+    ORC_TRY(s.a_di.zero());
+    hipLaunchKernelGGL(diffusion_k, dim3(grid_for(s.n)), dim3(kBlock), 0, ctx().stream, m.dev(), m.pat.dev(), s.mu, s.a_di.p,
+                       s.b_u_di.p, s.b_v_di.p, s.b_w_di.p, s.dev_status.p);
+    ORC_HIP(hipGetLastError());
+    return ORC_OK;
+}
+
+int k_init_momentum(SolverState &s) {
+    OrcMesh &m = *s.mesh;
+    DevBuf<double> *mats[3] = {&s.a_u, &s.a_v, &s.a_w};
+    for (auto *a : mats) {
+        ORC_TRY(a->zero());
+        hipLaunchKernelGGL(init_momentum_k, dim3(grid_for(s.n)), dim3(kBlock), 0, ctx().stream, m.dev(), m.pat.dev(), a->p);
+    }
+    ORC_HIP(hipGetLastError());
+    ORC_TRY(vec_fill(s.du.p, 1., s.n));  // diag = 1.0: what Rhie-Chow reads in iteration 1
+    ORC_TRY(vec_fill(s.dv.p, 1., s.n));
+    ORC_TRY(vec_fill(s.dw.p, 1., s.n));
+    return ORC_OK;
+}
+
+int solver_init(SolverState &s, OrcMesh *m, const OrcSettings *settings, double rho, double mu) {
+    ORC_TRY(ensure_init());
+    s.mesh = m;
+    s.settings = *settings;
+    s.rho = rho; s.mu = mu; s.n = m->n_cells;
+    ORC_TRY(validate_settings(s.settings));
+    const size_t n = (size_t)s.n, pad = (size_t)std::max<int64_t>(m->pat.padded, 1), F = (size_t)m->n_faces;
+    DevBuf<double> *nvec[] = {&s.u, &s.v, &s.w, &s.p, &s.p_prime, &s.b_u_di, &s.b_v_di, &s.b_w_di, &s.b_u, &s.b_v, &s.b_w, &s.b_p, &s.du, &s.dv, &s.dw};
+    for (auto *b : nvec) { ORC_TRY(b->alloc(n)); ORC_TRY(b->zero()); }
+    DevBuf<double> *mats[] = {&s.a_di, &s.a_u, &s.a_v, &s.a_w, &s.a_p};
+    for (auto *b : mats) { ORC_TRY(b->alloc(pad)); ORC_TRY(b->zero()); }
+    ORC_TRY(s.gp.alloc(3 * n));
+    ORC_TRY(s.gu.alloc(9 * n));
+    ORC_TRY(s.flux.alloc(F));
+    ORC_TRY(s.pf.alloc(F));
+    ORC_TRY(s.coef.alloc(F));
+    ORC_TRY(s.partials.alloc((size_t)8 * kMaxPartials));
+    ORC_TRY(s.scal.alloc(16));
+    ORC_TRY(s.dev_status.alloc(1));
+    ORC_TRY(s.dev_status.zero());
+    ORC_TRY(k_diffusion(s));       // solver.rs:41-42
+    ORC_TRY(k_init_momentum(s));   // solver.rs:43-45
+    int st = fetch_status(s);
+    if (st) return set_error(st, "unsupported boundary condition in mesh zones");
+    return ORC_OK;
+}
+
+int k_gradients(SolverState &s, bool need_gu) {
+    OrcMesh &m = *s.mesh;
+    hipLaunchKernelGGL(grad_p_k, dim3(grid_for(s.n)), dim3(kBlock), 0, ctx().stream, m.dev(), s.p.p, s.gp.p, s.settings.q1_compat, s.dev_status.p);
+    if (need_gu)
+        hipLaunchKernelGGL(grad_u_k, dim3(grid_for(s.n)), dim3(kBlock), 0, ctx().stream, m.dev(), s.u.p, s.v.p, s.w.p, s.gu.p, s.dev_status.p);
+    ORC_HIP(hipGetLastError());
+    return ORC_OK;
+}
+
+int k_face_flux(SolverState &s, bool momentum_phase) {
+    OrcMesh &m = *s.mesh;
+    FaceArgs A{s.u.p, s.v.p, s.w.p, s.p.p, s.gp.p, s.du.p, s.dv.p, s.dw.p, s.settings.velocity_interpolation,
+               s.settings.pressure_interpolation, s.settings.q1_compat, s.rho};
+    const int g = grid_for(m.n_faces);
+    if (momentum_phase)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(face_k<0>), dim3(g), dim3(kBlock), 0, ctx().stream, m.dev(), A, s.flux.p, s.pf.p, s.coef.p, s.dev_status.p);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(face_k<1>), dim3(g), dim3(kBlock), 0, ctx().stream, m.dev(), A, s.flux.p, s.pf.p, s.coef.p, s.dev_status.p);
+    ORC_HIP(hipGetLastError());
+    return ORC_OK;
+}
+
+int k_momentum(SolverState &s, double *peclet_host) {
+    OrcMesh &m = *s.mesh;
+    MomentumArgs A{s.u.p, s.v.p, s.w.p, s.gu.p, s.flux.p, s.pf.p, s.a_di.p, s.b_u_di.p, s.b_v_di.p, s.b_w_di.p,
+                   s.a_u.p, s.a_v.p, s.a_w.p, s.b_u.p, s.b_v.p, s.b_w.p, s.du.p, s.dv.p, s.dw.p, s.settings.momentum,
+                   s.settings.q1_compat, s.rho};
+    const int g = grid_for(s.n);
+    hipLaunchKernelGGL(momentum_k, dim3(g), dim3(kBlock), 0, ctx().stream, m.dev(), m.pat.dev(), A, s.partials.p);
+    hipLaunchKernelGGL(reduce_minmax_k, dim3(1), dim3(64), 0, ctx().stream, s.partials.p, g, s.scal.p + 8);
+    ORC_HIP(hipGetLastError());
+    if (peclet_host) {
+        ORC_HIP(hipMemcpyAsync(peclet_host, s.scal.p + 8, 3 * sizeof(double), hipMemcpyDeviceToHost, ctx().stream));
+        ORC_HIP(hipStreamSynchronize(ctx().stream));
+        peclet_host[0] /= (double)s.n;  // discretization.rs:355
+    }
+    return ORC_OK;
+}
+
+int k_pressure_correction(SolverState &s) {
+    OrcMesh &m = *s.mesh;
+    ORC_TRY(k_face_flux(s, false));
+    hipLaunchKernelGGL(pressure_k, dim3(grid_for(s.n)), dim3(kBlock), 0, ctx().stream, m.dev(), m.pat.dev(), s.flux.p, s.coef.p, s.rho,
+                       s.a_p.p, s.b_p.p);
+    ORC_HIP(hipGetLastError());
+    return ORC_OK;
+}
+
+int k_apply_correction(SolverState &s, double *sums_host) {
+    OrcMesh &m = *s.mesh;
+    const int g = grid_for(s.n);
+    hipLaunchKernelGGL(correction_k, dim3(g), dim3(kBlock), 0, ctx().stream, m.dev(), s.du.p, s.dv.p, s.dw.p, s.p_prime.p, s.u.p, s.v.p,
+                       s.w.p, s.p.p, s.settings.pressure_relaxation, s.settings.momentum_relaxation, s.partials.p, s.dev_status.p);
+    ORC_HIP(hipGetLastError());
+    ORC_TRY(reduce_partials(s.partials.p, g, 5, s.scal.p));
+    if (sums_host) {
+        ORC_HIP(hipMemcpyAsync(sums_host, s.scal.p, 5 * sizeof(double), hipMemcpyDeviceToHost, ctx().stream));
+        ORC_HIP(hipStreamSynchronize(ctx().stream));
+    }
+    return ORC_OK;
+}
+
+static int solve_field(SolverState &s, DevBuf<double> &a, DevBuf<double> &b, DevBuf<double> &x) {
+    MatView A;
+    A.P = s.mesh->pat.dev();
+    A.val = a.p;
+    A.symmetric = s.mesh->pat.symmetric;
+    const OrcSettings &t = s.settings;
+    ctx().breakdown_guard = t.breakdown_guard != 0;
+    return iterative_solve_dev(A, b.p, x.p, t.iterations, t.solver_type, t.relaxation, t.relative_convergence_threshold,
+                               t.preconditioner, s.arena, &s.stats);
+}
+
+// One pass of solver.rs:60-222 per iteration.
+static void debug_field(SolverState &s, const char *name, const DevBuf<double> &f) {
+    std::vector<double> h((size_t)s.n);
+    (void)f.download(h.data(), (size_t)s.n);
+    int nn = 0;
+    double mx = 0.;
+    for (double x : h) { if (std::isnan(x)) nn++; else mx = std::max(mx, std::fabs(x)); }
+    fprintf(stderr, "[orc debug] it %llu %s: nan=%d max=%.17g\n", (unsigned long long)s.iterations_done, name, nn, mx);
+}
+
+int solver_iterate(SolverState &s, uint64_t iterations, double *report) {
+    const bool tvd = is_tvd(s.settings.momentum);
+    const bool dbg = getenv("ORC_DEBUG_NAN") != nullptr;
+    for (uint64_t it = 0; it < iterations; ++it) {
+        double peclet[3] = {0., 0., 0.};
+        ORC_TRY(k_gradients(s, tvd));
+        ORC_TRY(k_face_flux(s, true));
+        ORC_TRY(k_momentum(s, report ? peclet : nullptr));       // :61-82
+        if (dbg) { debug_field(s, "b_u", s.b_u); debug_field(s, "b_v", s.b_v); debug_field(s, "b_w", s.b_w); }
+        ORC_TRY(solve_field(s, s.a_u, s.b_u, s.u));              // :99-110
+        if (dbg) debug_field(s, "u", s.u);
+        ORC_TRY(solve_field(s, s.a_v, s.b_v, s.v));              // :112-123
+        if (dbg) debug_field(s, "v", s.v);
+        ORC_TRY(solve_field(s, s.a_w, s.b_w, s.w));              // :125-136
+        if (dbg) debug_field(s, "w", s.w);
+        ORC_TRY(k_pressure_correction(s));                       // :137-148
+        ORC_TRY(vec_fill(s.p_prime.p, 0., s.n));                 // :167
+        if (dbg) debug_field(s, "b_p", s.b_p);
+        ORC_TRY(solve_field(s, s.a_p, s.b_p, s.p_prime));        // :168-179
+        if (dbg) debug_field(s, "p_prime", s.p_prime);
+        double sums[5];
+        ORC_TRY(k_apply_correction(s, sums));                    // :193-208
+        s.iterations_done++;
+        const double nn = (double)s.n * (double)ctx().world;  // global cell count is handled by the caller in multi-GPU runs
+        (void)nn;
+        const double u_avg = sums[2] / (double)s.n, v_avg = sums[3] / (double)s.n, w_avg = sums[4] / (double)s.n;
+        if (report) {
+            double *r = report + 8 * it;
+            r[0] = u_avg; r[1] = v_avg; r[2] = w_avg; r[3] = peclet[0]; r[4] = peclet[1]; r[5] = peclet[2];
+            r[6] = std::sqrt(sums[1]); r[7] = std::sqrt(sums[0]);
+        }
+        int st = 0;
+        ORC_HIP(hipMemcpyAsync(&st, s.dev_status.p, sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
+        ORC_HIP(hipStreamSynchronize(ctx().stream));
+        if (st) return st;
+        if (std::isnan(u_avg) || std::isnan(v_avg) || std::isnan(w_avg)) return ORC_ERR_SOLUTION_DIVERGED;  // :217-221
+    }
+    return ORC_OK;
+}
+
+}  // namespace orc

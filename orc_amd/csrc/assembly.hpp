@@ -1,0 +1,87 @@
+// assembly.hpp — device mesh (SoA image of mesh::Mesh) and the SIMPLE-iteration state.
+#pragma once
+#include <memory>
+
+#include "linalg.hpp"
+
+namespace orc {
+
+// Device pointers of the mesh, passed to kernels by value.  AoS `Vec<Face>` / `Vec<Cell>` with heap
+// adjacency (mesh.rs:140-187) becomes structure-of-arrays so face- and cell-parallel kernels read
+// coalesced; the zone HashMap lookup (solver.rs:1113) becomes a per-face zone index into three
+// tiny tables.
+struct MeshDev {
+    int64_t n_cells = 0, n_faces = 0;
+    int32_t n_zones = 0;
+    const int32_t *c0 = nullptr, *c1 = nullptr, *fzone = nullptr;
+    const double *area = nullptr, *nx = nullptr, *ny = nullptr, *nz = nullptr;
+    const double *fcx = nullptr, *fcy = nullptr, *fcz = nullptr;
+    const double *ccx = nullptr, *ccy = nullptr, *ccz = nullptr, *vol = nullptr;
+    const int32_t *cfp = nullptr;    // [n+1] cell -> face list (Cell.face_indices, ascending face id)
+    const int32_t *cf = nullptr;     // face ids
+    const int32_t *cfpos = nullptr;  // SELL element offset of A(cell, neighbour) for that face, -1 on boundary faces
+    const int32_t *ztype = nullptr;  // OrcFaceConditionType per zone
+    const double *zscal = nullptr;   // FaceZone.scalar_value
+    const double *zvec = nullptr;    // FaceZone.vector_value [3Z]
+};
+
+}  // namespace orc
+
+struct OrcMesh {
+    int64_t n_cells = 0, n_faces = 0, n_cell_faces = 0;
+    int32_t n_zones = 0;
+    orc::DevBuf<int32_t> c0, c1, fzone, cfp, cf, cfpos, ztype;
+    orc::DevBuf<double> area, nx, ny, nz, fcx, fcy, fcz, ccx, ccy, ccz, vol, zscal, zvec;
+    orc::SellMatrix pat;  // shared sparsity of a_di, a_u, a_v, a_w, A_p
+    std::vector<int64_t> h_row_ptr, h_col;  // the same pattern in CSR (ORC order) for the C ABI
+    orc::MeshDev dev() const;
+};
+
+namespace orc {
+
+struct Fields {
+    double *u, *v, *w, *p;
+};
+
+// Everything solve_steady allocates before its loop (solver.rs:39-49) plus per-iteration scratch.
+struct SolverState {
+    OrcMesh *mesh = nullptr;
+    OrcSettings settings;
+    double rho = 0., mu = 0.;
+    int64_t n = 0;
+    DevBuf<double> u, v, w, p, p_prime;
+    DevBuf<double> a_di, a_u, a_v, a_w, a_p;            // SELL value arrays (mesh pattern)
+    DevBuf<double> b_u_di, b_v_di, b_w_di, b_u, b_v, b_w, b_p;
+    DevBuf<double> du, dv, dw;                           // a_{u,v,w}.get(i,i): what Rhie-Chow reads
+    DevBuf<double> gp;                                   // grad p  [3][n]
+    DevBuf<double> gu;                                   // grad U  [9][n]  (TVD only)
+    DevBuf<double> flux, pf, coef;                       // per face: outward (from c0) flux, face pressure, p' coefficient
+    DevBuf<double> partials, scal;
+    DevBuf<int> dev_status;
+    Arena arena;
+    SolveStats stats;
+    uint64_t iterations_done = 0;
+};
+
+int mesh_upload(OrcMesh &m, int64_t n_cells, int64_t n_faces, int32_t n_zones, const int64_t *face_c0, const int64_t *face_c1,
+                const int32_t *face_zone, const double *face_area, const double *face_normal, const double *face_centroid,
+                const double *cell_centroid, const double *cell_volume, const int64_t *cell_face_ptr, const int64_t *cell_faces,
+                const int32_t *zone_type, const double *zone_scalar, const double *zone_vector);
+
+int solver_init(SolverState &s, OrcMesh *m, const OrcSettings *settings, double rho, double mu);
+// kernels (all asynchronous on the library stream)
+int k_diffusion(SolverState &s);                 // K14  discretization.rs:39-131
+int k_init_momentum(SolverState &s);             // discretization.rs:450-472
+int k_gradients(SolverState &s, bool need_gu);   // K9   solver.rs:774-802, 874-902
+int k_face_flux(SolverState &s, bool with_pf);   // K10  solver.rs:1007-1150
+int k_momentum(SolverState &s, double *peclet_host /*3, may be null*/);  // K11  discretization.rs:134-356
+int k_pressure_correction(SolverState &s);       // K12  discretization.rs:359-448
+int k_apply_correction(SolverState &s, double *sums_host /*5: p'^2, |dU|^2, sum u, sum v, sum w*/);  // K13 solver.rs:1170-1227
+int solver_iterate(SolverState &s, uint64_t iterations, double *report);
+int fetch_status(SolverState &s);
+
+}  // namespace orc
+
+struct OrcSolver {
+    orc::SolverState st;
+};

@@ -25,6 +25,7 @@ struct Ctx {
     hipStream_t stream = nullptr;
     std::string last_error;
     bool profile = false;
+    bool breakdown_guard = true;  // OrcSettings.breakdown_guard of the running solve
     // multi-GPU (comm.cpp)
     int rank = 0, world = 1;
     void *nccl_comm = nullptr;

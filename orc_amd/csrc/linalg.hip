@@ -193,11 +193,11 @@ struct EpiTs {  // t = A s ; partials t.s, t.t            (linear_algebra.rs:260
 };
 
 template <class Epi>
-static int launch_spmv(const MatView &A, const double *x, const Epi &epi, double *partials, int *grid_out) {
+static int launch_spmv(const MatView &A, const double *x, const Epi &epi, double *partials, int *grid_out, const double *skip_flags = nullptr) {
     const int g = spmv_grid(A.P.n_slices);
     if (grid_out) *grid_out = g;
     if (A.P.n == 0) return ORC_OK;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
     ORC_HIP(hipGetLastError());
     return ORC_OK;
 }
@@ -209,41 +209,78 @@ int spmv_dev(const MatView &A, const double *x, double *y) {
 
 // ------------------------------------------------------------------ BiCGSTAB (linear_algebra.rs:247-269)
 // scal[] layout (device doubles):
-enum { S_RHO0 = 0, S_RHO1 = 1, S_SUM_NU = 2, S_TS = 3, S_TT = 4, S_COUNT = 8 };
+enum { S_RHO0 = 0, S_RHO1 = 1, S_SUM_NU = 2, S_TS = 3, S_TT = 4, S_FROZEN = 5, S_FROZEN2 = 6, S_COUNT = 8 };
+
+// Breakdown guard (OrcSettings.breakdown_guard, new-build extension).  The reference iterates a fixed
+// count with no test at all (:255-268); when rho, r_hat.nu, t.t or omega is exactly 0 (a cancelling
+// tree sum, a zero right-hand side, a converged start) it divides 0/0 and the SIMPLE loop panics
+// with "solution diverged".  With the guard the solve freezes instead: x keeps its last finite
+// value and the remaining iterations are no-ops.  Nothing changes when no denominator is 0.
+// S_FROZEN is written only by kernels whose reaction to a breakdown is "do nothing" (so a block
+// that starts late and sees the flag behaves like one that evaluated the test itself); the x/r
+// update kernel reacts with x = h, r = s and therefore publishes through S_FROZEN2, which it does
+// not read.
+__device__ __forceinline__ bool bicg_frozen(const double *__restrict__ scal, int guard) {
+    return guard && (scal[S_FROZEN] != 0. || scal[S_FROZEN2] != 0.);
+}
+__device__ __forceinline__ bool finite_nonzero(double v) { return v != 0. && isfinite(v); }
 
 // s = r - alpha*nu, alpha = rho / (r_hat_0 . nu)                     (:257, :259)
-__global__ void bicg_s_k(const double *__restrict__ scal, int rho_idx, const double *__restrict__ r, const double *__restrict__ nu,
-                         double *__restrict__ s, int64_t n) {
+__global__ void bicg_s_k(double *__restrict__ scal, int rho_idx, const double *__restrict__ r, const double *__restrict__ nu,
+                         double *__restrict__ s, int64_t n, int guard) {
+    if (bicg_frozen(scal, guard)) return;
     const double alpha = scal[rho_idx] / scal[S_SUM_NU];
+    if (guard && !(finite_nonzero(scal[rho_idx]) && finite_nonzero(scal[S_SUM_NU]) && isfinite(alpha))) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) scal[S_FROZEN] = 1.;
+        return;
+    }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) s[i] = r[i] - alpha * nu[i];
 }
 // h = x + alpha p ; x = h + omega s ; r = s - omega t ; partial sum(r)   (:258, :261-263, :265)
-__global__ __launch_bounds__(kBlock) void bicg_xr_k(const double *__restrict__ scal, int rho_idx, double *__restrict__ x,
+__global__ __launch_bounds__(kBlock) void bicg_xr_k(double *__restrict__ scal, int rho_idx, double *__restrict__ x,
                                                     const double *__restrict__ p, const double *__restrict__ s,
                                                     const double *__restrict__ t, double *__restrict__ r, int64_t n,
-                                                    double *__restrict__ partials) {
+                                                    double *__restrict__ partials, int guard) {
     __shared__ double lds[8];
+    if (guard && scal[S_FROZEN] != 0.) return;
     const double alpha = scal[rho_idx] / scal[S_SUM_NU];
-    const double omega = scal[S_TS] / scal[S_TT];
+    double omega = scal[S_TS] / scal[S_TT];
+    const bool bad = guard && !(finite_nonzero(scal[S_TT]) && isfinite(omega));
     double acc = 0.;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const double h = x[i] + alpha * p[i];
-        const double si = s[i];
-        x[i] = h + omega * si;
-        const double ri = si - omega * t[i];
-        r[i] = ri;
-        acc += ri;
+    if (bad) {
+        // t = A s vanished (s is already the zero residual) or overflowed: take x = h, r = s and stop
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+            x[i] = x[i] + alpha * p[i];
+            const double si = s[i];
+            r[i] = si;
+            acc += si;
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) scal[S_FROZEN2] = 1.;
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+            const double h = x[i] + alpha * p[i];
+            const double si = s[i];
+            x[i] = h + omega * si;
+            const double ri = si - omega * t[i];
+            r[i] = ri;
+            acc += ri;
+        }
     }
     const double tsum = block_sum(acc, lds);
     if (threadIdx.x == 0) partials[blockIdx.x] = tsum;
 }
 // beta = rho/rho_prev * alpha/omega ; p = r + beta (p - omega nu)       (:266-267)
-__global__ void bicg_p_k(const double *__restrict__ scal, int rho_prev_idx, int rho_idx, const double *__restrict__ r,
-                         const double *__restrict__ nu, double *__restrict__ p, int64_t n) {
+__global__ void bicg_p_k(double *__restrict__ scal, int rho_prev_idx, int rho_idx, const double *__restrict__ r,
+                         const double *__restrict__ nu, double *__restrict__ p, int64_t n, int guard) {
+    if (bicg_frozen(scal, guard)) return;
     const double rho_prev = scal[rho_prev_idx], rho = scal[rho_idx];
     const double alpha = rho_prev / scal[S_SUM_NU];
     const double omega = scal[S_TS] / scal[S_TT];
     const double beta = rho / rho_prev * alpha / omega;
+    if (guard && !(finite_nonzero(omega) && isfinite(beta))) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) scal[S_FROZEN] = 1.;
+        return;
+    }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         p[i] = r[i] + beta * (p[i] - omega * nu[i]);
 }
@@ -261,22 +298,24 @@ static int bicg_alloc(Arena &arena, int64_t n, BicgWork &w) {
     ORC_TRY(arena.alloc(nn, &w.t));
     ORC_TRY(arena.alloc((size_t)2 * kMaxPartials, &w.partials));
     ORC_TRY(arena.alloc((size_t)S_COUNT, &w.scal));
+    ORC_HIP(hipMemsetAsync(w.scal, 0, S_COUNT * sizeof(double), ctx().stream));
     return ORC_OK;
 }
 
-static int bicg_iteration(const MatView &A, double *x, const BicgWork &w, uint64_t it) {
+static int bicg_iteration(const MatView &A, double *x, const BicgWork &w, uint64_t it, int guard) {
     const int64_t n = A.P.n;
     const int vg = grid_for(n);
     const int cur = (int)(it & 1), nxt = cur ^ 1;
+    const double *skip = guard ? w.scal + S_FROZEN : nullptr;  // frozen solves skip their SpMVs too
     int g = 0;
-    ORC_TRY(launch_spmv(A, w.p, EpiStoreSum{w.nu}, w.partials, &g));           // nu = A p, sum(nu)
+    ORC_TRY(launch_spmv(A, w.p, EpiStoreSum{w.nu}, w.partials, &g, skip));     // nu = A p, sum(nu)
     ORC_TRY(reduce_partials(w.partials, g, 1, w.scal + S_SUM_NU));
-    hipLaunchKernelGGL(bicg_s_k, dim3(vg), dim3(kBlock), 0, ctx().stream, w.scal, S_RHO0 + cur, w.r, w.nu, w.s, n);
-    ORC_TRY(launch_spmv(A, w.s, EpiTs{w.s, w.t}, w.partials, &g));             // t = A s, t.s, t.t
+    hipLaunchKernelGGL(bicg_s_k, dim3(vg), dim3(kBlock), 0, ctx().stream, w.scal, S_RHO0 + cur, w.r, w.nu, w.s, n, guard);
+    ORC_TRY(launch_spmv(A, w.s, EpiTs{w.s, w.t}, w.partials, &g, skip));       // t = A s, t.s, t.t
     ORC_TRY(reduce_partials(w.partials, g, 2, w.scal + S_TS));
-    hipLaunchKernelGGL(bicg_xr_k, dim3(vg), dim3(kBlock), 0, ctx().stream, w.scal, S_RHO0 + cur, x, w.p, w.s, w.t, w.r, n, w.partials);
+    hipLaunchKernelGGL(bicg_xr_k, dim3(vg), dim3(kBlock), 0, ctx().stream, w.scal, S_RHO0 + cur, x, w.p, w.s, w.t, w.r, n, w.partials, guard);
     ORC_TRY(reduce_partials(w.partials, vg, 1, w.scal + S_RHO0 + nxt));        // rho = r_hat_0 . r
-    hipLaunchKernelGGL(bicg_p_k, dim3(vg), dim3(kBlock), 0, ctx().stream, w.scal, S_RHO0 + cur, S_RHO0 + nxt, w.r, w.nu, w.p, n);
+    hipLaunchKernelGGL(bicg_p_k, dim3(vg), dim3(kBlock), 0, ctx().stream, w.scal, S_RHO0 + cur, S_RHO0 + nxt, w.r, w.nu, w.p, n, guard);
     ORC_HIP(hipGetLastError());
     return ORC_OK;
 }
@@ -287,10 +326,11 @@ static int bicgstab_dev(const MatView &A, const double *b, double *x, uint64_t i
     Arena::Mark mk = arena.mark();
     BicgWork w;
     ORC_TRY(bicg_alloc(arena, n, w));
+    const int guard = ctx().breakdown_guard ? 1 : 0;
     int g = 0;
     ORC_TRY(launch_spmv(A, x, EpiResidual{b, w.r, w.p}, w.partials, &g));      // r = b - A x ; p = r ; rho = sum(r)
     ORC_TRY(reduce_partials(w.partials, g, 1, w.scal + S_RHO0));
-    for (uint64_t it = 0; it < iteration_count; ++it) ORC_TRY(bicg_iteration(A, x, w, it));
+    for (uint64_t it = 0; it < iteration_count; ++it) ORC_TRY(bicg_iteration(A, x, w, it, guard));
     arena.release(mk);
     return ORC_OK;
 }
@@ -306,9 +346,9 @@ int bench_bicgstab_dev(const MatView &A, const double *b, double *x, int reps, A
     hipEvent_t e0, e1;
     ORC_HIP(hipEventCreate(&e0));
     ORC_HIP(hipEventCreate(&e1));
-    ORC_TRY(bicg_iteration(A, x, w, 0));  // warm
+    ORC_TRY(bicg_iteration(A, x, w, 0, 0));  // warm; guard off so every timed launch does full work
     ORC_HIP(hipEventRecord(e0, ctx().stream));
-    for (int it = 1; it <= reps; ++it) ORC_TRY(bicg_iteration(A, x, w, (uint64_t)it));
+    for (int it = 1; it <= reps; ++it) ORC_TRY(bicg_iteration(A, x, w, (uint64_t)it, 0));
     ORC_HIP(hipEventRecord(e1, ctx().stream));
     ORC_HIP(hipEventSynchronize(e1));
     ORC_HIP(hipEventElapsedTime(ms, e0, e1));

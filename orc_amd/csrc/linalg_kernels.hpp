@@ -41,8 +41,10 @@ struct SliceWalk {
 // may accumulate up to two per-thread reduction terms; partial sums per workgroup go to
 // partials[q * gridDim.x + blockIdx.x] and are folded by reduce_partials_k.
 template <class Epi>
-__global__ __launch_bounds__(kBlock) void spmv_k(MatView A, const double *__restrict__ x, Epi epi, double *__restrict__ partials) {
+__global__ __launch_bounds__(kBlock) void spmv_k(MatView A, const double *__restrict__ x, Epi epi, double *__restrict__ partials,
+                                                 const double *__restrict__ skip_flags /* 2 doubles or null: non-zero = no-op */) {
     __shared__ double lds[8];
+    if (skip_flags && (skip_flags[0] != 0. || skip_flags[1] != 0.)) return;
     const int lane = threadIdx.x & 63;
     double r0 = 0., r1 = 0.;
     SliceWalk w(A.P.n_slices);

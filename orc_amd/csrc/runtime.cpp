@@ -1,4 +1,5 @@
 // runtime.cpp — process-wide context (device, stream, error text), arena allocator.
+#include <algorithm>
 #include <cstdarg>
 
 #include "common.hpp"
@@ -131,7 +132,13 @@ void orc_settings_default(OrcSettings *s) {  // lib.rs:58-86
     s->relative_convergence_threshold = 1e-3;
     s->preconditioner = ORC_PRECOND_JACOBI;
     s->q1_compat = 1;
+    s->breakdown_guard = 1;
     s->frozen_diagonals = 1;  // the device evaluates all Rhie-Chow diagonals from the previous iteration
+}
+
+int orc_set_breakdown_guard(int on) {
+    orc::ctx().breakdown_guard = on != 0;
+    return ORC_OK;
 }
 
 int orc_profile_enable(int on) {

@@ -36,6 +36,11 @@ def iterative_solve(a, b, solution_vector, iteration_count, method, relaxation_f
     return st
 
 
+def set_breakdown_guard(on):
+    """process-wide OrcSettings.breakdown_guard for iterative_solve (default on); off = NaN like the reference"""
+    check(lib().orc_set_breakdown_guard(C.c_int(1 if on else 0)))
+
+
 def last_jacobi_sweeps():
     return lib().orc_last_jacobi_sweeps()
 

@@ -12,7 +12,7 @@ class NumericalSettings(C.Structure):
         ("solver_type", C.c_int32), ("preconditioner", C.c_int32), ("q1_compat", C.c_int32),
         ("iterations", C.c_uint64), ("momentum_relaxation", C.c_double), ("pressure_relaxation", C.c_double),
         ("relaxation", C.c_double), ("relative_convergence_threshold", C.c_double),
-        ("frozen_diagonals", C.c_int32), ("reserved", C.c_int32),
+        ("frozen_diagonals", C.c_int32), ("breakdown_guard", C.c_int32),
     ]
 
     @classmethod

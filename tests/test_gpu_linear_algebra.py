@@ -88,10 +88,42 @@ def test_bicgstab_zero_iterations_and_nan_propagation(gpu, oracle):
     iterative_solve(a, b, x, 0, BICGSTAB, 0.5, 1e-3, PRE_JACOBI)
     assert np.array_equal(x, np.zeros(n))
     # b = 0, x = 0: rho = 0 and r_hat.nu = 0 -> alpha = 0/0: the reference has no breakdown guard
-    iterative_solve(a, b, x, 2, BICGSTAB, 0.5, 1e-3, PRE_JACOBI)
+    from orc_amd.linear_algebra import set_breakdown_guard
+    try:
+        set_breakdown_guard(False)  # reference behaviour
+        iterative_solve(a, b, x, 2, BICGSTAB, 0.5, 1e-3, PRE_JACOBI)
+    finally:
+        set_breakdown_guard(True)
     xo = np.zeros(n)
     oracle.iterative_solve(oracle.Csr.from_scipy(a), b, xo, 2, BICGSTAB, 0.5, 1e-3, PRE_JACOBI)
     assert np.isnan(xo).all() and np.isnan(x).all()
+    # with the guard (product default) the solve freezes: x keeps its (exact) value
+    x = np.zeros(n)
+    iterative_solve(a, b, x, 2, BICGSTAB, 0.5, 1e-3, PRE_JACOBI)
+    assert np.array_equal(x, np.zeros(n))
+
+
+def test_breakdown_guard_is_inert_without_breakdown_and_stops_past_convergence(gpu, oracle):
+    """guard on/off give identical bits while no denominator is 0; far past convergence (where the
+    reference divides 0/0) the guarded solve returns the converged iterate."""
+    from orc_amd.linear_algebra import iterative_solve, set_breakdown_guard
+    a = fv_like_matrix(7, 5, 3)
+    n = a.shape[0]
+    xs = splitmix64_uniform(n, 4)
+    b = a @ xs
+    res = []
+    for on in (True, False):
+        try:
+            set_breakdown_guard(on)
+            x = np.zeros(n)
+            iterative_solve(a, b, x, 10, BICGSTAB, 0.5, 1e-3, PRE_JACOBI)
+            res.append(x)
+        finally:
+            set_breakdown_guard(True)
+    assert np.array_equal(res[0], res[1])
+    x = np.zeros(n)
+    iterative_solve(a, b, x, 2000, BICGSTAB, 0.5, 1e-3, PRE_JACOBI)
+    assert np.isfinite(x).all() and rel(x, xs) < 1e-9
 
 
 @pytest.mark.parametrize("precond", [PRE_NONE, PRE_JACOBI])
