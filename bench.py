@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py — SIMPLE iterations/s on the ~10M-cell synthetic hex channel (BASELINE.json configs[3]) on MI355X.
+
+One "step" = one full SIMPLE iteration of solver::solve_steady (solver.rs:60-222): momentum assembly, three
+momentum solves, pressure-correction assembly + solve, correction — all device-resident in liborc_amd.so.
+N = 1: 400 x 160 x 160 = 10 240 000 hex cells, UMIST TVD momentum, Rhie-Chow, SecondOrder,
+reference Multigrid arm (pairwise-aggregation AMG with BiCGSTAB smoother) + Jacobi preconditioning.
+N > 1: weak scaling, every rank owns a 400 x 160 x 160 slab of a (400 N) x 160 x 160 channel.
+
+Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (CSR SpMV inside BiCGSTAB, HBM bound,
+measured live with HIP events on the library stream) and `cpu_baseline` (the CPU oracle = restatement of
+ORC's Rust path, 1 core, on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy ceiling)
+REF_CELLS = 400 * 160 * 160
+
+
+def initial_fields(cc, dp_dx=5.0, h=1e-3, mu=1e-3, lx=0.002, seed=0x4F5243, x0=0.0, lx_total=None):
+    """Analytical Poiseuille profile (tests.rs:26-29) + 2 % splitmix64 noise; linear pressure drop."""
+    from orc_amd.mesh import splitmix64_uniform
+    n = len(cc)
+    y = cc[:, 1]
+    lx_total = lx_total or lx
+    u = 1.0 / (2.0 * mu) * dp_dx * (y * y - h * y) * (1.0 + 0.02 * splitmix64_uniform(n, seed))
+    v = 1e-7 * splitmix64_uniform(n, seed + 1)
+    w = 1e-7 * splitmix64_uniform(n, seed + 2)
+    p = -dp_dx * lx_total * (1.0 - (cc[:, 0] + x0) / lx_total) * (1.0 + 1e-3 * splitmix64_uniform(n, seed + 3))
+    return u, v, w, p
+
+
+def cpu_baseline(settings_kw, sample=(100, 40, 40), iters=2):
+    """The CPU oracle (oracle/: single-threaded C restatement of ORC's Rust path) timed on a bounded sample of
+    the same workload: same generator, BCs, settings and initial-field recipe at 1/64 of the cells."""
+    from oracle import pyoracle as po
+    from orc_amd.mesh import hex_channel, set_channel_bcs
+    nx, ny, nz = sample
+    a = set_channel_bcs(hex_channel(nx, ny, nz))
+    om = po.Mesh.from_arrays(a)
+    u, v, w, p = initial_fields(np.asarray(a["cell_centroid"]))
+    kw = dict(settings_kw)
+    kw["frozen_diagonals"] = 0  # the reference's own mode
+    kw["breakdown_guard"] = 0
+    s = po.default_settings(**kw)
+    t0 = time.perf_counter()
+    st, _ = po.solve_steady(om, u, v, w, p, s, 1000.0, 1e-3, iters)
+    dt = time.perf_counter() - t0
+    n = nx * ny * nz
+    it_per_s_sample = iters / dt
+    return {
+        "value": it_per_s_sample * n / REF_CELLS,
+        "unit": "SIMPLE iterations/s (10.24M-cell equivalent)",
+        "cores": 1,
+        "kind": "port",
+        "sample": "%dx%dx%d hex channel (%d cells = 1/%d of the workload), %d SIMPLE iterations in %.2f s, status %d; scaled by cells"
+                  % (nx, ny, nz, n, REF_CELLS // n, iters, dt, st),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--nx", type=int, default=400)
+    ap.add_argument("--ny", type=int, default=160)
+    ap.add_argument("--nz", type=int, default=160)
+    ap.add_argument("--solver", default="multigrid", choices=["multigrid", "bicgstab", "jacobi", "multigrid_gs", "bicgstab_gs"])
+    ap.add_argument("--momentum", default="umist", choices=["ud", "cd1", "quick", "umist"])
+    ap.add_argument("--inner", type=int, default=50, help="matrix_solver.iterations (lib.rs:80)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--spmv-reps", type=int, default=50)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group(backend="gloo")  # control plane only; the data path uses RCCL inside liborc_amd
+
+    import orc_amd
+    from orc_amd.mesh import Mesh, hex_channel, set_channel_bcs
+    from orc_amd.settings import MomentumDiscretization as MD
+    from orc_amd.settings import NumericalSettings, SolutionMethod as SM
+    from orc_amd.solver import Solver
+
+    orc_amd.init(local_rank)
+    if world > 1:
+        from orc_amd import parallel
+        parallel.init_comm(dist, rank, world)
+
+    solver_map = {"multigrid": SM.Multigrid, "bicgstab": SM.BiCGSTAB, "jacobi": SM.Jacobi, "multigrid_gs": SM.Multigrid_GS,
+                  "bicgstab_gs": SM.BiCGSTAB_GS}
+    mom_map = {"ud": MD.UD, "cd1": MD.CD1, "quick": MD.TVD_QUICK, "umist": MD.TVD_UMIST}
+    settings_kw = dict(momentum=mom_map[args.momentum], solver_type=solver_map[args.solver], iterations=args.inner)
+    settings = NumericalSettings.default(**settings_kw)
+
+    nx, ny, nz = args.nx, args.ny, args.nz
+    t_setup = time.perf_counter()
+    if world == 1:
+        a = set_channel_bcs(hex_channel(nx, ny, nz))
+        mesh = Mesh(a)
+        u, v, w, p = initial_fields(np.asarray(a["cell_centroid"]))
+        solver = Solver(mesh, settings, 1000.0, 1e-3)
+        solver.set_fields(u, v, w, p)
+        n_cells_total = mesh.n_cells
+        nnz = mesh.nnz
+    else:
+        from orc_amd import parallel
+        solver, mesh, n_cells_total, nnz = parallel.make_slab_solver(nx, ny, nz, rank, world, settings, initial_fields)
+    del_a = None
+    t_setup = time.perf_counter() - t_setup
+
+    def barrier_sync():
+        orc_amd._lib.check(orc_amd._lib.lib().orc_synchronize())
+        if dist is not None:
+            dist.barrier()
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+        except Exception:
+            pass
+
+    solver.iterate(args.warmup) if args.warmup > 0 else None
+    barrier_sync()
+    t0 = time.perf_counter()
+    st, rep = solver.iterate(args.steps, report=True, raise_on_error=False)
+    barrier_sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # dominant kernel: CSR(SELL-64) SpMV inside BiCGSTAB, timed live with HIP events on the library stream
+    spmv_ms, _ = solver.bench_spmv(args.spmv_reps)
+    n_local = mesh.n_cells
+    nnz_local = mesh.nnz
+    spmv_bytes = 12.0 * nnz_local + 20.0 * n_local  # f64 value + i32 column per nnz; row_ptr, x, y per row
+    achieved = spmv_bytes / (spmv_ms * 1e-3) / 1e9
+    bicg_ms = solver.bench_bicgstab_iteration(10)
+    bicg_bytes = 2.0 * spmv_bytes + 104.0 * n_local
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        units = n_cells_total / float(REF_CELLS)  # 10.24M-cell SIMPLE iterations per step (N at weak scaling)
+        out = {
+            "metric": "SIMPLE iterations/s (10.24M-cell hex channel equivalents; = iterations/s at N=1)",
+            "value": units * args.steps / dt,
+            "unit": "iterations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "status": int(st),
+            "config": {
+                "workload": "BASELINE configs[3]: synthetic hex channel %dx%dx%d per GPU (%d cells total), TVD-%s momentum, "
+                            "Rhie-Chow + SecondOrder, solver=%s (%d inner iterations) + Jacobi preconditioner, full SIMPLE iteration"
+                            % (nx, ny, nz, n_cells_total, args.momentum.upper(), args.solver, args.inner),
+                "cells_total": int(n_cells_total),
+                "parallelism": "cell slabs x%d, RCCL halo + all-reduce" % world if world > 1 else "single GPU",
+                "setup_s": round(t_setup, 2),
+            },
+            "roofline": {
+                "kernel": "spmv_k<EpiStore> (CSR/SELL-64 SpMV, a_u of the momentum system)",
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "avg_launch_ms": spmv_ms,
+                "algorithmic_bytes_per_launch": spmv_bytes,
+                "bicgstab_iteration_ms": bicg_ms,
+                "bicgstab_iteration_GBs": bicg_bytes / (bicg_ms * 1e-3) / 1e9,
+            },
+            "report_last": [float(x) for x in rep[-1]] if rep is not None and len(rep) else None,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(settings_kw)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

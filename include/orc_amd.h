@@ -72,6 +72,13 @@ int64_t orc_last_jacobi_sweeps(void);
 int orc_csr_spmv(int64_t n, const int64_t *row_ptr, const int64_t *col_idx, const double *values, const double *x,
                  double *y, int reps, double *avg_ms);
 
+/* Test hooks for the two private functions under the Multigrid arm (linear_algebra.rs:12-63, :80-84):
+ * partner[i] = strongest_unmerged_neighbor of row i (-1 = none) of build_restriction_matrix(Strongest), and
+ * a' = (R a) R^T as CSR.  Call with out_col == NULL to get the sizes (out_n_coarse, out_nnz). */
+int orc_amg_coarsen(int64_t n, const int64_t *row_ptr, const int64_t *col_idx, const double *values, int64_t *partner /*[n]*/,
+                    int64_t *out_n_coarse, int64_t *out_nnz, int64_t *out_row_ptr, int64_t *out_col, double *out_val,
+                    int *rounds);
+
 /* ---------- discretization::* ---------- */
 /* build_momentum_diffusion_matrix (discretization.rs:39-48): values in pattern order + 3 RHS */
 int orc_build_momentum_diffusion_matrix(const OrcMesh *m, int diffusion_scheme, double mu,

@@ -4,6 +4,8 @@
 #include "linalg.hpp"
 
 namespace orc {
+int amg_debug_coarsen(const MatView &A, Arena &arena, std::vector<int> &choice_h, std::vector<int64_t> &row_ptr_h,
+                      std::vector<int64_t> &col_h, std::vector<double> &val_h, int *rounds);
 static SolveStats g_last_stats;
 SolveStats &last_stats() { return g_last_stats; }
 }  // namespace orc
@@ -74,6 +76,36 @@ int orc_csr_spmv(int64_t n, const int64_t *row_ptr, const int64_t *col_idx, cons
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     return dy.download(y, (size_t)n);
+}
+
+int orc_amg_coarsen(int64_t n, const int64_t *row_ptr, const int64_t *col_idx, const double *values, int64_t *partner,
+                    int64_t *out_n_coarse, int64_t *out_nnz, int64_t *out_row_ptr, int64_t *out_col, double *out_val, int *rounds) {
+    using namespace orc;
+    ORC_TRY(ensure_init());
+    SellMatrix pat;
+    ORC_TRY(sell_from_csr_host(n, row_ptr, col_idx, pat));
+    DevBuf<double> csr_vals, vals;
+    ORC_TRY(csr_vals.upload(values, (size_t)pat.nnz));
+    ORC_TRY(vals.alloc((size_t)std::max<int64_t>(pat.padded, 1)));
+    ORC_TRY(sell_import_values(pat, csr_vals.p, vals.p));
+    MatView A;
+    A.P = pat.dev();
+    A.val = vals.p;
+    A.symmetric = pat.symmetric;
+    Arena arena;
+    std::vector<int> choice;
+    std::vector<int64_t> rp, ci;
+    std::vector<double> v;
+    ORC_TRY(amg_debug_coarsen(A, arena, choice, rp, ci, v, rounds));
+    if (partner) for (int64_t i = 0; i < n; ++i) partner[i] = choice[(size_t)i];
+    if (out_n_coarse) *out_n_coarse = (int64_t)rp.size() - 1;
+    if (out_nnz) *out_nnz = (int64_t)ci.size();
+    if (out_col) {
+        std::copy(rp.begin(), rp.end(), out_row_ptr);
+        std::copy(ci.begin(), ci.end(), out_col);
+        std::copy(v.begin(), v.end(), out_val);
+    }
+    return ORC_OK;
 }
 
 int64_t orc_last_jacobi_sweeps(void) { return orc::g_last_stats.jacobi_sweeps; }

@@ -207,6 +207,19 @@ int spmv_dev(const MatView &A, const double *x, double *y) {
     return launch_spmv(A, x, e, nullptr, nullptr);
 }
 
+int residual_dev(const MatView &A, const double *b, const double *x, double *r) {
+    int g = 0;
+    static double *dummy = nullptr;
+    if (!dummy) ORC_HIP(hipMalloc((void **)&dummy, sizeof(double) * kMaxPartials));
+    return launch_spmv(A, x, EpiResidual{b, r, nullptr}, dummy, &g);
+}
+
+int residual_norm2_dev(const MatView &A, const double *b, const double *x, double *partials, double *out) {
+    int g = 0;
+    ORC_TRY(launch_spmv(A, x, EpiResidualNorm{b, nullptr}, partials, &g));
+    return reduce_partials(partials, g, 1, out);
+}
+
 // ------------------------------------------------------------------ BiCGSTAB (linear_algebra.rs:247-269)
 // scal[] layout (device doubles):
 enum { S_RHO0 = 0, S_RHO1 = 1, S_SUM_NU = 2, S_TS = 3, S_TT = 4, S_FROZEN = 5, S_FROZEN2 = 6, S_COUNT = 8 };

@@ -69,6 +69,10 @@ int spmv_dev(const MatView &A, const double *x, double *y);
 // one BiCGSTAB iteration body repeated reps times (bench)
 int bench_bicgstab_dev(const MatView &A, const double *b, double *x, int reps, Arena &arena, float *ms);
 
+// r = b - A x ;  out[0] = sum((b - A x)^2) (NaN iff the reference's .norm() is NaN)
+int residual_dev(const MatView &A, const double *b, const double *x, double *r);
+int residual_norm2_dev(const MatView &A, const double *b, const double *x, double *partials, double *out);
+
 // plain vector helpers used by the SIMPLE driver
 int vec_fill(double *x, double v, int64_t n);
 int vec_copy(double *dst, const double *src, int64_t n);

@@ -56,3 +56,19 @@ def csr_spmv(a, x, reps=1):
     check(lib().orc_csr_spmv(C.c_int64(a.shape[0]), _p(rp, C.c_int64), _p(ci, C.c_int64), _p(v, C.c_double),
                              _p(x, C.c_double), _p(y, C.c_double), C.c_int(reps), C.byref(ms)))
     return y, ms.value
+
+
+def amg_coarsen(a):
+    """Test hook: (partner[n], coarse CSR a' = (R a) R^T, rounds) of the device Multigrid set-up."""
+    import scipy.sparse as sp
+    a = a.tocsr()
+    a.sort_indices()
+    n = a.shape[0]
+    rp, ci, v = _i64(a.indptr), _i64(a.indices), _f64(a.data)
+    partner = np.empty(n, np.int64)
+    nc, nnz, rounds = C.c_int64(0), C.c_int64(0), C.c_int(0)
+    args = (C.c_int64(n), _p(rp, C.c_int64), _p(ci, C.c_int64), _p(v, C.c_double), _p(partner, C.c_int64), C.byref(nc), C.byref(nnz))
+    check(lib().orc_amg_coarsen(*args, None, None, None, C.byref(rounds)))
+    orp, oci, ov = np.empty(nc.value + 1, np.int64), np.empty(nnz.value, np.int64), np.empty(nnz.value)
+    check(lib().orc_amg_coarsen(*args, _p(orp, C.c_int64), _p(oci, C.c_int64), _p(ov, C.c_double), C.byref(rounds)))
+    return partner, sp.csr_matrix((ov, oci, orp), shape=(nc.value, nc.value)), rounds.value

@@ -53,6 +53,17 @@ class MeshArrays(dict):
         self["zone_vector"][k] = vector
 
 
+def splitmix64_uniform(n, seed=0x4F5243):
+    """uniform[-1,1) f64 from splitmix64, seed "ORC" (SURVEY §8d synthetic inputs); vectorised, stateless."""
+    idx = np.arange(1, n + 1, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) + idx * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return (z >> np.uint64(11)).astype(np.float64) * (2.0 / (1 << 53)) - 1.0
+
+
 ZONE_NAMES = ["FLUID", "INLET", "OUTLET", "PERIODIC_-Z", "PERIODIC_+Z", "TOP_WALL", "BOTTOM_WALL"]
 
 
