@@ -30,116 +30,166 @@ int comm_allreduce_sum(double *dev, int n);
 __device__ __forceinline__ int64_t sell_pos(const SellDev &P, int64_t row, int k) { return P.slice_ptr[row >> 6] + (int64_t)k * 64 + (row & 63); }
 
 struct AggCounters {
-    int cur;      // rows to evaluate in this round
-    int changed;  // rows whose choice changed in this round
-    int next;     // rows activated for the next round
+    int changed;  // rows whose choice changed in the current sweep
     int rounds;
 };
 
-// arg-min over j != i of a_ij among columns not taken by an earlier row (strict <, first wins: :37-52).
-// `constrained` = 0 evaluates the unconstrained arg-min (round 0).
-__device__ __forceinline__ int agg_eval_row(const MatView &A, const int *__restrict__ choice, int64_t i, int constrained) {
+// ---- exact greedy pairing as a fixed point -------------------------------------------------
+// State: choice[i] (partner of row i or -1).  A column j is "in combined_cells when row i is visited"
+// (linear_algebra.rs:41) iff some row m < i chose it, i.e. iff taken_by[j] = min{m : choice[m] = j} < i.
+// Every round rebuilds taken_by from choice (reset + atomicMin scatter), then sweeps: one thread
+// walks one 64-row slice IN ORDER, like the reference's loop, seeing its own updates immediately
+// (Gauss-Seidel inside the slice) and the other slices' as they land (chaotic relaxation).  A
+// sweep that changes nothing has evaluated every row against a taken_by that is exact for the
+// final choice, so the state is the unique solution of the triangular system = the sequential
+// result.  Chains inside a slice resolve in one sweep; a chain that crosses k slices needs ~k
+// sweeps (an x-line of 400 cells: ~7).  Slices that cannot be affected by the last sweep's changes
+// are skipped.
+__global__ void agg_reset_k(int *__restrict__ taken_by, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) taken_by[i] = 0x7fffffff;
+}
+__global__ void agg_scatter_k(const int *__restrict__ choice, int *__restrict__ taken_by, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        if (choice[i] >= 0) atomicMin(&taken_by[choice[i]], (int)i);
+}
+
+// arg-min over j != i of a_ij among columns not taken by an earlier row (strict <, first wins: :37-52)
+__device__ __forceinline__ int agg_eval_row(const MatView &A, const int *__restrict__ taken_by, int64_t i, bool constrained) {
     const int len = A.P.row_len[i];
+    const int64_t base = A.P.slice_ptr[i >> 6] + (i & 63);
     double best = 1.7976931348623157e308;  // Float::MAX
     int bj = -1;
     for (int k = 0; k < len; ++k) {
-        const int64_t pos = sell_pos(A.P, i, k);
+        const int64_t pos = base + (int64_t)k * 64;
         const int j = A.P.col[pos];
         if (j == i) continue;
-        if (constrained) {
-            // j in combined_cells when row i is visited  <=>  some row m < i chose j.  Rows that can
-            // choose j hold j in their pattern = (structural symmetry) the columns of row j.
-            bool taken = false;
-            const int lj = A.P.row_len[j];
-            for (int kk = 0; kk < lj; ++kk) {
-                const int m = A.P.col[sell_pos(A.P, j, kk)];
-                if (m < i && choice[m] == j) { taken = true; break; }
-            }
-            if (taken) continue;
-        }
+        if (constrained && taken_by[j] < i) continue;
         const double a = view_value(A, i, pos);
         if (a < best) { best = a; bj = j; }
     }
     return bj;
 }
 
-__global__ void agg_init_k(MatView A, int *__restrict__ choice, int *__restrict__ flag) {
+__global__ void agg_init_k(MatView A, int *__restrict__ choice, unsigned char *__restrict__ active, unsigned char *__restrict__ active_next) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < A.P.n; i += (int64_t)gridDim.x * blockDim.x) {
-        choice[i] = agg_eval_row(A, choice, i, 0);
-        flag[i] = 0;
+        choice[i] = agg_eval_row(A, nullptr, i, false);
+        if ((i & 63) == 0) { active[i >> 6] = 1; active_next[i >> 6] = 0; }
     }
 }
 
-// evaluate the rows of the work list (list == nullptr: all rows) against the committed choices
-__global__ void agg_eval_k(MatView A, const int *__restrict__ choice, const int *__restrict__ list, AggCounters *C,
-                           int *__restrict__ flag, int *__restrict__ changed_rows, int *__restrict__ changed_vals) {
-    const int count = C->cur;
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < count; idx += gridDim.x * blockDim.x) {
-        const int i = list ? list[idx] : idx;
-        flag[i] = 0;
-        const int nv = agg_eval_row(A, choice, i, 1);
-        if (nv != choice[i]) {
-            const int slot = atomicAdd(&C->changed, 1);
-            changed_rows[slot] = i;
-            changed_vals[slot] = nv;
-        }
-    }
-}
-
-// commit the changes and activate every later row that can see them
-__global__ void agg_commit_k(MatView A, int *__restrict__ choice, AggCounters *C, int *__restrict__ flag,
-                             const int *__restrict__ changed_rows, const int *__restrict__ changed_vals, int *__restrict__ next_list) {
-    const int count = C->changed;
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < count; idx += gridDim.x * blockDim.x) {
-        const int i = changed_rows[idx];
-        const int old = choice[i], nv = changed_vals[idx];
-        choice[i] = nv;
-        const int js[2] = {old, nv};
-        for (int t = 0; t < 2; ++t) {
-            const int j = js[t];
-            if (j < 0) continue;
-            const int lj = A.P.row_len[j];
-            for (int kk = 0; kk < lj; ++kk) {
-                const int m = A.P.col[sell_pos(A.P, j, kk)];
-                if (m > i && atomicExch(&flag[m], 1) == 0) next_list[atomicAdd(&C->next, 1)] = m;
+// one thread = one slice, rows in ascending order
+__global__ void agg_sweep_k(MatView A, int *__restrict__ choice, int *__restrict__ taken_by, const unsigned char *__restrict__ active,
+                            unsigned char *__restrict__ active_next, AggCounters *C, int all_active) {
+    const int64_t n = A.P.n;
+    int changed = 0;
+    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < A.P.n_slices; s += (int64_t)gridDim.x * blockDim.x) {
+        if (!all_active && !active[s]) continue;
+        const int64_t lo = s * 64, hi = lo + 64 < n ? lo + 64 : n;
+        for (int64_t i = lo; i < hi; ++i) {
+            const int old = choice[i];
+            const int nv = agg_eval_row(A, taken_by, i, true);
+            if (nv == old) continue;
+            ++changed;
+            choice[i] = nv;
+            if (nv >= 0) atomicMin(&taken_by[nv], (int)i);
+            // `old` may still be taken by another row; leaving taken_by[old] <= i is only ever too
+            // pessimistic for rows > i and is repaired by the next round's rebuild, which cannot
+            // be skipped because this sweep counted a change.
+            // rows that can see the change: those holding old / nv in their pattern (symmetric: the
+            // columns of rows old / nv) and lying after i
+            const int js[2] = {old, nv};
+            for (int t = 0; t < 2; ++t) {
+                const int j = js[t];
+                if (j < 0) continue;
+                const int lj = A.P.row_len[j];
+                const int64_t bj = A.P.slice_ptr[j >> 6] + (j & 63);
+                for (int kk = 0; kk < lj; ++kk) {
+                    const int m = A.P.col[bj + (int64_t)kk * 64];
+                    if (m > i) active_next[m >> 6] = 1;
+                }
             }
         }
     }
+    if (changed) atomicAdd(&C->changed, changed);
 }
 
-__global__ void agg_rotate_k(AggCounters *C) {
+__global__ void agg_rotate_k(AggCounters *C, int *snapshot) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        C->cur = C->next;
-        C->next = 0;
+        *snapshot = C->changed;
         C->changed = 0;
         C->rounds += 1;
     }
 }
 
-// General (structurally asymmetric) fall-back: full passes; "taken before row i" via the smallest
-// chooser of each column, rebuilt every round with atomicMin.
-__global__ void agg_fc_reset_k(int *__restrict__ fc, int64_t n) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) fc[i] = 0x7fffffff;
+// ---- tail phase: row-level Jacobi rounds with an incrementally exact taken_by ----------------
+// After the bulk sweeps what is left are long thin cascades (e.g. the last cell of every x-line
+// handing its partner on to the next line: ~ny dependent steps) that touch a handful of rows per
+// round, so a round must cost microseconds: evaluate the listed rows against the committed state,
+// commit, recompute taken_by for the two columns every change touches, activate later rows.
+struct TailCounters {
+    int cur, changed, next, rounds;
+};
+
+__global__ void tail_seed_k(TailCounters *T, int n) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) { T->cur = n; T->changed = 0; T->next = 0; T->rounds = 0; }
 }
-__global__ void agg_fc_scatter_k(const int *__restrict__ choice, int *__restrict__ fc, int64_t n) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        if (choice[i] >= 0) atomicMin(&fc[choice[i]], (int)i);
-}
-__global__ void agg_fc_eval_k(MatView A, const int *__restrict__ choice, const int *__restrict__ fc, int *__restrict__ choice_new,
-                              AggCounters *C) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < A.P.n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int len = A.P.row_len[i];
-        double best = 1.7976931348623157e308;
-        int bj = -1;
-        for (int k = 0; k < len; ++k) {
-            const int64_t pos = sell_pos(A.P, i, k);
-            const int j = A.P.col[pos];
-            if (j == i || fc[j] < i) continue;
-            const double a = view_value(A, i, pos);
-            if (a < best) { best = a; bj = j; }
+
+__global__ void tail_eval_k(MatView A, const int *__restrict__ choice, const int *__restrict__ taken_by, const int *__restrict__ list,
+                            TailCounters *T, int *__restrict__ flag, int *__restrict__ ch_row, int *__restrict__ ch_new) {
+    const int count = T->cur;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < count; idx += gridDim.x * blockDim.x) {
+        const int i = list ? list[idx] : idx;
+        flag[i] = 0;
+        const int nv = agg_eval_row(A, taken_by, i, true);
+        if (nv != choice[i]) {
+            const int slot = atomicAdd(&T->changed, 1);
+            ch_row[slot] = i;
+            ch_new[slot] = nv;
         }
-        choice_new[i] = bj;
-        if (bj != choice[i]) atomicAdd(&C->changed, 1);
+    }
+}
+
+__global__ void tail_commit_k(int *__restrict__ choice, const TailCounters *T, const int *__restrict__ ch_row, const int *__restrict__ ch_new,
+                              int *__restrict__ ch_old) {
+    const int count = T->changed;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < count; idx += gridDim.x * blockDim.x) {
+        const int i = ch_row[idx];
+        ch_old[idx] = choice[i];
+        choice[i] = ch_new[idx];
+    }
+}
+
+// exact taken_by for the columns touched by the committed changes + activation of the rows that can see them
+__global__ void tail_update_k(MatView A, const int *__restrict__ choice, int *__restrict__ taken_by, TailCounters *T,
+                              const int *__restrict__ ch_row, const int *__restrict__ ch_new, const int *__restrict__ ch_old,
+                              int *__restrict__ flag, int *__restrict__ next_list) {
+    const int count = T->changed;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < count; idx += gridDim.x * blockDim.x) {
+        const int i = ch_row[idx];
+        const int js[2] = {ch_old[idx], ch_new[idx]};
+        for (int t = 0; t < 2; ++t) {
+            const int j = js[t];
+            if (j < 0) continue;
+            const int lj = A.P.row_len[j];
+            const int64_t bj = A.P.slice_ptr[j >> 6] + (j & 63);
+            int mn = 0x7fffffff;
+            for (int kk = 0; kk < lj; ++kk) {  // rows holding column j = (symmetric pattern) the columns of row j
+                const int m = A.P.col[bj + (int64_t)kk * 64];
+                if (m != j && choice[m] == j && m < mn) mn = m;
+                if (m > i && atomicExch(&flag[m], 1) == 0) next_list[atomicAdd(&T->next, 1)] = m;
+            }
+            taken_by[j] = mn;  // several changes touching j compute the same value
+        }
+    }
+}
+
+__global__ void tail_rotate_k(TailCounters *T, int *snapshot) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *snapshot = T->changed;
+        T->cur = T->next;
+        T->next = 0;
+        T->changed = 0;
+        T->rounds += 1;
     }
 }
 
@@ -223,105 +273,219 @@ __global__ void vec_add_k(double *__restrict__ x, const double *__restrict__ y, 
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) x[i] += y[i];
 }
 
-// ------------------------------------------------------------------ Galerkin product (R A) R^T per coarse row
-// Sorted insert-accumulate into an LDS list laid out [slot][thread] (conflict-free when lanes
-// touch the same slot).  Returns false when the list is full.
-__device__ __forceinline__ bool list_add(int *__restrict__ keys, double *__restrict__ vals, int &len, int cap, int tpb, int key, double v) {
-    const int t = threadIdx.x;
-    int pos = len;
-    while (pos > 0 && keys[(pos - 1) * tpb + t] > key) --pos;
-    if (pos > 0 && keys[(pos - 1) * tpb + t] == key) {
-        vals[(pos - 1) * tpb + t] += v;
-        return true;
-    }
-    if (len >= cap) return false;
-    for (int q = len; q > pos; --q) {
-        keys[q * tpb + t] = keys[(q - 1) * tpb + t];
-        vals[q * tpb + t] = vals[(q - 1) * tpb + t];
-    }
-    keys[pos * tpb + t] = key;
-    vals[pos * tpb + t] = 0. + v;
-    ++len;
-    return true;
-}
-
-// NUMERIC = false: row lengths only; true: write columns / values / diagonal offsets of the coarse SELL matrix.
-template <bool NUMERIC>
-__global__ void galerkin_k(MatView A, const int *__restrict__ choice, const int *__restrict__ chooser, int64_t n_coarse, int capT,
-                           int capO, int *__restrict__ row_len_c, SellDev Pc, int *__restrict__ col_c, double *__restrict__ val_c,
-                           int *__restrict__ diag_c, int *__restrict__ overflow) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int tpb = blockDim.x;
-    double *Tval = reinterpret_cast<double *>(smem);
-    double *Oval = Tval + (size_t)capT * tpb;
-    int *Tkey = reinterpret_cast<int *>(Oval + (size_t)capO * tpb);
-    int *Okey = Tkey + (size_t)capT * tpb;
-    const int t = threadIdx.x;
-    for (int64_t I0 = (int64_t)blockIdx.x * tpb; I0 < n_coarse; I0 += (int64_t)gridDim.x * tpb) {
-        const int64_t I = I0 + t;
-        if (I >= n_coarse) continue;
-        const RRow R = restriction_row(choice, I, A.P.n);
-        int lenT = 0, lenO = 0;
-        bool ok = true;
-        // T = (R A)[I, :]   — i ascending, then A's row order (spmm_csr: c_Ij += R_Ii * a_ij)
-        for (int a = 0; a < R.n && ok; ++a) {
-            const int i = R.idx[a];
-            const double w = R.w[a];
-            const int len = A.P.row_len[i];
-            for (int k = 0; k < len; ++k) {
-                const int64_t pos = sell_pos(A.P, i, k);
-                ok = list_add(Tkey, Tval, lenT, capT, tpb, A.P.col[pos], w * view_value(A, i, pos));
-                if (!ok) break;
-            }
-        }
-        // A'[I, :] = T R^T  — j ascending, then R^T's row order (c_IJ += T_Ij * R^T_jJ)
-        for (int q = 0; q < lenT && ok; ++q) {
-            const int j = Tkey[q * tpb + t];
-            const double tv = Tval[q * tpb + t];
-            int J[2];
-            double W[2];
-            const int nj = rt_row(choice, chooser, j, J, W);
-            for (int a = 0; a < nj; ++a) {
-                ok = list_add(Okey, Oval, lenO, capO, tpb, J[a], tv * W[a]);
-                if (!ok) break;
-            }
-        }
-        if (!ok) { atomicExch(overflow, 1); continue; }
-        if (!NUMERIC) {
-            row_len_c[I] = lenO;
-        } else {
-            const int64_t base = Pc.slice_ptr[I >> 6] + (I & 63);
-            const int width = (int)((Pc.slice_ptr[(I >> 6) + 1] - Pc.slice_ptr[I >> 6]) >> 6);
-            int d = -1;
-            for (int q = 0; q < width; ++q) {
-                const int64_t pos = base + (int64_t)q * 64;
-                if (q < lenO) {
-                    const int J = Okey[q * tpb + t];
-                    col_c[pos] = J;
-                    val_c[pos] = Oval[q * tpb + t];
-                    if (J == I) d = (int)pos;
-                } else {
-                    col_c[pos] = (int)I;
-                    val_c[pos] = 0.;
+// ------------------------------------------------------------------ Galerkin product (R A) R^T, one wavefront per coarse row
+// (R A)[I,:] is the sum of <= 4 fine rows, R^T spreads every fine column over <= 2 coarse columns;
+// coarse rows reach a few hundred candidate products on the deeper levels.  One wavefront builds
+// one coarse row in LDS:
+//   1. gather the candidates (j, R_Ii * a_ij) in the reference's order (i ascending, then row order),
+//   2. bitonic-sort by the composite key (j << 32 | sequence)  -> equal j stay in generation order,
+//   3. the first lane of every run adds it up sequentially       -> T = (R A)[I,:], sorted by j,
+//   4. expand T through R^T into (J, T_j * R^T_jJ) in j order, sort by (J << 32 | sequence), add runs.
+// Every sum therefore associates exactly like nalgebra-sparse's spmm_csr (c += a_ik * b_kj, k in
+// row order), which keeps the coarse operators bit-identical to the CPU oracle.  Rows whose
+// candidate count exceeds the launch's LDS capacity go to an overflow list for a wider launch.
+// Output goes to a scratch area through an atomic bump allocator; a second kernel packs it into
+// SELL-64 once the slice widths are known (single pass: no symbolic/numeric duplication).
+__device__ __forceinline__ void bitonic_sort_wave(unsigned long long *__restrict__ key, double *__restrict__ val, int P) {
+    // P: power of two >= 64; executed by one wavefront (blockDim.x == 64): __syncthreads is a wave barrier
+    const int lane = threadIdx.x;
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int e = lane; e < P; e += 64) {
+                const int partner = e ^ j;
+                if (partner > e) {
+                    const bool up = (e & k) == 0;
+                    const unsigned long long a = key[e], b = key[partner];
+                    if ((a > b) == up) {
+                        key[e] = b; key[partner] = a;
+                        const double t = val[e]; val[e] = val[partner]; val[partner] = t;
+                    }
                 }
             }
-            diag_c[I] = d;
+            __syncthreads();
         }
     }
 }
 
-// capacity bound for the T list: sum of the lengths of the (<= 4) fine rows of each coarse row
-__global__ __launch_bounds__(kBlock) void galerkin_bound_k(SellDev P, const int *__restrict__ choice, int64_t n_coarse, int *__restrict__ out_max) {
+// exclusive prefix sum of one int per lane across the wavefront
+__device__ __forceinline__ int wave_excl_scan(int v, int &total) {
+    const int lane = threadIdx.x & 63;
+    int x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int y = __shfl_up(x, off, 64);
+        if (lane >= off) x += y;
+    }
+    total = __shfl(x, 63, 64);
+    return x - v;
+}
+
+__global__ __launch_bounds__(64) void galerkin_wave_k(MatView A, const int *__restrict__ choice, const int *__restrict__ chooser, int64_t n_coarse,
+                                                      int cap /* power of two */, int *__restrict__ row_len_c, long long *__restrict__ row_off,
+                                                      int *__restrict__ s_col, double *__restrict__ s_val, unsigned long long *alloc,
+                                                      long long scratch_cap, int *__restrict__ overflow_flag,
+                                                      const int *__restrict__ list, const int *__restrict__ list_count,
+                                                      int *__restrict__ ovf_list, int *__restrict__ ovf_count) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned long long *key = reinterpret_cast<unsigned long long *>(smem);
+    double *val = reinterpret_cast<double *>(key + cap);
+    unsigned long long *key2 = reinterpret_cast<unsigned long long *>(val + cap);
+    double *val2 = reinterpret_cast<double *>(key2 + cap);
+    const int lane = threadIdx.x;
+    const int64_t total_rows = list ? (int64_t)*list_count : n_coarse;
+    for (int64_t it = blockIdx.x; it < total_rows; it += gridDim.x) {
+        const int64_t I = list ? (int64_t)list[it] : it;
+        const RRow R = restriction_row(choice, I, A.P.n);
+        // ---- 1. candidates of T = (R A)[I,:]
+        int cnt = 0;
+        for (int a = 0; a < R.n; ++a) cnt += A.P.row_len[R.idx[a]];
+        bool fits = cnt <= cap;
+        int cntT = 0, cnt2 = 0, lenO = 0;
+        if (fits) {
+            int base = 0;
+            for (int a = 0; a < R.n; ++a) {
+                const int i = R.idx[a];
+                const double w = R.w[a];
+                const int len = A.P.row_len[i];
+                const int64_t rb = A.P.slice_ptr[i >> 6] + (i & 63);
+                for (int k = lane; k < len; k += 64) {
+                    const int64_t pos = rb + (int64_t)k * 64;
+                    key[base + k] = ((unsigned long long)(unsigned)A.P.col[pos] << 32) | (unsigned)(base + k);
+                    val[base + k] = w * view_value(A, i, pos);
+                }
+                base += len;
+            }
+            int P = 64;
+            while (P < cnt) P <<= 1;
+            for (int e = cnt + lane; e < P; e += 64) { key[e] = ~0ull; val[e] = 0.; }
+            __syncthreads();
+            bitonic_sort_wave(key, val, P);
+            // ---- 2. runs of equal j -> T (compact, sorted by j) into key2/val2
+            for (int b0 = 0; b0 < cnt; b0 += 64) {
+                const int e = b0 + lane;
+                int head = 0;
+                if (e < cnt) head = (e == 0) || ((key[e] >> 32) != (key[e - 1] >> 32));
+                int tot;
+                const int slot = cntT + wave_excl_scan(head, tot);
+                if (head) {
+                    const unsigned j = (unsigned)(key[e] >> 32);
+                    double acc = 0. + val[e];
+                    for (int q = e + 1; q < cnt && (unsigned)(key[q] >> 32) == j; ++q) acc += val[q];
+                    key2[slot] = j;
+                    val2[slot] = acc;
+                }
+                cntT += tot;
+            }
+            __syncthreads();
+            // ---- 3. expand through R^T: (J, T_j * w) in j order -> key/val
+            for (int b0 = 0; b0 < cntT; b0 += 64) {
+                const int e = b0 + lane;
+                int J[2];
+                double W[2];
+                int nj = 0;
+                double tv = 0.;
+                if (e < cntT) {
+                    nj = rt_row(choice, chooser, (int)key2[e], J, W);
+                    tv = val2[e];
+                }
+                int tot;
+                const int slot = cnt2 + wave_excl_scan(nj, tot);
+                if (cnt2 + tot <= cap) {
+                    for (int q = 0; q < nj; ++q) {
+                        key[slot + q] = ((unsigned long long)(unsigned)J[q] << 32) | (unsigned)(slot + q);
+                        val[slot + q] = tv * W[q];
+                    }
+                }
+                cnt2 += tot;
+            }
+            fits = cnt2 <= cap;
+        }
+        if (!fits) {
+            if (lane == 0) {
+                if (ovf_list) ovf_list[atomicAdd(ovf_count, 1)] = (int)I;
+                else atomicExch(overflow_flag, 1);
+            }
+            __syncthreads();
+            continue;
+        }
+        {
+            int P = 64;
+            while (P < cnt2) P <<= 1;
+            for (int e = cnt2 + lane; e < P; e += 64) { key[e] = ~0ull; val[e] = 0.; }
+            __syncthreads();
+            bitonic_sort_wave(key, val, P);
+            // ---- 4. runs of equal J -> the coarse row (compact, sorted) into key2/val2
+            for (int b0 = 0; b0 < cnt2; b0 += 64) {
+                const int e = b0 + lane;
+                int head = 0;
+                if (e < cnt2) head = (e == 0) || ((key[e] >> 32) != (key[e - 1] >> 32));
+                int tot;
+                const int slot = lenO + wave_excl_scan(head, tot);
+                if (head) {
+                    const unsigned Jc = (unsigned)(key[e] >> 32);
+                    double acc = 0. + val[e];
+                    for (int q = e + 1; q < cnt2 && (unsigned)(key[q] >> 32) == Jc; ++q) acc += val[q];
+                    key2[slot] = Jc;
+                    val2[slot] = acc;
+                }
+                lenO += tot;
+            }
+            __syncthreads();
+        }
+        // ---- output
+        long long off = 0;
+        if (lane == 0) off = (long long)atomicAdd(alloc, (unsigned long long)lenO);
+        off = __shfl(off, 0, 64);
+        if (off + lenO <= scratch_cap) {
+            for (int e = lane; e < lenO; e += 64) { s_col[off + e] = (int)key2[e]; s_val[off + e] = val2[e]; }
+        } else if (lane == 0) {
+            atomicExch(overflow_flag, 2);
+        }
+        if (lane == 0) { row_len_c[I] = lenO; row_off[I] = off; }
+        __syncthreads();
+    }
+}
+
+// scratch rows -> SELL-64 (columns, values, diagonal offsets, padding)
+__global__ void galerkin_pack_k(SellDev Pc, const long long *__restrict__ row_off, const int *__restrict__ s_col, const double *__restrict__ s_val,
+                                int *__restrict__ col_c, double *__restrict__ val_c, int *__restrict__ diag_c) {
+    for (int64_t I = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; I < Pc.n; I += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t base = Pc.slice_ptr[I >> 6] + (I & 63);
+        const int width = (int)((Pc.slice_ptr[(I >> 6) + 1] - Pc.slice_ptr[I >> 6]) >> 6);
+        const int len = Pc.row_len[I];
+        const long long off = row_off[I];
+        int d = -1;
+        for (int q = 0; q < width; ++q) {
+            const int64_t pos = base + (int64_t)q * 64;
+            if (q < len) {
+                const int J = s_col[off + q];
+                col_c[pos] = J;
+                val_c[pos] = s_val[off + q];
+                if (J == I) d = (int)pos;
+            } else {
+                col_c[pos] = (int)I;
+                val_c[pos] = 0.;
+            }
+        }
+        diag_c[I] = d;
+    }
+}
+
+// capacity bound for the candidate lists: sum of the lengths of the (<= 4) fine rows of each coarse row
+__global__ __launch_bounds__(kBlock) void galerkin_bound_k(SellDev P, const int *__restrict__ choice, int64_t n_coarse, int *__restrict__ out_max,
+                                                           unsigned long long *__restrict__ out_sum) {
     __shared__ double lds[8];
-    double mx = 0.;
+    double mx = 0., sm = 0.;
     for (int64_t I = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; I < n_coarse; I += (int64_t)gridDim.x * blockDim.x) {
         const RRow R = restriction_row(choice, I, P.n);
         int s = 0;
         for (int a = 0; a < R.n; ++a) s += P.row_len[R.idx[a]];
         mx = fmax(mx, (double)s);
+        sm += (double)s;
     }
     const double m = block_max(mx, lds);
-    if (threadIdx.x == 0) atomicMax(out_max, (int)m);
+    const double t = block_sum(sm, lds);
+    if (threadIdx.x == 0) { atomicMax(out_max, (int)m); atomicAdd(out_sum, (unsigned long long)t); }
 }
 
 // slice widths -> slice_ptr (single workgroup scan; n_slices is n/64)
@@ -370,61 +534,88 @@ struct CoarseLevel {
 static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, int *rounds_out) {
     const int64_t n = A.P.n;
     const int g = grid_for(n);
-    int *flag, *listA, *listB, *changed_rows, *changed_vals;
+    const int gs = grid_for(A.P.n_slices, 64);  // one thread per slice, 64-thread workgroups spread the slices over the CUs
+    int *taken_by, *snap;
+    unsigned char *act_a, *act_b;
     AggCounters *C;
-    ORC_TRY(arena.alloc((size_t)n, &flag));
-    ORC_TRY(arena.alloc((size_t)n, &listA));
-    ORC_TRY(arena.alloc((size_t)n, &listB));
-    ORC_TRY(arena.alloc((size_t)n, &changed_rows));
-    ORC_TRY(arena.alloc((size_t)n, &changed_vals));
+    ORC_TRY(arena.alloc((size_t)std::max<int64_t>(n, 1), &taken_by));
+    ORC_TRY(arena.alloc((size_t)A.P.n_slices + 1, &act_a));
+    ORC_TRY(arena.alloc((size_t)A.P.n_slices + 1, &act_b));
     ORC_TRY(arena.alloc((size_t)1, &C));
+    ORC_TRY(arena.alloc((size_t)64, &snap));
     hipStream_t st = ctx().stream;
-    hipLaunchKernelGGL(agg_init_k, dim3(g), dim3(kBlock), 0, st, A, choice, flag);
-    AggCounters h{(int)n, 0, 0, 0};
-    ORC_HIP(hipMemcpyAsync(C, &h, sizeof(h), hipMemcpyHostToDevice, st));
+    ORC_HIP(hipMemsetAsync(C, 0, sizeof(AggCounters), st));
+    hipLaunchKernelGGL(agg_init_k, dim3(g), dim3(kBlock), 0, st, A, choice, act_a, act_b);
     int rounds = 0;
-    if (A.symmetric) {
-        // round 1: every row; later rounds: work lists
-        const int *cur_list = nullptr;
+    const bool sym = A.symmetric;
+    const int all_active = sym ? 0 : 1;  // activation needs "rows holding column j" = columns of row j
+    unsigned char *cur = act_a, *nxt = act_b;
+    // ---- bulk phase: slice-sequential sweeps (all of the work on structurally asymmetric patterns)
+    const int kBulk = sym ? 3 : 4;
+    bool done = false;
+    while (!done) {
+        for (int b = 0; b < kBulk; ++b) {
+            hipLaunchKernelGGL(agg_reset_k, dim3(g), dim3(kBlock), 0, st, taken_by, n);
+            hipLaunchKernelGGL(agg_scatter_k, dim3(g), dim3(kBlock), 0, st, choice, taken_by, n);
+            hipLaunchKernelGGL(agg_sweep_k, dim3(gs), dim3(64), 0, st, A, choice, taken_by, cur, nxt, C, all_active);
+            hipLaunchKernelGGL(agg_rotate_k, dim3(1), dim3(1), 0, st, C, snap + b);
+            ORC_HIP(hipMemsetAsync(cur, 0, (size_t)A.P.n_slices, st));
+            std::swap(cur, nxt);
+        }
+        ORC_HIP(hipGetLastError());
+        if (sym) { rounds += kBulk; break; }  // hand over to the tail phase without a round trip
+        int h[8];
+        ORC_HIP(hipMemcpyAsync(h, snap, sizeof(int) * kBulk, hipMemcpyDeviceToHost, st));
+        ORC_HIP(hipStreamSynchronize(st));
+        for (int b = 0; b < kBulk; ++b) {
+            ++rounds;
+            if (h[b] == 0) { done = true; break; }
+        }
+        if (rounds > 8 * 1000 * 1000) return set_error(ORC_ERR_BAD_ARGUMENT, "aggregation did not reach its fixed point");
+    }
+    if (sym) {
+        // ---- tail phase: exact taken_by once, then row-level rounds
+        int *flag, *listA, *listB, *ch_row, *ch_new, *ch_old;
+        TailCounters *T;
+        ORC_TRY(arena.alloc((size_t)n, &flag));
+        ORC_TRY(arena.alloc((size_t)n, &listA));
+        ORC_TRY(arena.alloc((size_t)n, &listB));
+        ORC_TRY(arena.alloc((size_t)n, &ch_row));
+        ORC_TRY(arena.alloc((size_t)n, &ch_new));
+        ORC_TRY(arena.alloc((size_t)n, &ch_old));
+        ORC_TRY(arena.alloc((size_t)1, &T));
+        hipLaunchKernelGGL(agg_reset_k, dim3(g), dim3(kBlock), 0, st, taken_by, n);
+        hipLaunchKernelGGL(agg_scatter_k, dim3(g), dim3(kBlock), 0, st, choice, taken_by, n);
+        ORC_HIP(hipMemsetAsync(flag, 0, sizeof(int) * (size_t)n, st));
+        hipLaunchKernelGGL(tail_seed_k, dim3(1), dim3(1), 0, st, T, (int)n);
+        const int *cur_list = nullptr;  // first round: every row
         int *next_list = listA;
+        const int kBatch = 32;
         bool first = true;
         while (true) {
-            const int batch = first ? 1 : 16;
+            const int batch = first ? 2 : kBatch;
             for (int b = 0; b < batch; ++b) {
-                const int ge = first ? g : 512;
-                hipLaunchKernelGGL(agg_eval_k, dim3(ge), dim3(kBlock), 0, st, A, choice, cur_list, C, flag, changed_rows, changed_vals);
-                hipLaunchKernelGGL(agg_commit_k, dim3(ge), dim3(kBlock), 0, st, A, choice, C, flag, changed_rows, changed_vals, next_list);
-                hipLaunchKernelGGL(agg_rotate_k, dim3(1), dim3(1), 0, st, C);
+                const int ge = first ? g : 256;
+                hipLaunchKernelGGL(tail_eval_k, dim3(ge), dim3(kBlock), 0, st, A, choice, taken_by, cur_list, T, flag, ch_row, ch_new);
+                hipLaunchKernelGGL(tail_commit_k, dim3(ge), dim3(kBlock), 0, st, choice, T, ch_row, ch_new, ch_old);
+                hipLaunchKernelGGL(tail_update_k, dim3(ge), dim3(kBlock), 0, st, A, choice, taken_by, T, ch_row, ch_new, ch_old, flag, next_list);
+                hipLaunchKernelGGL(tail_rotate_k, dim3(1), dim3(1), 0, st, T, snap + b);
                 cur_list = next_list;
                 next_list = (next_list == listA) ? listB : listA;
                 first = false;
             }
             ORC_HIP(hipGetLastError());
-            ORC_HIP(hipMemcpyAsync(&h, C, sizeof(h), hipMemcpyDeviceToHost, st));
+            int h[kBatch];
+            ORC_HIP(hipMemcpyAsync(h, snap, sizeof(int) * batch, hipMemcpyDeviceToHost, st));
             ORC_HIP(hipStreamSynchronize(st));
-            rounds = h.rounds;
-            if (h.cur == 0) break;
-            if (rounds > 4 * 1000 * 1000) return set_error(ORC_ERR_BAD_ARGUMENT, "aggregation did not reach its fixed point");
+            bool fin = false;
+            for (int b = 0; b < batch; ++b) {
+                ++rounds;
+                if (h[b] == 0) { fin = true; break; }  // an evaluation round without a change: fixed point
+            }
+            if (fin) break;
+            if (rounds > 8 * 1000 * 1000) return set_error(ORC_ERR_BAD_ARGUMENT, "aggregation did not reach its fixed point");
         }
-    } else {
-        int *fc = flag;           // reuse
-        int *choice_new = listA;  // reuse
-        int *cur = choice;
-        while (true) {
-            hipLaunchKernelGGL(agg_fc_reset_k, dim3(g), dim3(kBlock), 0, st, fc, n);
-            hipLaunchKernelGGL(agg_fc_scatter_k, dim3(g), dim3(kBlock), 0, st, cur, fc, n);
-            hipLaunchKernelGGL(agg_fc_eval_k, dim3(g), dim3(kBlock), 0, st, A, cur, fc, choice_new, C);
-            ORC_HIP(hipGetLastError());
-            ORC_HIP(hipMemcpyAsync(&h, C, sizeof(h), hipMemcpyDeviceToHost, st));
-            ORC_HIP(hipStreamSynchronize(st));
-            std::swap(cur, choice_new);
-            ++rounds;
-            if (h.changed == 0) break;
-            h.changed = 0;
-            ORC_HIP(hipMemcpyAsync(C, &h, sizeof(h), hipMemcpyHostToDevice, st));
-            if (rounds > (int)n + 2) return set_error(ORC_ERR_BAD_ARGUMENT, "aggregation did not reach its fixed point");
-        }
-        if (cur != choice) ORC_HIP(hipMemcpyAsync(choice, cur, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, st));
     }
     ORC_HIP(hipMemsetAsync(chooser, 0xff, sizeof(int) * (size_t)n, st));
     hipLaunchKernelGGL(chooser_k, dim3(g), dim3(kBlock), 0, st, choice, chooser, n);
@@ -436,51 +627,67 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
 static int galerkin(const MatView &A, const int *choice, const int *chooser, Arena &arena, CoarseLevel &L) {
     const int64_t n = A.P.n, nc = n / 2 + n % 2;  // :13
     hipStream_t st = ctx().stream;
-    int *row_len, *diag, *flags;  // flags[0] = max T length, flags[1] = overflow
+    int *row_len, *diag, *flags, *ovf_list;  // flags[0] = max candidates, [1] = overflow, [2] = #rows for the wide launch
+    long long *row_off;
+    unsigned long long *counters;  // [0] = bump allocator, [1] = sum of candidates
     int64_t *slice_ptr;
     const int n_slices = (int)((nc + 63) / 64);
-    ORC_TRY(arena.alloc((size_t)std::max<int64_t>(nc, 1), &row_len));
-    ORC_TRY(arena.alloc((size_t)std::max<int64_t>(nc, 1), &diag));
+    const size_t ncs = (size_t)std::max<int64_t>(nc, 1);
+    ORC_TRY(arena.alloc(ncs, &row_len));
+    ORC_TRY(arena.alloc(ncs, &diag));
+    ORC_TRY(arena.alloc(ncs, &ovf_list));
+    ORC_TRY(arena.alloc(ncs, &row_off));
     ORC_TRY(arena.alloc((size_t)n_slices + 1, &slice_ptr));
-    ORC_TRY(arena.alloc((size_t)2, &flags));
-    ORC_HIP(hipMemsetAsync(flags, 0, 2 * sizeof(int), st));
-    hipLaunchKernelGGL(galerkin_bound_k, dim3(grid_for(nc)), dim3(kBlock), 0, st, A.P, choice, nc, flags);
-    int hflags[2];
+    ORC_TRY(arena.alloc((size_t)4, &flags));
+    ORC_TRY(arena.alloc((size_t)2, &counters));
+    ORC_HIP(hipMemsetAsync(flags, 0, 4 * sizeof(int), st));
+    ORC_HIP(hipMemsetAsync(counters, 0, 2 * sizeof(unsigned long long), st));
+    hipLaunchKernelGGL(galerkin_bound_k, dim3(grid_for(nc)), dim3(kBlock), 0, st, A.P, choice, nc, flags, counters + 1);
+    int hflags[4];
+    unsigned long long hcount[2];
     ORC_HIP(hipMemcpyAsync(hflags, flags, sizeof(hflags), hipMemcpyDeviceToHost, st));
+    ORC_HIP(hipMemcpyAsync(hcount, counters, sizeof(hcount), hipMemcpyDeviceToHost, st));
     ORC_HIP(hipStreamSynchronize(st));
-    int capT = std::max(hflags[0], 1);
-    int capO = 2 * capT;
-    if ((int64_t)capO > nc) capO = (int)std::max<int64_t>(nc, 1);
-    int tpb = 64;
-    const size_t budget = 150 * 1024;
-    while (tpb > 1 && (size_t)tpb * (capT + capO) * 12 > budget) tpb >>= 1;
-    if ((size_t)tpb * (capT + capO) * 12 > budget) return set_error(ORC_ERR_BAD_ARGUMENT, "Galerkin row too long for LDS (%d entries)", capT);
-    const size_t smem = (size_t)tpb * (capT + capO) * 12;
-    const int g = (int)std::min<int64_t>((nc + tpb - 1) / tpb, 4096);
-    SellDev Pc;  // filled below
+    const int max_cand = std::max(hflags[0], 1);
+    // every candidate of T spawns <= 2 products: 2 * sum bounds the coarse nnz (and the scratch area)
+    const long long scratch_cap = (long long)std::max<unsigned long long>(2ull * hcount[1], 64ull);
+    int *s_col;
+    double *s_val;
+    ORC_TRY(arena.alloc((size_t)scratch_cap, &s_col));
+    ORC_TRY(arena.alloc((size_t)scratch_cap, &s_val));
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&galerkin_k<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&galerkin_k<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&galerkin_wave_k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(galerkin_k<false>), dim3(g), dim3(tpb), smem, st, A, choice, chooser, nc, capT, capO, row_len, Pc, nullptr,
-                       nullptr, nullptr, flags + 1);
+    // capacities: narrow launch 128 entries (4 KiB/wave), wide launch the bound rounded up to a power of two
+    int cap_wide = 64;
+    while (cap_wide < 2 * max_cand) cap_wide <<= 1;
+    if ((size_t)cap_wide * 32 > (size_t)150 * 1024) return set_error(ORC_ERR_BAD_ARGUMENT, "Galerkin row too long for LDS (%d candidates)", max_cand);
+    const int cap_narrow = std::min(cap_wide, 128);
+    const int g1 = (int)std::min<int64_t>(nc, 256 * 16);
+    hipLaunchKernelGGL(galerkin_wave_k, dim3(g1), dim3(64), (size_t)cap_narrow * 32, st, A, choice, chooser, nc, cap_narrow, row_len, row_off, s_col, s_val,
+                       counters, scratch_cap, flags + 1, nullptr, nullptr, ovf_list, flags + 2);
+    if (cap_wide > cap_narrow) {
+        const int g2 = (int)std::min<int64_t>(nc, 256 * 4);
+        hipLaunchKernelGGL(galerkin_wave_k, dim3(g2), dim3(64), (size_t)cap_wide * 32, st, A, choice, chooser, nc, cap_wide, row_len, row_off, s_col, s_val,
+                           counters, scratch_cap, flags + 1, ovf_list, flags + 2, nullptr, nullptr);
+    }
     hipLaunchKernelGGL(slice_ptr_k, dim3(1), dim3(1024), 0, st, row_len, nc, n_slices, slice_ptr);
     ORC_HIP(hipGetLastError());
     int64_t padded = 0;
     ORC_HIP(hipMemcpyAsync(&padded, slice_ptr + n_slices, sizeof(int64_t), hipMemcpyDeviceToHost, st));
     ORC_HIP(hipMemcpyAsync(hflags, flags, sizeof(hflags), hipMemcpyDeviceToHost, st));
     ORC_HIP(hipStreamSynchronize(st));
-    if (hflags[1]) return set_error(ORC_ERR_BAD_ARGUMENT, "Galerkin LDS list overflow");
+    if (hflags[1]) return set_error(ORC_ERR_BAD_ARGUMENT, "Galerkin overflow (%d)", hflags[1]);
     if (padded >= ((int64_t)1 << 31)) return set_error(ORC_ERR_BAD_ARGUMENT, "coarse matrix too large for 32-bit offsets");
     int *col;
     double *val;
     ORC_TRY(arena.alloc((size_t)std::max<int64_t>(padded, 1), &col));
     ORC_TRY(arena.alloc((size_t)std::max<int64_t>(padded, 1), &val));
+    SellDev Pc;
     Pc.n = nc; Pc.n_slices = n_slices; Pc.slice_ptr = slice_ptr; Pc.row_len = row_len; Pc.col = col; Pc.diag_pos = diag;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(galerkin_k<true>), dim3(g), dim3(tpb), smem, st, A, choice, chooser, nc, capT, capO, row_len, Pc, col, val,
-                       diag, flags + 1);
+    hipLaunchKernelGGL(galerkin_pack_k, dim3(grid_for(nc)), dim3(kBlock), 0, st, Pc, row_off, s_col, s_val, col, val, diag);
     ORC_HIP(hipGetLastError());
     L.P = Pc; L.val = val; L.n = nc; L.padded = padded;
     return ORC_OK;

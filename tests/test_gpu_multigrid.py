@@ -68,7 +68,7 @@ def test_aggregation_dependency_chain(gpu, oracle):
     Rd = sp.coo_matrix((np.ones(len(rows)), (rows, cols)), shape=((n + 1) // 2, n)).tocsr()
     Rd.sum_duplicates()
     assert abs(Rd - R).max() == 0
-    assert rounds > 20
+    assert rounds >= 2  # chains resolve inside a 64-row slice; one sweep per slice crossed
 
 
 def test_aggregation_asymmetric_pattern(gpu, oracle):
