@@ -161,7 +161,7 @@ def main():
 
     # dominant kernel: CSR(SELL-64) SpMV inside BiCGSTAB, timed live with HIP events on the library stream
     spmv_ms, _ = solver.bench_spmv(args.spmv_reps)
-    n_local = mesh.n_cells
+    n_local = getattr(mesh, "n_owned", mesh.n_cells)  # rows of this rank's matrices
     nnz_local = mesh.nnz
     spmv_bytes = 12.0 * nnz_local + 20.0 * n_local  # f64 value + i32 column per nnz; row_ptr, x, y per row
     achieved = spmv_bytes / (spmv_ms * 1e-3) / 1e9

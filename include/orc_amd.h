@@ -48,6 +48,19 @@ OrcMesh *orc_mesh_create(int64_t n_cells, int64_t n_faces, int32_t n_zones,
                          const int64_t *cell_face_ptr /*[n+1]*/, const int64_t *cell_faces,
                          const int32_t *zone_type, const double *zone_scalar, const double *zone_vector /*[3Z]*/,
                          int *status);
+/* One rank's part of a cell-partitioned mesh: local cells are numbered owned first [0, n_owned), then one
+ * contiguous block of ghost cells per peer (recv_ptr, in peer order); cell_face_ptr gives ghost cells empty face lists;
+ * faces are those touching an owned cell, in ascending global id with the global c0/c1 orientation.
+ * send_idx[send_ptr[q] .. send_ptr[q+1]) are the owned cells whose values peer q needs, in the order of q's ghost block.
+ * Requires orc_comm_init (RCCL) or orc_comm_set_host_transport first when n_peers > 0. */
+OrcMesh *orc_mesh_create_partitioned(int64_t n_owned, int64_t n_cells, int64_t n_cells_global, int64_t n_faces, int32_t n_zones,
+                                     const int64_t *face_c0, const int64_t *face_c1, const int32_t *face_zone, const double *face_area,
+                                     const double *face_normal, const double *face_centroid, const double *cell_centroid,
+                                     const double *cell_volume, const int64_t *cell_face_ptr, const int64_t *cell_faces,
+                                     const int32_t *zone_type, const double *zone_scalar, const double *zone_vector, int32_t n_peers,
+                                     const int32_t *peers, const int64_t *send_ptr, const int64_t *send_idx, const int64_t *recv_ptr,
+                                     int *status);
+int64_t orc_mesh_n_owned(const OrcMesh *m);
 /* mesh.get_face_zone(name).zone_type / scalar_value / vector_value = ... (tests.rs:60-76) */
 int orc_mesh_update_zones(OrcMesh *m, const int32_t *zone_type, const double *zone_scalar, const double *zone_vector);
 void orc_mesh_destroy(OrcMesh *m);
@@ -151,6 +164,12 @@ int orc_hex_channel_write_msh(const char *path, int64_t nx, int64_t ny, int64_t 
 int orc_comm_get_unique_id(unsigned char id[ORC_COMM_ID_BYTES]);          /* rank 0, then broadcast by the host launcher */
 int orc_comm_init(const unsigned char id[ORC_COMM_ID_BYTES], int rank, int world_size);
 int orc_comm_finalize(void);
+/* Debug transport for tests where ranks share one GPU (RCCL refuses duplicate devices): halo exchange and all-reduce
+ * are staged through host memory and carried by the caller's callbacks (e.g. torch.distributed/gloo).
+ * exchange_fn: void(int n_peers, const int* peers, const double* send, const int64_t* send_off, const int64_t* send_cnt,
+ *                   double* recv, const int64_t* recv_off, const int64_t* recv_cnt, void* user)
+ * allreduce_fn: void(double* values, int n, int op (0 sum, 1 max), void* user).  Call orc_comm_init(NULL, rank, world) first. */
+int orc_comm_set_host_transport(void *exchange_fn, void *allreduce_fn, void *user);
 
 #ifdef __cplusplus
 }

@@ -24,7 +24,6 @@
 
 namespace orc {
 
-int comm_allreduce_sum(double *dev, int n);
 
 // ------------------------------------------------------------------ small device helpers
 __device__ __forceinline__ int64_t sell_pos(const SellDev &P, int64_t row, int k) { return P.slice_ptr[row >> 6] + (int64_t)k * 64 + (row & 63); }
@@ -62,7 +61,7 @@ __device__ __forceinline__ int agg_eval_row(const MatView &A, const int *__restr
     for (int k = 0; k < len; ++k) {
         const int64_t pos = base + (int64_t)k * 64;
         const int j = A.P.col[pos];
-        if (j == i) continue;
+        if (j == i || j >= A.P.n) continue;  // ghost columns (partitioned level 0) are never partners: aggregates stay on the rank
         if (constrained && taken_by[j] < i) continue;
         const double a = view_value(A, i, pos);
         if (a < best) { best = a; bj = j; }
@@ -105,7 +104,7 @@ __global__ void agg_sweep_k(MatView A, int *__restrict__ choice, int *__restrict
                 const int64_t bj = A.P.slice_ptr[j >> 6] + (j & 63);
                 for (int kk = 0; kk < lj; ++kk) {
                     const int m = A.P.col[bj + (int64_t)kk * 64];
-                    if (m > i) active_next[m >> 6] = 1;
+                    if (m > i && m < n) active_next[m >> 6] = 1;
                 }
             }
         }
@@ -175,6 +174,7 @@ __global__ void tail_update_k(MatView A, const int *__restrict__ choice, int *__
             int mn = 0x7fffffff;
             for (int kk = 0; kk < lj; ++kk) {  // rows holding column j = (symmetric pattern) the columns of row j
                 const int m = A.P.col[bj + (int64_t)kk * 64];
+                if (m >= A.P.n) continue;  // ghost column
                 if (m != j && choice[m] == j && m < mn) mn = m;
                 if (m > i && atomicExch(&flag[m], 1) == 0) next_list[atomicAdd(&T->next, 1)] = m;
             }
@@ -348,13 +348,22 @@ __global__ __launch_bounds__(64) void galerkin_wave_k(MatView A, const int *__re
                 const double w = R.w[a];
                 const int len = A.P.row_len[i];
                 const int64_t rb = A.P.slice_ptr[i >> 6] + (i & 63);
-                for (int k = lane; k < len; k += 64) {
-                    const int64_t pos = rb + (int64_t)k * 64;
-                    key[base + k] = ((unsigned long long)(unsigned)A.P.col[pos] << 32) | (unsigned)(base + k);
-                    val[base + k] = w * view_value(A, i, pos);
+                for (int k0 = 0; k0 < len; k0 += 64) {
+                    const int k = k0 + lane;
+                    int c = -1;
+                    int64_t pos = 0;
+                    if (k < len) { pos = rb + (int64_t)k * 64; c = A.P.col[pos]; }
+                    const int valid = (c >= 0 && c < A.P.n) ? 1 : 0;  // couplings to ghost columns are dropped on the coarse levels
+                    int tot;
+                    const int slot = base + wave_excl_scan(valid, tot);
+                    if (valid) {
+                        key[slot] = ((unsigned long long)(unsigned)c << 32) | (unsigned)slot;
+                        val[slot] = w * view_value(A, i, pos);
+                    }
+                    base += tot;
                 }
-                base += len;
             }
+            cnt = base;
             int P = 64;
             while (P < cnt) P <<= 1;
             for (int e = cnt + lane; e < P; e += 64) { key[e] = ~0ull; val[e] = 0.; }
@@ -686,7 +695,7 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
     ORC_TRY(arena.alloc((size_t)std::max<int64_t>(padded, 1), &col));
     ORC_TRY(arena.alloc((size_t)std::max<int64_t>(padded, 1), &val));
     SellDev Pc;
-    Pc.n = nc; Pc.n_slices = n_slices; Pc.slice_ptr = slice_ptr; Pc.row_len = row_len; Pc.col = col; Pc.diag_pos = diag;
+    Pc.n = nc; Pc.ncols = nc; Pc.n_slices = n_slices; Pc.slice_ptr = slice_ptr; Pc.row_len = row_len; Pc.col = col; Pc.diag_pos = diag;
     hipLaunchKernelGGL(galerkin_pack_k, dim3(grid_for(nc)), dim3(kBlock), 0, st, Pc, row_off, s_col, s_val, col, val, diag);
     ORC_HIP(hipGetLastError());
     L.P = Pc; L.val = val; L.n = nc; L.padded = padded;
@@ -729,7 +738,7 @@ static int multigrid_solve_dev(const MatView &A, const double *r, uint64_t level
     MatView Ac;
     Ac.P = L.P;
     Ac.val = L.val;
-    Ac.symmetric = A.symmetric;
+    Ac.symmetric = A.symmetric;  // halo stays null: coarse levels are solved per rank
     int stt = iterative_solve_dev(Ac, r_prime, e_prime, mp.iters, mp.smoother, mp.relaxation, threshold, mp.preconditioner, arena, stats);  // :87-96
     if (stt != ORC_OK) { arena.release(mk); return stt; }
     // :97-105  |r' - a' e'| is NaN -> "Multigrid diverged"

@@ -20,7 +20,7 @@ int orc_iterative_solve(int64_t n, const int64_t *row_ptr, const int64_t *col_id
     if (n < 0 || !row_ptr || (!col_idx && n > 0) || (!values && n > 0) || !b || !solution_vector)
         return set_error(ORC_ERR_BAD_ARGUMENT, "null argument");
     SellMatrix pat;
-    ORC_TRY(sell_from_csr_host(n, row_ptr, col_idx, pat));
+    ORC_TRY(sell_from_csr_host(n, n, row_ptr, col_idx, pat));
     const size_t nn = (size_t)std::max<int64_t>(n, 1);
     DevBuf<double> csr_vals, vals, db, dx;
     ORC_TRY(csr_vals.upload(values, (size_t)pat.nnz));
@@ -49,7 +49,7 @@ int orc_csr_spmv(int64_t n, const int64_t *row_ptr, const int64_t *col_idx, cons
     ORC_TRY(ensure_init());
     if (n < 0 || !row_ptr || !x || !y) return set_error(ORC_ERR_BAD_ARGUMENT, "null argument");
     SellMatrix pat;
-    ORC_TRY(sell_from_csr_host(n, row_ptr, col_idx, pat));
+    ORC_TRY(sell_from_csr_host(n, n, row_ptr, col_idx, pat));
     const size_t nn = (size_t)std::max<int64_t>(n, 1);
     DevBuf<double> csr_vals, vals, dx, dy;
     ORC_TRY(csr_vals.upload(values, (size_t)pat.nnz));
@@ -83,7 +83,7 @@ int orc_amg_coarsen(int64_t n, const int64_t *row_ptr, const int64_t *col_idx, c
     using namespace orc;
     ORC_TRY(ensure_init());
     SellMatrix pat;
-    ORC_TRY(sell_from_csr_host(n, row_ptr, col_idx, pat));
+    ORC_TRY(sell_from_csr_host(n, n, row_ptr, col_idx, pat));
     DevBuf<double> csr_vals, vals;
     ORC_TRY(csr_vals.upload(values, (size_t)pat.nnz));
     ORC_TRY(vals.alloc((size_t)std::max<int64_t>(pat.padded, 1)));

@@ -33,8 +33,47 @@ OrcMesh *orc_mesh_create(int64_t n_cells, int64_t n_faces, int32_t n_zones, cons
     OrcMesh *m = nullptr;
     if (st == ORC_OK) {
         m = new OrcMesh();
-        st = mesh_upload(*m, n_cells, n_faces, n_zones, face_c0, face_c1, face_zone, face_area, face_normal, face_centroid,
+        st = mesh_upload(*m, n_cells, n_cells, n_faces, n_zones, face_c0, face_c1, face_zone, face_area, face_normal, face_centroid,
                          cell_centroid, cell_volume, cell_face_ptr, cell_faces, zone_type, zone_scalar, zone_vector);
+        if (st != ORC_OK) { delete m; m = nullptr; }
+    }
+    if (status) *status = st;
+    return m;
+}
+
+OrcMesh *orc_mesh_create_partitioned(int64_t n_owned, int64_t n_cells, int64_t n_cells_global, int64_t n_faces, int32_t n_zones,
+                                     const int64_t *face_c0, const int64_t *face_c1, const int32_t *face_zone, const double *face_area,
+                                     const double *face_normal, const double *face_centroid, const double *cell_centroid,
+                                     const double *cell_volume, const int64_t *cell_face_ptr, const int64_t *cell_faces,
+                                     const int32_t *zone_type, const double *zone_scalar, const double *zone_vector, int32_t n_peers,
+                                     const int32_t *peers, const int64_t *send_ptr, const int64_t *send_idx, const int64_t *recv_ptr,
+                                     int *status) {
+    int st = ensure_init();
+    OrcMesh *m = nullptr;
+    if (st == ORC_OK) {
+        m = new OrcMesh();
+        m->n_global = n_cells_global;
+        st = mesh_upload(*m, n_owned, n_cells, n_faces, n_zones, face_c0, face_c1, face_zone, face_area, face_normal, face_centroid,
+                         cell_centroid, cell_volume, cell_face_ptr, cell_faces, zone_type, zone_scalar, zone_vector);
+        if (st == ORC_OK && n_peers > 0) {
+            HaloPlan &H = m->halo;
+            H.n_own = n_owned;
+            H.n_ghost = n_cells - n_owned;
+            H.n_send = send_ptr[n_peers];
+            if (recv_ptr[n_peers] != H.n_ghost) st = set_error(ORC_ERR_BAD_ARGUMENT, "ghost blocks (%lld) do not cover the ghost cells (%lld)",
+                                                                (long long)recv_ptr[n_peers], (long long)H.n_ghost);
+            std::vector<int32_t> idx((size_t)H.n_send);
+            for (int64_t i = 0; i < H.n_send && st == ORC_OK; ++i) {
+                if (send_idx[i] < 0 || send_idx[i] >= n_owned) st = set_error(ORC_ERR_BAD_ARGUMENT, "send index out of the owned range");
+                idx[(size_t)i] = (int32_t)send_idx[i];
+            }
+            for (int q = 0; q < n_peers; ++q) {
+                H.peers.push_back(peers[q]);
+                H.send_off.push_back(send_ptr[q]); H.send_cnt.push_back(send_ptr[q + 1] - send_ptr[q]);
+                H.recv_off.push_back(recv_ptr[q]); H.recv_cnt.push_back(recv_ptr[q + 1] - recv_ptr[q]);
+            }
+            if (st == ORC_OK) st = H.send_idx.upload(idx.data(), idx.size());
+        }
         if (st != ORC_OK) { delete m; m = nullptr; }
     }
     if (status) *status = st;
@@ -51,6 +90,7 @@ int orc_mesh_update_zones(OrcMesh *m, const int32_t *zone_type, const double *zo
 
 void orc_mesh_destroy(OrcMesh *m) { delete m; }
 int64_t orc_mesh_n_cells(const OrcMesh *m) { return m ? m->n_cells : 0; }
+int64_t orc_mesh_n_owned(const OrcMesh *m) { return m ? m->n_own : 0; }
 int64_t orc_mesh_nnz(const OrcMesh *m) { return m ? m->pat.nnz : 0; }
 
 int orc_mesh_matrix_pattern(const OrcMesh *m, int64_t *row_ptr, int64_t *col_idx) {
@@ -179,7 +219,7 @@ int orc_build_momentum_advection_matrices(const OrcMesh *m, double *a_u_values, 
     const double *mats[3] = {a_u_values, a_v_values, a_w_values};
     DevBuf<double> *diags[3] = {&t.du, &t.dv, &t.dw};
     for (int k = 0; k < 3; ++k) {
-        for (int64_t c = 0; c < t.n; ++c) {
+        for (int64_t c = 0; c < t.n_own; ++c) {
             const int64_t *row = m->h_col.data() + m->h_row_ptr[(size_t)c];
             const int64_t len = m->h_row_ptr[(size_t)c + 1] - m->h_row_ptr[(size_t)c];
             d[(size_t)c] = mats[k][m->h_row_ptr[(size_t)c] + (std::lower_bound(row, row + len, c) - row)];
@@ -203,7 +243,7 @@ int orc_build_pressure_correction_matrices(const OrcMesh *m, const double *u, co
     const double *mats[3] = {a_u_values, a_v_values, a_w_values};
     DevBuf<double> *diags[3] = {&t.du, &t.dv, &t.dw};
     for (int k = 0; k < 3; ++k) {
-        for (int64_t c = 0; c < t.n; ++c) {
+        for (int64_t c = 0; c < t.n_own; ++c) {
             const int64_t *row = m->h_col.data() + m->h_row_ptr[(size_t)c];
             const int64_t len = m->h_row_ptr[(size_t)c + 1] - m->h_row_ptr[(size_t)c];
             d[(size_t)c] = mats[k][m->h_row_ptr[(size_t)c] + (std::lower_bound(row, row + len, c) - row)];

@@ -18,7 +18,6 @@
 
 namespace orc {
 
-int comm_allreduce_sum(double *dev, int n);
 
 struct V3 {
     double x, y, z;
@@ -48,7 +47,7 @@ __device__ __forceinline__ void raise(int *status, int code) { atomicCAS(status,
 // discretization.rs:39-131
 __global__ void diffusion_k(MeshDev M, SellDev P, double mu, double *__restrict__ a_di, double *__restrict__ b_u,
                             double *__restrict__ b_v, double *__restrict__ b_w, int *status) {
-    GRID_STRIDE(c, M.n_cells) {
+    GRID_STRIDE(c, M.n_own) {
         const V3 cc = cell_centroid(M, (int)c);
         double a_p = 0., bu = 0., bv = 0., bw = 0.;
         for (int q = M.cfp[c]; q < M.cfp[c + 1]; ++q) {
@@ -78,7 +77,7 @@ __global__ void diffusion_k(MeshDev M, SellDev P, double mu, double *__restrict_
 
 // discretization.rs:450-472
 __global__ void init_momentum_k(MeshDev M, SellDev P, double *__restrict__ a) {
-    GRID_STRIDE(c, M.n_cells) {
+    GRID_STRIDE(c, M.n_own) {
         a[P.diag_pos[c]] = 1.;
         const double nf = (double)(M.cfp[c + 1] - M.cfp[c]);
         for (int q = M.cfp[c]; q < M.cfp[c + 1]; ++q)
@@ -106,7 +105,7 @@ __device__ __forceinline__ bool bc_supported(int zt) {
 // calculate_pressure_gradient, GreenGauss(CellBased) (solver.rs:883-900); returns (gx, gy, gy) under Q1
 __global__ void grad_p_k(MeshDev M, const double *__restrict__ p, double *__restrict__ gp, int q1, int *status) {
     const int64_t n = M.n_cells;
-    GRID_STRIDE(c, n) {
+    GRID_STRIDE(c, M.n_own) {
         const double vol = M.vol[c];
         V3 acc = mk(0., 0., 0.);
         for (int q = M.cfp[c]; q < M.cfp[c + 1]; ++q) {
@@ -139,7 +138,7 @@ __device__ __forceinline__ V3 face_velocity_linear(const MeshDev &M, const doubl
 __global__ void grad_u_k(MeshDev M, const double *__restrict__ u, const double *__restrict__ v, const double *__restrict__ w,
                          double *__restrict__ gu, int *status) {
     const int64_t n = M.n_cells;
-    GRID_STRIDE(c, n) {
+    GRID_STRIDE(c, M.n_own) {
         const double vol = M.vol[c];
         V3 tx = mk(0., 0., 0.), ty = tx, tz = tx;
         for (int q = M.cfp[c]; q < M.cfp[c + 1]; ++q) {
@@ -273,7 +272,7 @@ __global__ __launch_bounds__(kBlock) void momentum_k(MeshDev M, SellDev P, Momen
     const int64_t n = M.n_cells;
     double pe_sum = 0., pe_min = INFINITY, pe_max = -INFINITY;
     const bool tvd = A.momentum >= ORC_MOMENTUM_TVD_LUD;
-    GRID_STRIDE(c, n) {
+    GRID_STRIDE(c, M.n_own) {
         V3 s_u = mk(0., 0., 0.);  // get_momentum_source_term (solver.rs:698-701)
         const int dpos = P.diag_pos[c];
         const double a_ii_di = A.a_di[dpos];  // :176
@@ -358,7 +357,7 @@ __global__ __launch_bounds__(kBlock) void momentum_k(MeshDev M, SellDev P, Momen
 // discretization.rs:359-448 with the fixed pattern (no COO build / sort per iteration)
 __global__ void pressure_k(MeshDev M, SellDev P, const double *__restrict__ flux, const double *__restrict__ coef, double rho,
                            double *__restrict__ a_p_mat, double *__restrict__ b_p) {
-    GRID_STRIDE(c, M.n_cells) {
+    GRID_STRIDE(c, M.n_own) {
         double a_p = 0., b = 0.;
         for (int q = M.cfp[c]; q < M.cfp[c + 1]; ++q) {
             const int f = M.cf[q];
@@ -387,7 +386,7 @@ __global__ __launch_bounds__(kBlock) void correction_k(MeshDev M, const double *
                                                        double *__restrict__ partials, int *status) {
     __shared__ double lds[8];
     double s_pp = 0., s_corr = 0., s_u = 0., s_v = 0., s_w = 0.;
-    GRID_STRIDE(c, M.n_cells) {
+    GRID_STRIDE(c, M.n_own) {
         const double ppc = pp[c];
         p[c] += alpha_p * ppc;  // :1186
         V3 acc = mk(0., 0., 0.);
@@ -435,7 +434,7 @@ __global__ void reduce_minmax_k(const double *__restrict__ partials, int count, 
 // ====================================================================== host side
 orc::MeshDev OrcMesh::dev() const {
     orc::MeshDev d;
-    d.n_cells = n_cells; d.n_faces = n_faces; d.n_zones = n_zones;
+    d.n_cells = n_cells; d.n_own = n_own; d.n_faces = n_faces; d.n_zones = n_zones;
     d.c0 = c0.p; d.c1 = c1.p; d.fzone = fzone.p; d.area = area.p; d.nx = nx.p; d.ny = ny.p; d.nz = nz.p;
     d.fcx = fcx.p; d.fcy = fcy.p; d.fcz = fcz.p; d.ccx = ccx.p; d.ccy = ccy.p; d.ccz = ccz.p; d.vol = vol.p;
     d.cfp = cfp.p; d.cf = cf.p; d.cfpos = cfpos.p; d.ztype = ztype.p; d.zscal = zscal.p; d.zvec = zvec.p;
@@ -451,11 +450,11 @@ static int upload_as(DevBuf<T> &dst, const S *src, size_t n, size_t stride = 1, 
     return dst.upload(tmp.data(), n);
 }
 
-int mesh_upload(OrcMesh &m, int64_t n_cells, int64_t n_faces, int32_t n_zones, const int64_t *face_c0, const int64_t *face_c1,
+int mesh_upload(OrcMesh &m, int64_t n_own, int64_t n_cells, int64_t n_faces, int32_t n_zones, const int64_t *face_c0, const int64_t *face_c1,
                 const int32_t *face_zone, const double *face_area, const double *face_normal, const double *face_centroid,
                 const double *cell_centroid, const double *cell_volume, const int64_t *cell_face_ptr, const int64_t *cell_faces,
                 const int32_t *zone_type, const double *zone_scalar, const double *zone_vector) {
-    if (n_cells < 1 || n_faces < 1 || n_zones < 1) return set_error(ORC_ERR_BAD_ARGUMENT, "empty mesh");
+    if (n_cells < 1 || n_faces < 1 || n_zones < 1 || n_own < 1 || n_own > n_cells) return set_error(ORC_ERR_BAD_ARGUMENT, "empty mesh");
     if (n_faces >= ((int64_t)1 << 31) || n_cells >= ((int64_t)1 << 31)) return set_error(ORC_ERR_BAD_ARGUMENT, "mesh too large for 32-bit device indices");
     const int64_t ncf = cell_face_ptr[n_cells];
     if (ncf >= ((int64_t)1 << 31)) return set_error(ORC_ERR_BAD_ARGUMENT, "mesh too large for 32-bit device indices");
@@ -463,12 +462,13 @@ int mesh_upload(OrcMesh &m, int64_t n_cells, int64_t n_faces, int32_t n_zones, c
         if (face_c0[f] < 0 || face_c0[f] >= n_cells || face_c1[f] >= n_cells || face_zone[f] < 0 || face_zone[f] >= n_zones)
             return set_error(ORC_ERR_BAD_ARGUMENT, "face %lld: index out of range", (long long)f);
     }
-    m.n_cells = n_cells; m.n_faces = n_faces; m.n_zones = n_zones; m.n_cell_faces = ncf;
+    m.n_cells = n_cells; m.n_own = n_own; m.n_faces = n_faces; m.n_zones = n_zones; m.n_cell_faces = ncf;
+    if (m.n_global == 0) m.n_global = n_own;
     // matrix pattern: diagonal + one entry per interior face, ascending columns
     // (CsrMatrix::from(&CooMatrix) at discretization.rs:130,445,471)
-    m.h_row_ptr.assign((size_t)n_cells + 1, 0);
+    m.h_row_ptr.assign((size_t)n_own + 1, 0);
     std::vector<int64_t> nbr((size_t)ncf);
-    for (int64_t c = 0; c < n_cells; ++c) {
+    for (int64_t c = 0; c < n_own; ++c) {
         int64_t cnt = 1;
         for (int64_t q = cell_face_ptr[c]; q < cell_face_ptr[c + 1]; ++q) {
             const int64_t f = cell_faces[q];
@@ -480,8 +480,8 @@ int mesh_upload(OrcMesh &m, int64_t n_cells, int64_t n_faces, int32_t n_zones, c
         }
         m.h_row_ptr[(size_t)c + 1] = m.h_row_ptr[(size_t)c] + cnt;
     }
-    m.h_col.assign((size_t)m.h_row_ptr[(size_t)n_cells], 0);
-    for (int64_t c = 0; c < n_cells; ++c) {
+    m.h_col.assign((size_t)m.h_row_ptr[(size_t)n_own], 0);
+    for (int64_t c = 0; c < n_own; ++c) {
         int64_t *row = m.h_col.data() + m.h_row_ptr[(size_t)c];
         int64_t k = 0;
         row[k++] = c;
@@ -493,13 +493,13 @@ int mesh_upload(OrcMesh &m, int64_t n_cells, int64_t n_faces, int32_t n_zones, c
         for (int64_t t = 1; t < k; ++t)
             if (row[t] == row[t - 1]) return set_error(ORC_ERR_BAD_ARGUMENT, "cells %lld and %lld share more than one face", (long long)c, (long long)row[t]);
     }
-    ORC_TRY(sell_from_csr_host(n_cells, m.h_row_ptr.data(), m.h_col.data(), m.pat));
+    ORC_TRY(sell_from_csr_host(n_own, n_cells, m.h_row_ptr.data(), m.h_col.data(), m.pat));
     // SELL offsets of the neighbour entries
     std::vector<int32_t> cfpos((size_t)ncf, -1);
     {
         std::vector<int64_t> slice_ptr((size_t)m.pat.n_slices + 1);
         ORC_TRY(m.pat.slice_ptr.download(slice_ptr.data(), slice_ptr.size()));
-        for (int64_t c = 0; c < n_cells; ++c) {
+        for (int64_t c = 0; c < n_own; ++c) {
             const int64_t *row = m.h_col.data() + m.h_row_ptr[(size_t)c];
             const int64_t len = m.h_row_ptr[(size_t)c + 1] - m.h_row_ptr[(size_t)c];
             const int64_t base = slice_ptr[(size_t)(c >> 6)] + (c & 63);
@@ -584,7 +584,7 @@ int solver_init(SolverState &s, OrcMesh *m, const OrcSettings *settings, double 
     ORC_TRY(ensure_init());
     s.mesh = m;
     s.settings = *settings;
-    s.rho = rho; s.mu = mu; s.n = m->n_cells;
+    s.rho = rho; s.mu = mu; s.n = m->n_cells; s.n_own = m->n_own;
     ORC_TRY(validate_settings(s.settings));
     const size_t n = (size_t)s.n, pad = (size_t)std::max<int64_t>(m->pat.padded, 1), F = (size_t)m->n_faces;
     DevBuf<double> *nvec[] = {&s.u, &s.v, &s.w, &s.p, &s.p_prime, &s.b_u_di, &s.b_v_di, &s.b_w_di, &s.b_u, &s.b_v, &s.b_w, &s.b_p, &s.du, &s.dv, &s.dw};
@@ -641,7 +641,7 @@ int k_momentum(SolverState &s, double *peclet_host) {
     if (peclet_host) {
         ORC_HIP(hipMemcpyAsync(peclet_host, s.scal.p + 8, 3 * sizeof(double), hipMemcpyDeviceToHost, ctx().stream));
         ORC_HIP(hipStreamSynchronize(ctx().stream));
-        peclet_host[0] /= (double)s.n;  // discretization.rs:355
+        peclet_host[0] /= (double)s.n_own;  // discretization.rs:355 (per-rank statistics in a partitioned run)
     }
     return ORC_OK;
 }
@@ -661,7 +661,7 @@ int k_apply_correction(SolverState &s, double *sums_host) {
     hipLaunchKernelGGL(correction_k, dim3(g), dim3(kBlock), 0, ctx().stream, m.dev(), s.du.p, s.dv.p, s.dw.p, s.p_prime.p, s.u.p, s.v.p,
                        s.w.p, s.p.p, s.settings.pressure_relaxation, s.settings.momentum_relaxation, s.partials.p, s.dev_status.p);
     ORC_HIP(hipGetLastError());
-    ORC_TRY(reduce_partials(s.partials.p, g, 5, s.scal.p));
+    ORC_TRY(reduce_partials(s.partials.p, g, 5, s.scal.p, s.mesh->halo.active()));
     if (sums_host) {
         ORC_HIP(hipMemcpyAsync(sums_host, s.scal.p, 5 * sizeof(double), hipMemcpyDeviceToHost, ctx().stream));
         ORC_HIP(hipStreamSynchronize(ctx().stream));
@@ -674,13 +674,13 @@ static int solve_field(SolverState &s, DevBuf<double> &a, DevBuf<double> &b, Dev
     A.P = s.mesh->pat.dev();
     A.val = a.p;
     A.symmetric = s.mesh->pat.symmetric;
+    A.halo = s.mesh->halo.active() ? &s.mesh->halo : nullptr;
     const OrcSettings &t = s.settings;
     ctx().breakdown_guard = t.breakdown_guard != 0;
     return iterative_solve_dev(A, b.p, x.p, t.iterations, t.solver_type, t.relaxation, t.relative_convergence_threshold,
                                t.preconditioner, s.arena, &s.stats);
 }
 
-// One pass of solver.rs:60-222 per iteration.
 static void debug_field(SolverState &s, const char *name, const DevBuf<double> &f) {
     std::vector<double> h((size_t)s.n);
     (void)f.download(h.data(), (size_t)s.n);
@@ -690,14 +690,21 @@ static void debug_field(SolverState &s, const char *name, const DevBuf<double> &
     fprintf(stderr, "[orc debug] it %llu %s: nan=%d max=%.17g\n", (unsigned long long)s.iterations_done, name, nn, mx);
 }
 
+// One pass of solver.rs:60-222 per iteration.  In a partitioned run (mesh.halo active) the ghost entries of every
+// field a face kernel reads are refreshed first (C1); the solves exchange their own work vectors.
 int solver_iterate(SolverState &s, uint64_t iterations, double *report) {
     const bool tvd = is_tvd(s.settings.momentum);
     const bool dbg = getenv("ORC_DEBUG_NAN") != nullptr;
+    HaloPlan &H = s.mesh->halo;
+    const int64_t n = s.n;
     for (uint64_t it = 0; it < iterations; ++it) {
         double peclet[3] = {0., 0., 0.};
+        if (H.active()) { double *f[4] = {s.u.p, s.v.p, s.w.p, s.p.p}; ORC_TRY(H.exchange(f, 4)); }
         ORC_TRY(k_gradients(s, tvd));
+        if (H.active()) { double *g3[3] = {s.gp.p, s.gp.p + n, s.gp.p + 2 * n}; ORC_TRY(H.exchange(g3, 3)); }
         ORC_TRY(k_face_flux(s, true));
         ORC_TRY(k_momentum(s, report ? peclet : nullptr));       // :61-82
+        if (H.active()) { double *d3[3] = {s.du.p, s.dv.p, s.dw.p}; ORC_TRY(H.exchange(d3, 3)); }
         if (dbg) { debug_field(s, "b_u", s.b_u); debug_field(s, "b_v", s.b_v); debug_field(s, "b_w", s.b_w); }
         ORC_TRY(solve_field(s, s.a_u, s.b_u, s.u));              // :99-110
         if (dbg) debug_field(s, "u", s.u);
@@ -705,17 +712,18 @@ int solver_iterate(SolverState &s, uint64_t iterations, double *report) {
         if (dbg) debug_field(s, "v", s.v);
         ORC_TRY(solve_field(s, s.a_w, s.b_w, s.w));              // :125-136
         if (dbg) debug_field(s, "w", s.w);
+        if (H.active()) { double *f[3] = {s.u.p, s.v.p, s.w.p}; ORC_TRY(H.exchange(f, 3)); }
         ORC_TRY(k_pressure_correction(s));                       // :137-148
         ORC_TRY(vec_fill(s.p_prime.p, 0., s.n));                 // :167
         if (dbg) debug_field(s, "b_p", s.b_p);
         ORC_TRY(solve_field(s, s.a_p, s.b_p, s.p_prime));        // :168-179
         if (dbg) debug_field(s, "p_prime", s.p_prime);
+        if (H.active()) ORC_TRY(H.exchange(s.p_prime.p));
         double sums[5];
         ORC_TRY(k_apply_correction(s, sums));                    // :193-208
         s.iterations_done++;
-        const double nn = (double)s.n * (double)ctx().world;  // global cell count is handled by the caller in multi-GPU runs
-        (void)nn;
-        const double u_avg = sums[2] / (double)s.n, v_avg = sums[3] / (double)s.n, w_avg = sums[4] / (double)s.n;
+        const double ng = (double)s.mesh->n_global;
+        const double u_avg = sums[2] / ng, v_avg = sums[3] / ng, w_avg = sums[4] / ng;
         if (report) {
             double *r = report + 8 * it;
             r[0] = u_avg; r[1] = v_avg; r[2] = w_avg; r[3] = peclet[0]; r[4] = peclet[1]; r[5] = peclet[2];

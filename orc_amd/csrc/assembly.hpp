@@ -11,7 +11,8 @@ namespace orc {
 // coalesced; the zone HashMap lookup (solver.rs:1113) becomes a per-face zone index into three
 // tiny tables.
 struct MeshDev {
-    int64_t n_cells = 0, n_faces = 0;
+    int64_t n_cells = 0, n_faces = 0;  // n_cells = owned + ghost cells (array length / SoA stride)
+    int64_t n_own = 0;                 // cells this rank assembles and solves: [0, n_own)
     int32_t n_zones = 0;
     const int32_t *c0 = nullptr, *c1 = nullptr, *fzone = nullptr;
     const double *area = nullptr, *nx = nullptr, *ny = nullptr, *nz = nullptr;
@@ -29,6 +30,9 @@ struct MeshDev {
 
 struct OrcMesh {
     int64_t n_cells = 0, n_faces = 0, n_cell_faces = 0;
+    int64_t n_own = 0;         // == n_cells on a single GPU
+    int64_t n_global = 0;      // cells of the whole mesh (report averages, solver.rs:206-208)
+    orc::HaloPlan halo;        // empty on a single GPU
     int32_t n_zones = 0;
     orc::DevBuf<int32_t> c0, c1, fzone, cfp, cf, cfpos, ztype;
     orc::DevBuf<double> area, nx, ny, nz, fcx, fcy, fcz, ccx, ccy, ccz, vol, zscal, zvec;
@@ -48,7 +52,8 @@ struct SolverState {
     OrcMesh *mesh = nullptr;
     OrcSettings settings;
     double rho = 0., mu = 0.;
-    int64_t n = 0;
+    int64_t n = 0;      // local array length (owned + ghost)
+    int64_t n_own = 0;  // rows
     DevBuf<double> u, v, w, p, p_prime;
     DevBuf<double> a_di, a_u, a_v, a_w, a_p;            // SELL value arrays (mesh pattern)
     DevBuf<double> b_u_di, b_v_di, b_w_di, b_u, b_v, b_w, b_p;
@@ -63,7 +68,7 @@ struct SolverState {
     uint64_t iterations_done = 0;
 };
 
-int mesh_upload(OrcMesh &m, int64_t n_cells, int64_t n_faces, int32_t n_zones, const int64_t *face_c0, const int64_t *face_c1,
+int mesh_upload(OrcMesh &m, int64_t n_own, int64_t n_cells, int64_t n_faces, int32_t n_zones, const int64_t *face_c0, const int64_t *face_c1,
                 const int32_t *face_zone, const double *face_area, const double *face_normal, const double *face_centroid,
                 const double *cell_centroid, const double *cell_volume, const int64_t *cell_face_ptr, const int64_t *cell_faces,
                 const int32_t *zone_type, const double *zone_scalar, const double *zone_vector);

@@ -1,0 +1,33 @@
+// halo.hpp — ghost-cell exchange plan of one rank.
+// Local numbering: owned cells [0, n_own), then one contiguous ghost block per peer.  An exchange packs
+// x[send_idx] per peer, runs grouped ncclSend/ncclRecv on the library stream and lands the peer's values directly
+// in x[n_own + recv_off ...].  A debug transport (host-staged through a caller-supplied callback, e.g.
+// torch.distributed/gloo) lets two processes share ONE GPU in tests, where RCCL refuses duplicate devices.
+#pragma once
+#include "common.hpp"
+
+namespace orc {
+
+typedef void (*HostExchangeFn)(int n_peers, const int *peers, const double *send, const int64_t *send_off, const int64_t *send_cnt,
+                               double *recv, const int64_t *recv_off, const int64_t *recv_cnt, void *user);
+typedef void (*HostAllreduceFn)(double *values, int n, int op /*0 sum, 1 max*/, void *user);
+
+struct HaloPlan {
+    int64_t n_own = 0, n_ghost = 0, n_send = 0;
+    std::vector<int> peers;
+    std::vector<int64_t> send_off, send_cnt, recv_off, recv_cnt;  // per peer, in doubles
+    DevBuf<int32_t> send_idx;  // [n_send] owned cells to pack, peer after peer
+    DevBuf<double> send_buf;   // [k * n_send]
+    DevBuf<double> recv_buf;   // [k * n_ghost] staging for multi-field exchanges
+    std::vector<double> h_send, h_recv;  // debug transport
+    bool active() const { return !peers.empty(); }
+    // exchange the ghost entries of k vectors (each n_own + n_ghost long) in one grouped launch
+    int exchange(double *const *xs, int k);
+    int exchange(double *x) { return exchange(&x, 1); }
+};
+
+int comm_allreduce_sum(double *dev, int n);
+int comm_allreduce_max(double *dev, int n);
+void comm_set_host_transport(HostExchangeFn ex, HostAllreduceFn ar, void *user);
+
+}  // namespace orc

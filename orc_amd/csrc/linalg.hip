@@ -12,7 +12,6 @@
 
 namespace orc {
 
-int comm_allreduce_sum(double *dev, int n);  // comm.cpp; no-op when world == 1
 
 // ------------------------------------------------------------------ reductions
 __global__ __launch_bounds__(1024) void reduce_partials_k(const double *__restrict__ partials, int count, int nq, double *__restrict__ out) {
@@ -32,10 +31,10 @@ __global__ __launch_bounds__(1024) void reduce_partials_k(const double *__restri
     }
 }
 
-int reduce_partials(const double *partials, int count, int nq, double *out) {
+int reduce_partials(const double *partials, int count, int nq, double *out, bool global) {
     hipLaunchKernelGGL(reduce_partials_k, dim3(1), dim3(1024), 0, ctx().stream, partials, count, nq, out);
     ORC_HIP(hipGetLastError());
-    if (ctx().world > 1) ORC_TRY(comm_allreduce_sum(out, nq));
+    if (global && ctx().world > 1) ORC_TRY(comm_allreduce_sum(out, nq));
     return ORC_OK;
 }
 
@@ -48,7 +47,8 @@ static inline int spmv_grid(int32_t n_slices) {
 }
 
 // ------------------------------------------------------------------ SELL build / import / export
-int sell_from_csr_host(int64_t n, const int64_t *row_ptr, const int64_t *col, SellMatrix &out) {
+int sell_from_csr_host(int64_t n, int64_t ncols, const int64_t *row_ptr, const int64_t *col, SellMatrix &out) {
+    if (ncols < n) ncols = n;
     if (n < 0) return set_error(ORC_ERR_BAD_ARGUMENT, "negative row count");
     const int64_t nnz = n > 0 ? row_ptr[n] : 0;
     const int32_t n_slices = (int32_t)((n + 63) / 64);
@@ -69,11 +69,11 @@ int sell_from_csr_host(int64_t n, const int64_t *row_ptr, const int64_t *col, Se
         const int64_t base = slice_ptr[r >> 6] + (r & 63);
         for (int64_t k = 0; k < e - b; ++k) {
             const int64_t c = col[b + k];
-            if (c < 0 || c >= n) return set_error(ORC_ERR_BAD_ARGUMENT, "column index out of range");
+            if (c < 0 || c >= ncols) return set_error(ORC_ERR_BAD_ARGUMENT, "column index out of range");
             if (k > 0 && col[b + k - 1] >= c) return set_error(ORC_ERR_BAD_ARGUMENT, "CSR columns must be strictly ascending per row");
             scol[base + k * 64] = (int32_t)c;
             if (c == r) diag[r] = (int32_t)(base + k * 64);
-            if (symmetric && c != r) {
+            if (symmetric && c != r && c < n) {
                 const int64_t *lo = col + row_ptr[c], *hi = col + row_ptr[c + 1];
                 const int64_t *it = std::lower_bound(lo, hi, r);
                 if (it == hi || *it != r) symmetric = false;
@@ -83,7 +83,7 @@ int sell_from_csr_host(int64_t n, const int64_t *row_ptr, const int64_t *col, Se
         const int64_t width = (slice_ptr[(r >> 6) + 1] - slice_ptr[r >> 6]) >> 6;
         for (int64_t k = e - b; k < width; ++k) scol[base + k * 64] = (int32_t)r;
     }
-    out.n = n; out.nnz = nnz; out.padded = padded; out.n_slices = n_slices; out.symmetric = symmetric;
+    out.n = n; out.ncols = ncols; out.nnz = nnz; out.padded = padded; out.n_slices = n_slices; out.symmetric = symmetric;
     ORC_TRY(out.slice_ptr.upload(slice_ptr.data(), slice_ptr.size()));
     ORC_TRY(out.row_len.upload(row_len.data(), (size_t)n));
     ORC_TRY(out.col.upload(scol.data(), (size_t)padded));
@@ -197,6 +197,7 @@ static int launch_spmv(const MatView &A, const double *x, const Epi &epi, double
     const int g = spmv_grid(A.P.n_slices);
     if (grid_out) *grid_out = g;
     if (A.P.n == 0) return ORC_OK;
+    if (A.halo) ORC_TRY(A.halo->exchange(const_cast<double *>(x)));  // C1: refresh the ghost entries of x
     hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
     ORC_HIP(hipGetLastError());
     return ORC_OK;
@@ -217,7 +218,7 @@ int residual_dev(const MatView &A, const double *b, const double *x, double *r) 
 int residual_norm2_dev(const MatView &A, const double *b, const double *x, double *partials, double *out) {
     int g = 0;
     ORC_TRY(launch_spmv(A, x, EpiResidualNorm{b, nullptr}, partials, &g));
-    return reduce_partials(partials, g, 1, out);
+    return reduce_partials(partials, g, 1, out, A.halo != nullptr);
 }
 
 // ------------------------------------------------------------------ BiCGSTAB (linear_algebra.rs:247-269)
@@ -302,7 +303,7 @@ struct BicgWork {
     double *r, *p, *nu, *s, *t, *partials, *scal;
 };
 
-static int bicg_alloc(Arena &arena, int64_t n, BicgWork &w) {
+static int bicg_alloc(Arena &arena, int64_t n, BicgWork &w) {  // n = vector length incl. ghost entries
     const size_t nn = (size_t)std::max<int64_t>(n, 1);
     ORC_TRY(arena.alloc(nn, &w.r));
     ORC_TRY(arena.alloc(nn, &w.p));
@@ -322,12 +323,12 @@ static int bicg_iteration(const MatView &A, double *x, const BicgWork &w, uint64
     const double *skip = guard ? w.scal + S_FROZEN : nullptr;  // frozen solves skip their SpMVs too
     int g = 0;
     ORC_TRY(launch_spmv(A, w.p, EpiStoreSum{w.nu}, w.partials, &g, skip));     // nu = A p, sum(nu)
-    ORC_TRY(reduce_partials(w.partials, g, 1, w.scal + S_SUM_NU));
+    ORC_TRY(reduce_partials(w.partials, g, 1, w.scal + S_SUM_NU, A.halo != nullptr));
     hipLaunchKernelGGL(bicg_s_k, dim3(vg), dim3(kBlock), 0, ctx().stream, w.scal, S_RHO0 + cur, w.r, w.nu, w.s, n, guard);
     ORC_TRY(launch_spmv(A, w.s, EpiTs{w.s, w.t}, w.partials, &g, skip));       // t = A s, t.s, t.t
-    ORC_TRY(reduce_partials(w.partials, g, 2, w.scal + S_TS));
+    ORC_TRY(reduce_partials(w.partials, g, 2, w.scal + S_TS, A.halo != nullptr));
     hipLaunchKernelGGL(bicg_xr_k, dim3(vg), dim3(kBlock), 0, ctx().stream, w.scal, S_RHO0 + cur, x, w.p, w.s, w.t, w.r, n, w.partials, guard);
-    ORC_TRY(reduce_partials(w.partials, vg, 1, w.scal + S_RHO0 + nxt));        // rho = r_hat_0 . r
+    ORC_TRY(reduce_partials(w.partials, vg, 1, w.scal + S_RHO0 + nxt, A.halo != nullptr));  // rho = r_hat_0 . r
     hipLaunchKernelGGL(bicg_p_k, dim3(vg), dim3(kBlock), 0, ctx().stream, w.scal, S_RHO0 + cur, S_RHO0 + nxt, w.r, w.nu, w.p, n, guard);
     ORC_HIP(hipGetLastError());
     return ORC_OK;
@@ -338,11 +339,11 @@ static int bicgstab_dev(const MatView &A, const double *b, double *x, uint64_t i
     if (n == 0) return ORC_OK;
     Arena::Mark mk = arena.mark();
     BicgWork w;
-    ORC_TRY(bicg_alloc(arena, n, w));
+    ORC_TRY(bicg_alloc(arena, std::max(A.P.ncols, n), w));
     const int guard = ctx().breakdown_guard ? 1 : 0;
     int g = 0;
     ORC_TRY(launch_spmv(A, x, EpiResidual{b, w.r, w.p}, w.partials, &g));      // r = b - A x ; p = r ; rho = sum(r)
-    ORC_TRY(reduce_partials(w.partials, g, 1, w.scal + S_RHO0));
+    ORC_TRY(reduce_partials(w.partials, g, 1, w.scal + S_RHO0, A.halo != nullptr));
     for (uint64_t it = 0; it < iteration_count; ++it) ORC_TRY(bicg_iteration(A, x, w, it, guard));
     arena.release(mk);
     return ORC_OK;
@@ -352,10 +353,10 @@ int bench_bicgstab_dev(const MatView &A, const double *b, double *x, int reps, A
     const int64_t n = A.P.n;
     Arena::Mark mk = arena.mark();
     BicgWork w;
-    ORC_TRY(bicg_alloc(arena, n, w));
+    ORC_TRY(bicg_alloc(arena, std::max(A.P.ncols, n), w));
     int g = 0;
     ORC_TRY(launch_spmv(A, x, EpiResidual{b, w.r, w.p}, w.partials, &g));
-    ORC_TRY(reduce_partials(w.partials, g, 1, w.scal + S_RHO0));
+    ORC_TRY(reduce_partials(w.partials, g, 1, w.scal + S_RHO0, A.halo != nullptr));
     hipEvent_t e0, e1;
     ORC_HIP(hipEventCreate(&e0));
     ORC_HIP(hipEventCreate(&e1));
@@ -452,13 +453,26 @@ __global__ __launch_bounds__(kBlock) void jacobi_residual_k(MatView A, const dou
     if (threadIdx.x == 0) { partials[blockIdx.x] = t; partials[gridDim.x + blockIdx.x] = m; }
 }
 
-// one thread: the reference's per-sweep bookkeeping (:208-216)
-__global__ void jacobi_control_k(const double *__restrict__ partials, int count, double threshold, JacobiCtrl *ctrl) {
+// fold the per-workgroup maxima (second partial array of jacobi_residual_k)
+__global__ __launch_bounds__(1024) void reduce_max_k(const double *__restrict__ partials, int count, double *__restrict__ out) {
+    __shared__ double lds[16];
+    double v = 0.;
+    for (int i = threadIdx.x; i < count; i += blockDim.x) v = fmax(v, partials[i]);
+    v = wave_max(v);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = lds[0];
+        for (int i = 1; i < (int)(blockDim.x >> 6); ++i) r = fmax(r, lds[i]);
+        out[0] = r;
+    }
+}
+
+// one thread: the reference's per-sweep bookkeeping (:208-216); red[0] = sum((b - A x)^2), red[1] = max |x|
+__global__ void jacobi_control_k(const double *__restrict__ red, double threshold, JacobiCtrl *ctrl) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (ctrl->done || ctrl->status) return;
-    double r2 = 0., mx = 0.;
-    for (int i = 0; i < count; ++i) { r2 += partials[i]; mx = fmax(mx, partials[count + i]); }
-    const double r = sqrt(r2);
+    const double r = sqrt(red[0]), mx = red[1];
     ctrl->sweeps += 1;
     const long long it = ctrl->iter_num;
     ctrl->iter_num = it + 1;
@@ -473,10 +487,12 @@ static int jacobi_dev(const MatView &A, const double *b, double *x, uint64_t ite
     *status_out = ORC_OK;
     if (n == 0 || iteration_count == 0) return ORC_OK;
     Arena::Mark mk = arena.mark();
-    double *x2, *partials;
+    double *x2, *partials, *red;
     JacobiCtrl *ctrl;
-    ORC_TRY(arena.alloc((size_t)n, &x2));
+    const bool global = A.halo != nullptr;
+    ORC_TRY(arena.alloc((size_t)std::max(A.P.ncols, n), &x2));
     ORC_TRY(arena.alloc((size_t)2 * kMaxPartials, &partials));
+    ORC_TRY(arena.alloc((size_t)2, &red));
     ORC_TRY(arena.alloc((size_t)1, &ctrl));
     ORC_HIP(hipMemsetAsync(ctrl, 0, sizeof(JacobiCtrl), ctx().stream));
     const int g = spmv_grid(A.P.n_slices);
@@ -484,9 +500,14 @@ static int jacobi_dev(const MatView &A, const double *b, double *x, uint64_t ite
     // buffers untouched, so the newest iterate is in x2 iff the executed sweep count is odd.
     double *cur = x, *nxt = x2;
     for (uint64_t it = 0; it < iteration_count; ++it) {
+        if (global) ORC_TRY(A.halo->exchange(cur));
         hipLaunchKernelGGL(jacobi_sweep_k, dim3(g), dim3(kBlock), 0, ctx().stream, A, b, cur, nxt, relaxation_factor, ctrl);
+        if (global) ORC_TRY(A.halo->exchange(nxt));
         hipLaunchKernelGGL(jacobi_residual_k, dim3(g), dim3(kBlock), 0, ctx().stream, A, b, nxt, partials, ctrl);
-        hipLaunchKernelGGL(jacobi_control_k, dim3(1), dim3(1), 0, ctx().stream, partials, g, threshold, ctrl);
+        ORC_TRY(reduce_partials(partials, g, 1, red, global));
+        hipLaunchKernelGGL(reduce_max_k, dim3(1), dim3(1024), 0, ctx().stream, partials + g, g, red + 1);
+        if (global) ORC_TRY(comm_allreduce_max(red + 1, 1));
+        hipLaunchKernelGGL(jacobi_control_k, dim3(1), dim3(1), 0, ctx().stream, red, threshold, ctrl);
         std::swap(cur, nxt);
     }
     ORC_HIP(hipGetLastError());

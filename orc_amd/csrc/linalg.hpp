@@ -1,6 +1,7 @@
 // linalg.hpp — device sparse matrix format and the iterative solvers (K1-K8 of SURVEY §2.1).
 #pragma once
 #include "common.hpp"
+#include "halo.hpp"
 
 namespace orc {
 
@@ -10,7 +11,8 @@ namespace orc {
 // is still accumulated in ascending-column order from 0.0 — the summation order of
 // nalgebra-sparse's CSR product, which makes y = A x bit-identical to the CPU oracle.
 struct SellDev {
-    int64_t n = 0;
+    int64_t n = 0;      // rows (owned cells)
+    int64_t ncols = 0;  // vector length: rows + ghost columns of a partitioned matrix (== n otherwise)
     int32_t n_slices = 0;
     const int64_t *slice_ptr = nullptr;  // [n_slices+1], element offsets (multiples of 64)
     const int32_t *row_len = nullptr;    // [n]
@@ -27,11 +29,13 @@ struct MatView {
     const double *s1 = nullptr;
     const double *s2 = nullptr;
     bool symmetric = true;  // structural symmetry of the pattern (aggregation fast path)
+    HaloPlan *halo = nullptr;  // partitioned level-0 operator: x's ghost entries are refreshed before every product,
+                               // reductions are summed over ranks; coarse AMG levels are per-rank (halo == nullptr)
 };
 
 // Owning pattern (built on the host from CSR, e.g. the mesh pattern or a user matrix).
 struct SellMatrix {
-    int64_t n = 0, nnz = 0, padded = 0;
+    int64_t n = 0, ncols = 0, nnz = 0, padded = 0;
     int32_t n_slices = 0;
     bool symmetric = true;
     DevBuf<int64_t> slice_ptr;
@@ -39,12 +43,12 @@ struct SellMatrix {
     DevBuf<int64_t> csr_row_ptr;  // for value import/export in CSR (ORC) order
     SellDev dev() const {
         SellDev d;
-        d.n = n; d.n_slices = n_slices; d.slice_ptr = slice_ptr.p; d.row_len = row_len.p; d.col = col.p; d.diag_pos = diag_pos.p;
+        d.n = n; d.ncols = ncols; d.n_slices = n_slices; d.slice_ptr = slice_ptr.p; d.row_len = row_len.p; d.col = col.p; d.diag_pos = diag_pos.p;
         return d;
     }
 };
 
-int sell_from_csr_host(int64_t n, const int64_t *row_ptr, const int64_t *col, SellMatrix &out);
+int sell_from_csr_host(int64_t n, int64_t ncols, const int64_t *row_ptr, const int64_t *col, SellMatrix &out);
 // values: CSR order (device) <-> SELL order (device)
 int sell_import_values(const SellMatrix &m, const double *csr_vals_dev, double *sell_vals_dev);
 int sell_export_values(const SellMatrix &m, const double *sell_vals_dev, double *csr_vals_dev);

@@ -83,6 +83,6 @@ __global__ __launch_bounds__(kBlock) void spmv_k(MatView A, const double *__rest
 // caller follows it with an RCCL all-reduce of out[0..nq).
 __global__ __launch_bounds__(1024) void reduce_partials_k(const double *__restrict__ partials, int count, int nq, double *__restrict__ out);
 
-int reduce_partials(const double *partials, int count, int nq, double *out);
+int reduce_partials(const double *partials, int count, int nq, double *out, bool global = false);
 
 }  // namespace orc

@@ -1,0 +1,192 @@
+"""Cell-partitioned multi-GPU runs: one process per GPU, slabs of cells with one layer of ghost cells.
+
+Host-side logic only: building a rank's slab of the synthetic hex channel (owned cells first, ghost blocks after),
+the halo plan (who sends which owned cells to whom), and the communicator bootstrap.  The data path is inside
+liborc_amd.so: grouped ncclSend/ncclRecv halo exchange and ncclAllReduce of the BiCGSTAB scalars over RCCL/xGMI.
+A host-staged debug transport over torch.distributed (gloo) lets the tests run two ranks on ONE GPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import check, lib
+from .mesh import Mesh, MeshArrays, hex_channel, set_channel_bcs
+
+_I64 = C.POINTER(C.c_int64)
+_I32 = C.POINTER(C.c_int32)
+_F64 = C.POINTER(C.c_double)
+
+
+# ------------------------------------------------------------------ slab construction (pure numpy: testable on CPU)
+def slab_arrays(nx, ny, nz_local, rank, world, lx=0.002, ly=0.001, dz=1e-4):
+    """Rank `rank`'s part of the (nx, ny, nz_local*world) hex channel, cut in z-slabs (contiguous in ORC's cell order).
+
+    Returns (MeshArrays of the local mesh, halo dict, global_ids[n_local]).  Local numbering: owned cells in global
+    order, then the ghost plane below (peer rank-1), then the ghost plane above (peer rank+1).  Faces: those touching an
+    owned cell, ascending global order, global c0/c1 orientation; ghost cells get empty face lists."""
+    g_lo = 1 if rank > 0 else 0
+    g_hi = 1 if rank < world - 1 else 0
+    nzt = nz_local + g_lo + g_hi
+    a = hex_channel(nx, ny, nzt, lx=lx, ly=ly, lz=dz * nzt)
+    plane = nx * ny
+    n_all = plane * nzt
+    n_own = plane * nz_local
+    old = np.arange(n_all)
+    kk = old // plane
+    owned = (kk >= g_lo) & (kk < g_lo + nz_local)
+    new_of_old = np.empty(n_all, np.int64)
+    new_of_old[owned] = old[owned] - g_lo * plane
+    if g_lo:
+        new_of_old[kk == 0] = n_own + old[kk == 0]
+    if g_hi:
+        top = kk == nzt - 1
+        new_of_old[top] = n_own + g_lo * plane + (old[top] - (nzt - 1) * plane)
+    c0, c1 = np.asarray(a["face_c0"]), np.asarray(a["face_c1"])
+    keep = owned[c0] | ((c1 >= 0) & owned[np.maximum(c1, 0)])
+    new_face = np.cumsum(keep) - 1
+    f0 = new_of_old[c0[keep]]
+    f1 = np.where(c1[keep] >= 0, new_of_old[np.maximum(c1[keep], 0)], -1)
+    n_local = n_own + (g_lo + g_hi) * plane
+    # owned cells keep their 6 faces (all kept); ghost cells: none
+    cf_old = np.asarray(a["cell_faces"]).reshape(n_all, 6)
+    cf = new_face[cf_old[owned]].reshape(-1)
+    cfp = np.concatenate([np.arange(0, 6 * n_own + 1, 6), np.full(n_local - n_own, 6 * n_own)]).astype(np.int64)
+    order = np.argsort(new_of_old, kind="stable")  # old ids in new order
+    z0 = dz * (rank * nz_local - g_lo)
+    cc = np.asarray(a["cell_centroid"])[order].copy()
+    cc[:, 2] += z0
+    fc = np.asarray(a["face_centroid"])[keep].copy()
+    fc[:, 2] += z0
+    out = MeshArrays(
+        face_c0=f0.astype(np.int64), face_c1=f1.astype(np.int64), face_zone=np.asarray(a["face_zone"])[keep].copy(),
+        face_area=np.asarray(a["face_area"])[keep].copy(), face_normal=np.asarray(a["face_normal"])[keep].copy(), face_centroid=fc,
+        cell_centroid=cc, cell_volume=np.asarray(a["cell_volume"])[order].copy(), cell_face_ptr=cfp, cell_faces=cf.astype(np.int64),
+        zone_type=a["zone_type"].copy(), zone_scalar=a["zone_scalar"].copy(), zone_vector=a["zone_vector"].copy(),
+        zone_names=list(a["zone_names"]))
+    peers, send, recv_ptr = [], [], [0]
+    if g_lo:
+        peers.append(rank - 1)
+        send.append(np.arange(0, plane, dtype=np.int64))             # my bottom owned plane -> their ghost-above block
+        recv_ptr.append(recv_ptr[-1] + plane)
+    if g_hi:
+        peers.append(rank + 1)
+        send.append(np.arange(n_own - plane, n_own, dtype=np.int64))  # my top owned plane -> their ghost-below block
+        recv_ptr.append(recv_ptr[-1] + plane)
+    send_ptr = np.concatenate([[0], np.cumsum([len(s) for s in send])]).astype(np.int64) if send else np.zeros(1, np.int64)
+    halo = dict(n_owned=n_own, n_global=plane * nz_local * world, peers=np.array(peers, np.int32), send_ptr=send_ptr,
+                send_idx=np.concatenate(send) if send else np.zeros(0, np.int64), recv_ptr=np.array(recv_ptr, np.int64))
+    global_ids = (old[order] - g_lo * plane) + rank * n_own  # global cell id of every local cell (ghosts included)
+    return out, halo, global_ids
+
+
+class PartitionedMesh(Mesh):
+    """Device mesh of one rank (orc_mesh_create_partitioned)."""
+
+    def __init__(self, arrays, halo):
+        a = arrays
+        self.arrays = a
+        self.halo = halo
+        k = [np.ascontiguousarray(a["face_c0"], np.int64), np.ascontiguousarray(a["face_c1"], np.int64),
+             np.ascontiguousarray(a["face_zone"], np.int32), np.ascontiguousarray(a["face_area"], np.float64),
+             np.ascontiguousarray(a["face_normal"], np.float64), np.ascontiguousarray(a["face_centroid"], np.float64),
+             np.ascontiguousarray(a["cell_centroid"], np.float64), np.ascontiguousarray(a["cell_volume"], np.float64),
+             np.ascontiguousarray(a["cell_face_ptr"], np.int64), np.ascontiguousarray(a["cell_faces"], np.int64),
+             np.ascontiguousarray(a["zone_type"], np.int32), np.ascontiguousarray(a["zone_scalar"], np.float64),
+             np.ascontiguousarray(a["zone_vector"], np.float64)]
+        peers = np.ascontiguousarray(halo["peers"], np.int32)
+        sp, si, rp = (np.ascontiguousarray(halo[x], np.int64) for x in ("send_ptr", "send_idx", "recv_ptr"))
+        st = C.c_int(0)
+        L = lib()
+        L.orc_mesh_create_partitioned.restype = C.c_void_p
+        ptr = L.orc_mesh_create_partitioned(
+            C.c_int64(halo["n_owned"]), C.c_int64(len(k[7])), C.c_int64(halo["n_global"]), C.c_int64(len(k[3])), C.c_int32(len(k[10])),
+            k[0].ctypes.data_as(_I64), k[1].ctypes.data_as(_I64), k[2].ctypes.data_as(_I32), k[3].ctypes.data_as(_F64),
+            k[4].ctypes.data_as(_F64), k[5].ctypes.data_as(_F64), k[6].ctypes.data_as(_F64), k[7].ctypes.data_as(_F64),
+            k[8].ctypes.data_as(_I64), k[9].ctypes.data_as(_I64), k[10].ctypes.data_as(_I32), k[11].ctypes.data_as(_F64),
+            k[12].ctypes.data_as(_F64), C.c_int32(len(peers)), peers.ctypes.data_as(_I32), sp.ctypes.data_as(_I64),
+            si.ctypes.data_as(_I64), rp.ctypes.data_as(_I64), C.byref(st))
+        check(st.value)
+        self.ptr = C.c_void_p(ptr)
+        self.n_cells = L.orc_mesh_n_cells(self.ptr)  # local array length (owned + ghost)
+        L.orc_mesh_n_owned.restype = C.c_int64
+        self.n_owned = L.orc_mesh_n_owned(self.ptr)
+        self.nnz = L.orc_mesh_nnz(self.ptr)
+
+
+# ------------------------------------------------------------------ communicator bootstrap
+def init_comm(dist, rank, world):
+    """RCCL: rank 0 creates the unique id, torch.distributed broadcasts the 128 bytes, every rank joins."""
+    import torch
+    buf = (C.c_ubyte * 128)()
+    if rank == 0:
+        check(lib().orc_comm_get_unique_id(buf))
+    t = torch.tensor(list(bytes(buf)), dtype=torch.uint8)
+    dist.broadcast(t, src=0)
+    raw = bytes(t.tolist())
+    check(lib().orc_comm_init((C.c_ubyte * 128).from_buffer_copy(raw), C.c_int(rank), C.c_int(world)))
+
+
+_EXCHANGE_FN = C.CFUNCTYPE(None, C.c_int, C.POINTER(C.c_int), _F64, _I64, _I64, _F64, _I64, _I64, C.c_void_p)
+_ALLREDUCE_FN = C.CFUNCTYPE(None, _F64, C.c_int, C.c_int, C.c_void_p)
+_keepalive = []
+
+
+def exchange_over_dist(dist, rank, peers, send, send_off, send_cnt, recv, recv_off, recv_cnt):
+    """The halo exchange of one field carried by torch.distributed point-to-point (numpy views in, filled in place).
+    Lower rank sends first on each pair to avoid a deadlock with blocking gloo sends."""
+    import torch
+    for q, peer in enumerate(peers):
+        s = torch.from_numpy(np.ascontiguousarray(send[send_off[q]:send_off[q] + send_cnt[q]]))
+        r = torch.empty(int(recv_cnt[q]), dtype=torch.float64)
+        if rank < peer:
+            dist.send(s, dst=int(peer))
+            dist.recv(r, src=int(peer))
+        else:
+            dist.recv(r, src=int(peer))
+            dist.send(s, dst=int(peer))
+        recv[recv_off[q]:recv_off[q] + recv_cnt[q]] = r.numpy()
+
+
+def init_host_transport(dist, rank, world):
+    """Debug transport (tests: ranks sharing one GPU): halos and all-reduces go through host memory and gloo."""
+    import torch
+
+    def ex(n_peers, peers, send, send_off, send_cnt, recv, recv_off, recv_cnt, _user):
+        ps = [peers[i] for i in range(n_peers)]
+        so = [send_off[i] for i in range(n_peers)]
+        sc = [send_cnt[i] for i in range(n_peers)]
+        ro = [recv_off[i] for i in range(n_peers)]
+        rc = [recv_cnt[i] for i in range(n_peers)]
+        n_send = max((o + c for o, c in zip(so, sc)), default=0)
+        n_recv = max((o + c for o, c in zip(ro, rc)), default=0)
+        sv = np.ctypeslib.as_array(send, shape=(max(n_send, 1),))
+        rv = np.ctypeslib.as_array(recv, shape=(max(n_recv, 1),))
+        exchange_over_dist(dist, rank, ps, sv, so, sc, rv, ro, rc)
+
+    def ar(values, n, op, _user):
+        v = np.ctypeslib.as_array(values, shape=(n,))
+        t = torch.from_numpy(v.copy())
+        dist.all_reduce(t, op=dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MAX)
+        v[:] = t.numpy()
+
+    cex, car = _EXCHANGE_FN(ex), _ALLREDUCE_FN(ar)
+    _keepalive.extend([cex, car])
+    check(lib().orc_comm_init(None, C.c_int(rank), C.c_int(world)))
+    check(lib().orc_comm_set_host_transport(C.cast(cex, C.c_void_p), C.cast(car, C.c_void_p), None))
+
+
+def finalize():
+    check(lib().orc_comm_finalize())
+
+
+# ------------------------------------------------------------------ bench helper
+def make_slab_solver(nx, ny, nz, rank, world, settings, initial_fields):
+    """Weak scaling: every rank owns an nx x ny x nz slab of the (nx, ny, nz*world) channel."""
+    from .solver import Solver
+    a, halo, gids = slab_arrays(nx, ny, nz, rank, world)
+    set_channel_bcs(a)
+    mesh = PartitionedMesh(a, halo)
+    u, v, w, p = initial_fields(np.asarray(a["cell_centroid"]))
+    solver = Solver(mesh, settings, 1000.0, 1e-3)
+    solver.set_fields(u, v, w, p)
+    return solver, mesh, halo["n_global"], mesh.nnz

@@ -1,0 +1,12 @@
+"""Two ranks sharing cuda:0 through the host-staged debug transport: partitioned SIMPLE iterations vs the single-rank run
+(Jacobi solver: bit-exact; BiCGSTAB: 1e-9; Multigrid with per-rank coarse levels: same answer to a few percent)."""
+import pytest
+
+from test_partition_cpu import launch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_two_ranks_match_single_rank(gpu):
+    r = launch(2, "gpu", timeout=900)
+    assert "MP_WORKER_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-4000:]
