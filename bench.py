@@ -107,10 +107,14 @@ def main():
     from orc_amd.settings import NumericalSettings, SolutionMethod as SM
     from orc_amd.solver import Solver
 
-    orc_amd.init(local_rank)
+    host_transport = os.environ.get("ORC_BENCH_HOST_TRANSPORT") == "1"  # rehearsal on a 1-GPU box: ranks share cuda:0
+    orc_amd.init(0 if host_transport else local_rank)
     if world > 1:
         from orc_amd import parallel
-        parallel.init_comm(dist, rank, world)
+        if host_transport:
+            parallel.init_host_transport(dist, rank, world)
+        else:
+            parallel.init_comm(dist, rank, world)
 
     solver_map = {"multigrid": SM.Multigrid, "bicgstab": SM.BiCGSTAB, "jacobi": SM.Jacobi, "multigrid_gs": SM.Multigrid_GS,
                   "bicgstab_gs": SM.BiCGSTAB_GS}

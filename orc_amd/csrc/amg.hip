@@ -133,53 +133,107 @@ __global__ void tail_seed_k(TailCounters *T, int n) {
     if (blockIdx.x == 0 && threadIdx.x == 0) { T->cur = n; T->changed = 0; T->next = 0; T->rounds = 0; }
 }
 
+// Row-level kernels use one 16-lane group per row: coarse-level rows hold 40-100 entries and a single thread
+// walking them is a chain of dependent gathers.  Lanes take entries k = lane, lane+16, ...; the group then
+// reduces (value, k) lexicographically, which is exactly the sequential "strict <, first wins" scan.
+constexpr int kG = 16;
+
+__device__ __forceinline__ int group_eval_row(const MatView &A, const int *__restrict__ taken_by, int64_t i, int gl) {
+    const int len = A.P.row_len[i];
+    const int64_t base = A.P.slice_ptr[i >> 6] + (i & 63);
+    double best = 1.7976931348623157e308;  // Float::MAX
+    int bk = 0x7fffffff, bj = -1;
+    for (int k = gl; k < len; k += kG) {
+        const int64_t pos = base + (int64_t)k * 64;
+        const int j = A.P.col[pos];
+        if (j == i || j >= A.P.n) continue;
+        if (taken_by[j] < i) continue;
+        const double a = view_value(A, i, pos);
+        if (a < best) { best = a; bk = k; bj = j; }
+    }
+#pragma unroll
+    for (int off = kG / 2; off > 0; off >>= 1) {
+        const double ob = __shfl_xor(best, off, kG);
+        const int ok = __shfl_xor(bk, off, kG);
+        const int oj = __shfl_xor(bj, off, kG);
+        if (ob < best || (ob == best && ok < bk)) { best = ob; bk = ok; bj = oj; }
+    }
+    return bj;
+}
+
 __global__ void tail_eval_k(MatView A, const int *__restrict__ choice, const int *__restrict__ taken_by, const int *__restrict__ list,
                             TailCounters *T, int *__restrict__ flag, int *__restrict__ ch_row, int *__restrict__ ch_new) {
     const int count = T->cur;
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < count; idx += gridDim.x * blockDim.x) {
-        const int i = list ? list[idx] : idx;
-        flag[i] = 0;
-        const int nv = agg_eval_row(A, taken_by, i, true);
-        if (nv != choice[i]) {
-            const int slot = atomicAdd(&T->changed, 1);
-            ch_row[slot] = i;
-            ch_new[slot] = nv;
+    const int gl = threadIdx.x & (kG - 1);
+    const int64_t groups = ((int64_t)gridDim.x * blockDim.x) / kG;
+    for (int64_t idx = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kG; idx < count; idx += groups) {
+        const int i = list ? list[idx] : (int)idx;
+        const int nv = group_eval_row(A, taken_by, i, gl);
+        if (gl == 0) {
+            flag[i] = 0;
+            if (nv != choice[i]) {
+                const int slot = atomicAdd(&T->changed, 1);
+                ch_row[slot] = i;
+                ch_new[slot] = nv;
+            }
         }
     }
 }
 
-__global__ void tail_commit_k(int *__restrict__ choice, const TailCounters *T, const int *__restrict__ ch_row, const int *__restrict__ ch_new,
-                              int *__restrict__ ch_old) {
+// commit the changes; remember who held the two touched columns before (for the exact activation interval)
+__global__ void tail_commit_k(int *__restrict__ choice, const int *__restrict__ taken_by, const TailCounters *T, const int *__restrict__ ch_row,
+                              const int *__restrict__ ch_new, int *__restrict__ ch_old, int *__restrict__ ch_t_old, int *__restrict__ ch_t_new) {
     const int count = T->changed;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < count; idx += gridDim.x * blockDim.x) {
         const int i = ch_row[idx];
-        ch_old[idx] = choice[i];
-        choice[i] = ch_new[idx];
+        const int old = choice[i], nv = ch_new[idx];
+        ch_old[idx] = old;
+        ch_t_old[idx] = old >= 0 ? taken_by[old] : 0x7fffffff;
+        ch_t_new[idx] = nv >= 0 ? taken_by[nv] : 0x7fffffff;
+        choice[i] = nv;
     }
 }
 
-// exact taken_by for the columns touched by the committed changes + activation of the rows that can see them
+// exact taken_by for the columns touched by the committed changes + activation of the rows that can see them.
+// Column j's first taker moves from t_old to t_new; only rows m holding j with min < m <= max see a different
+// "taken" status: if j got taken earlier, just those that had chosen it; if it was freed, all of them (they may
+// prefer it now).
+__device__ __forceinline__ void tail_touch_column(const MatView &A, const int *choice, int *taken_by, int j, int t_before, int gl, int *flag,
+                                                  int *next_list, int *next_count) {
+    const int lj = A.P.row_len[j];
+    const int64_t bj = A.P.slice_ptr[j >> 6] + (j & 63);
+    int mn = 0x7fffffff;
+    for (int kk = gl; kk < lj; kk += kG) {  // rows holding column j = (symmetric pattern) the columns of row j
+        const int m = A.P.col[bj + (int64_t)kk * 64];
+        if (m >= A.P.n || m == j) continue;
+        if (choice[m] == j && m < mn) mn = m;
+    }
+#pragma unroll
+    for (int off = kG / 2; off > 0; off >>= 1) mn = min(mn, __shfl_xor(mn, off, kG));
+    if (mn != t_before) {
+        const int lo = min(mn, t_before), hi = max(mn, t_before);
+        const bool taken_earlier = mn < t_before;
+        for (int kk = gl; kk < lj; kk += kG) {
+            const int m = A.P.col[bj + (int64_t)kk * 64];
+            if (m >= A.P.n || m <= lo || m > hi) continue;
+            if (taken_earlier && choice[m] != j) continue;
+            if (atomicExch(&flag[m], 1) == 0) next_list[atomicAdd(next_count, 1)] = m;
+        }
+    }
+    if (gl == 0) taken_by[j] = mn;  // several changes touching j compute the same value
+}
+
 __global__ void tail_update_k(MatView A, const int *__restrict__ choice, int *__restrict__ taken_by, TailCounters *T,
                               const int *__restrict__ ch_row, const int *__restrict__ ch_new, const int *__restrict__ ch_old,
-                              int *__restrict__ flag, int *__restrict__ next_list) {
+                              const int *__restrict__ ch_t_old, const int *__restrict__ ch_t_new, int *__restrict__ flag,
+                              int *__restrict__ next_list) {
     const int count = T->changed;
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < count; idx += gridDim.x * blockDim.x) {
-        const int i = ch_row[idx];
-        const int js[2] = {ch_old[idx], ch_new[idx]};
-        for (int t = 0; t < 2; ++t) {
-            const int j = js[t];
-            if (j < 0) continue;
-            const int lj = A.P.row_len[j];
-            const int64_t bj = A.P.slice_ptr[j >> 6] + (j & 63);
-            int mn = 0x7fffffff;
-            for (int kk = 0; kk < lj; ++kk) {  // rows holding column j = (symmetric pattern) the columns of row j
-                const int m = A.P.col[bj + (int64_t)kk * 64];
-                if (m >= A.P.n) continue;  // ghost column
-                if (m != j && choice[m] == j && m < mn) mn = m;
-                if (m > i && atomicExch(&flag[m], 1) == 0) next_list[atomicAdd(&T->next, 1)] = m;
-            }
-            taken_by[j] = mn;  // several changes touching j compute the same value
-        }
+    const int gl = threadIdx.x & (kG - 1);
+    const int64_t groups = ((int64_t)gridDim.x * blockDim.x) / kG;
+    for (int64_t idx = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kG; idx < count; idx += groups) {
+        const int old = ch_old[idx], nv = ch_new[idx];
+        if (old >= 0) tail_touch_column(A, choice, taken_by, old, ch_t_old[idx], gl, flag, next_list, &T->next);
+        if (nv >= 0) tail_touch_column(A, choice, taken_by, nv, ch_t_new[idx], gl, flag, next_list, &T->next);
     }
 }
 
@@ -540,7 +594,7 @@ struct CoarseLevel {
     int rounds = 0;
 };
 
-static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, int *rounds_out) {
+static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, int *rounds_out, const int *warm = nullptr) {
     const int64_t n = A.P.n;
     const int g = grid_for(n);
     const int gs = grid_for(A.P.n_slices, 64);  // one thread per slice, 64-thread workgroups spread the slices over the CUs
@@ -554,14 +608,16 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
     ORC_TRY(arena.alloc((size_t)64, &snap));
     hipStream_t st = ctx().stream;
     ORC_HIP(hipMemsetAsync(C, 0, sizeof(AggCounters), st));
-    hipLaunchKernelGGL(agg_init_k, dim3(g), dim3(kBlock), 0, st, A, choice, act_a, act_b);
+    hipLaunchKernelGGL(agg_init_k, dim3(g), dim3(kBlock), 0, st, A, choice, act_a, act_b);  // also resets the slice flags
+    if (warm) ORC_HIP(hipMemcpyAsync(choice, warm, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, st));
     int rounds = 0;
     const bool sym = A.symmetric;
     const int all_active = sym ? 0 : 1;  // activation needs "rows holding column j" = columns of row j
     unsigned char *cur = act_a, *nxt = act_b;
     // ---- bulk phase: slice-sequential sweeps (all of the work on structurally asymmetric patterns)
     const int kBulk = sym ? 3 : 4;
-    bool done = false;
+    static const int warm_mode = getenv("ORC_AMG_WARM") ? atoi(getenv("ORC_AMG_WARM")) : 0;
+    bool done = sym && warm != nullptr && warm_mode == 1;  // mode 1: straight to the certifying row-level rounds; 2: sweeps first
     while (!done) {
         for (int b = 0; b < kBulk; ++b) {
             hipLaunchKernelGGL(agg_reset_k, dim3(g), dim3(kBlock), 0, st, taken_by, n);
@@ -584,7 +640,7 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
     }
     if (sym) {
         // ---- tail phase: exact taken_by once, then row-level rounds
-        int *flag, *listA, *listB, *ch_row, *ch_new, *ch_old;
+        int *flag, *listA, *listB, *ch_row, *ch_new, *ch_old, *ch_t_old, *ch_t_new;
         TailCounters *T;
         ORC_TRY(arena.alloc((size_t)n, &flag));
         ORC_TRY(arena.alloc((size_t)n, &listA));
@@ -592,6 +648,8 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
         ORC_TRY(arena.alloc((size_t)n, &ch_row));
         ORC_TRY(arena.alloc((size_t)n, &ch_new));
         ORC_TRY(arena.alloc((size_t)n, &ch_old));
+        ORC_TRY(arena.alloc((size_t)n, &ch_t_old));
+        ORC_TRY(arena.alloc((size_t)n, &ch_t_new));
         ORC_TRY(arena.alloc((size_t)1, &T));
         hipLaunchKernelGGL(agg_reset_k, dim3(g), dim3(kBlock), 0, st, taken_by, n);
         hipLaunchKernelGGL(agg_scatter_k, dim3(g), dim3(kBlock), 0, st, choice, taken_by, n);
@@ -599,15 +657,14 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
         hipLaunchKernelGGL(tail_seed_k, dim3(1), dim3(1), 0, st, T, (int)n);
         const int *cur_list = nullptr;  // first round: every row
         int *next_list = listA;
-        const int kBatch = 32;
-        bool first = true;
-        while (true) {
-            const int batch = first ? 2 : kBatch;
-            for (int b = 0; b < batch; ++b) {
-                const int ge = first ? g : 256;
+        const int kBatch = 16;  // rounds per host round trip; a round past the fixed point is a no-op
+        bool first = true, fin = false;
+        while (!fin) {
+            for (int b = 0; b < kBatch; ++b) {
+                const int ge = first ? g : 1024;
                 hipLaunchKernelGGL(tail_eval_k, dim3(ge), dim3(kBlock), 0, st, A, choice, taken_by, cur_list, T, flag, ch_row, ch_new);
-                hipLaunchKernelGGL(tail_commit_k, dim3(ge), dim3(kBlock), 0, st, choice, T, ch_row, ch_new, ch_old);
-                hipLaunchKernelGGL(tail_update_k, dim3(ge), dim3(kBlock), 0, st, A, choice, taken_by, T, ch_row, ch_new, ch_old, flag, next_list);
+                hipLaunchKernelGGL(tail_commit_k, dim3(ge), dim3(kBlock), 0, st, choice, taken_by, T, ch_row, ch_new, ch_old, ch_t_old, ch_t_new);
+                hipLaunchKernelGGL(tail_update_k, dim3(ge), dim3(kBlock), 0, st, A, choice, taken_by, T, ch_row, ch_new, ch_old, ch_t_old, ch_t_new, flag, next_list);
                 hipLaunchKernelGGL(tail_rotate_k, dim3(1), dim3(1), 0, st, T, snap + b);
                 cur_list = next_list;
                 next_list = (next_list == listA) ? listB : listA;
@@ -615,14 +672,12 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
             }
             ORC_HIP(hipGetLastError());
             int h[kBatch];
-            ORC_HIP(hipMemcpyAsync(h, snap, sizeof(int) * batch, hipMemcpyDeviceToHost, st));
+            ORC_HIP(hipMemcpyAsync(h, snap, sizeof(h), hipMemcpyDeviceToHost, st));
             ORC_HIP(hipStreamSynchronize(st));
-            bool fin = false;
-            for (int b = 0; b < batch; ++b) {
+            for (int b = 0; b < kBatch; ++b) {
                 ++rounds;
                 if (h[b] == 0) { fin = true; break; }  // an evaluation round without a change: fixed point
             }
-            if (fin) break;
             if (rounds > 8 * 1000 * 1000) return set_error(ORC_ERR_BAD_ARGUMENT, "aggregation did not reach its fixed point");
         }
     }
@@ -718,7 +773,15 @@ static int multigrid_solve_dev(const MatView &A, const double *r, uint64_t level
     ORC_TRY(arena.alloc((size_t)std::max<int64_t>(n, 1), &choice));
     ORC_TRY(arena.alloc((size_t)std::max<int64_t>(n, 1), &chooser));
     CoarseLevel L;
-    ORC_TRY(aggregate(A, arena, choice, chooser, &L.rounds));  // :80 (scratch is released with the level)
+    AmgCache *cache = stats ? stats->cache : nullptr;
+    const int *warm = nullptr;
+    static const bool warm_enabled = getenv("ORC_AMG_WARM") != nullptr && atoi(getenv("ORC_AMG_WARM")) != 0;
+    if (warm_enabled && cache && level < 8 && cache->size[level] == n) warm = cache->choice[level].p;
+    ORC_TRY(aggregate(A, arena, choice, chooser, &L.rounds, warm));  // :80 (scratch is released with the level)
+    if (cache && level < 8) {
+        if (cache->size[level] != n) { ORC_TRY(cache->choice[level].alloc((size_t)std::max<int64_t>(n, 1))); cache->size[level] = n; }
+        ORC_HIP(hipMemcpyAsync(cache->choice[level].p, choice, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, st));
+    }
     ORC_TRY(galerkin(A, choice, chooser, arena, L));  // :84
     const int64_t nc = L.n;
     if (stats && level < 8) {

@@ -669,7 +669,7 @@ int k_apply_correction(SolverState &s, double *sums_host) {
     return ORC_OK;
 }
 
-static int solve_field(SolverState &s, DevBuf<double> &a, DevBuf<double> &b, DevBuf<double> &x) {
+static int solve_field(SolverState &s, DevBuf<double> &a, DevBuf<double> &b, DevBuf<double> &x, int eq) {
     MatView A;
     A.P = s.mesh->pat.dev();
     A.val = a.p;
@@ -677,6 +677,7 @@ static int solve_field(SolverState &s, DevBuf<double> &a, DevBuf<double> &b, Dev
     A.halo = s.mesh->halo.active() ? &s.mesh->halo : nullptr;
     const OrcSettings &t = s.settings;
     ctx().breakdown_guard = t.breakdown_guard != 0;
+    s.stats.cache = &s.amg_cache[eq];
     return iterative_solve_dev(A, b.p, x.p, t.iterations, t.solver_type, t.relaxation, t.relative_convergence_threshold,
                                t.preconditioner, s.arena, &s.stats);
 }
@@ -706,17 +707,17 @@ int solver_iterate(SolverState &s, uint64_t iterations, double *report) {
         ORC_TRY(k_momentum(s, report ? peclet : nullptr));       // :61-82
         if (H.active()) { double *d3[3] = {s.du.p, s.dv.p, s.dw.p}; ORC_TRY(H.exchange(d3, 3)); }
         if (dbg) { debug_field(s, "b_u", s.b_u); debug_field(s, "b_v", s.b_v); debug_field(s, "b_w", s.b_w); }
-        ORC_TRY(solve_field(s, s.a_u, s.b_u, s.u));              // :99-110
+        ORC_TRY(solve_field(s, s.a_u, s.b_u, s.u, 0));              // :99-110
         if (dbg) debug_field(s, "u", s.u);
-        ORC_TRY(solve_field(s, s.a_v, s.b_v, s.v));              // :112-123
+        ORC_TRY(solve_field(s, s.a_v, s.b_v, s.v, 1));              // :112-123
         if (dbg) debug_field(s, "v", s.v);
-        ORC_TRY(solve_field(s, s.a_w, s.b_w, s.w));              // :125-136
+        ORC_TRY(solve_field(s, s.a_w, s.b_w, s.w, 2));              // :125-136
         if (dbg) debug_field(s, "w", s.w);
         if (H.active()) { double *f[3] = {s.u.p, s.v.p, s.w.p}; ORC_TRY(H.exchange(f, 3)); }
         ORC_TRY(k_pressure_correction(s));                       // :137-148
         ORC_TRY(vec_fill(s.p_prime.p, 0., s.n));                 // :167
         if (dbg) debug_field(s, "b_p", s.b_p);
-        ORC_TRY(solve_field(s, s.a_p, s.b_p, s.p_prime));        // :168-179
+        ORC_TRY(solve_field(s, s.a_p, s.b_p, s.p_prime, 3));        // :168-179
         if (dbg) debug_field(s, "p_prime", s.p_prime);
         if (H.active()) ORC_TRY(H.exchange(s.p_prime.p));
         double sums[5];

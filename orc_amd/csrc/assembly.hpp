@@ -65,6 +65,7 @@ struct SolverState {
     DevBuf<int> dev_status;
     Arena arena;
     SolveStats stats;
+    AmgCache amg_cache[4];  // u, v, w, p' (warm start of the per-solve hierarchy set-up)
     uint64_t iterations_done = 0;
 };
 

@@ -53,7 +53,16 @@ int sell_from_csr_host(int64_t n, int64_t ncols, const int64_t *row_ptr, const i
 int sell_import_values(const SellMatrix &m, const double *csr_vals_dev, double *sell_vals_dev);
 int sell_export_values(const SellMatrix &m, const double *sell_vals_dev, double *csr_vals_dev);
 
+// Warm start of the AMG set-up: the greedy pairing is a fixed point that the device reaches by iteration from ANY
+// initial state, and a SIMPLE run changes its matrices slowly, so each (equation, level) keeps its last pairing as
+// the next solve's starting guess.  The result is the same exact fixed point; only the number of rounds changes.
+struct AmgCache {
+    DevBuf<int> choice[8];  // per level: partner of every fine row of that level
+    int64_t size[8] = {0};
+};
+
 struct SolveStats {
+    AmgCache *cache = nullptr;  // optional, owned by the caller (one per equation)
     int64_t jacobi_sweeps = 0;
     int amg_levels = 0;
     int64_t amg_rows[8] = {0};

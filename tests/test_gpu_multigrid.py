@@ -130,3 +130,25 @@ def test_solve_steady_default_stack_one_iteration(gpu, oracle, mesh_path):
     assert oracle.solve_steady(om, uo, vo, wo, po_, oracle.default_settings(**kw), 1000.0, 1e-3, 1)[0] == 0
     solve_steady(dm, u, v, w, p, NumericalSettings.default(**kw), 1000.0, 1e-3, 1)
     assert H.rel_l2(u, uo) < 1e-8 and H.rel_l2(p, po_) < 1e-8
+
+
+def test_default_stack_is_reproducible_run_to_run(gpu, oracle, mesh_path):
+    """Reductions fold their partials in a fixed order and the aggregation's fixed point is unique, so two runs of the
+    same four SIMPLE iterations (default stack) give identical bits even though the aggregation rounds use atomics."""
+    import helpers as H
+    from orc_amd.mesh import Mesh, MeshArrays
+    from orc_amd.settings import NumericalSettings
+    from orc_amd.solver import Solver
+    om = oracle.Mesh.read(mesh_path("channel_flow"))
+    H.channel_bcs(om)
+    a = MeshArrays(om.arrays())
+    dm = Mesh(a)
+    u, v, w, p = H.seeded_fields(a, seed=4, scale_u=4e-4)
+    runs = []
+    for _ in range(2):
+        s = Solver(dm, NumericalSettings.default(iterations=10), 1000.0, 1e-3)
+        s.set_fields(u, v, w, p)
+        s.iterate(4)
+        runs.append(s.get_fields())
+    for x, y in zip(*runs):
+        assert np.array_equal(x, y)
