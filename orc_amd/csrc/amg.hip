@@ -375,9 +375,9 @@ __device__ __forceinline__ int wave_excl_scan(int v, int &total) {
 }
 
 __global__ __launch_bounds__(64) void galerkin_wave_k(MatView A, const int *__restrict__ choice, const int *__restrict__ chooser, int64_t n_coarse,
-                                                      int cap /* power of two */, int *__restrict__ row_len_c, long long *__restrict__ row_off,
-                                                      int *__restrict__ s_col, double *__restrict__ s_val, unsigned long long *alloc,
-                                                      long long scratch_cap, int *__restrict__ overflow_flag,
+                                                      int cap /* power of two */, int *__restrict__ row_len_c, const long long *__restrict__ slice_base,
+                                                      const int *__restrict__ intra_off, int *__restrict__ s_col, double *__restrict__ s_val,
+                                                      int *__restrict__ overflow_flag,
                                                       const int *__restrict__ list, const int *__restrict__ list_count,
                                                       int *__restrict__ ovf_list, int *__restrict__ ovf_count) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -495,28 +495,23 @@ __global__ __launch_bounds__(64) void galerkin_wave_k(MatView A, const int *__re
             }
             __syncthreads();
         }
-        // ---- output
-        long long off = 0;
-        if (lane == 0) off = (long long)atomicAdd(alloc, (unsigned long long)lenO);
-        off = __shfl(off, 0, 64);
-        if (off + lenO <= scratch_cap) {
-            for (int e = lane; e < lenO; e += 64) { s_col[off + e] = (int)key2[e]; s_val[off + e] = val2[e]; }
-        } else if (lane == 0) {
-            atomicExch(overflow_flag, 2);
-        }
-        if (lane == 0) { row_len_c[I] = lenO; row_off[I] = off; }
+        // ---- output (scratch offset = exclusive scan of the per-row bound: deterministic, no atomics)
+        const long long off = slice_base[I >> 6] + intra_off[I];
+        for (int e = lane; e < lenO; e += 64) { s_col[off + e] = (int)key2[e]; s_val[off + e] = val2[e]; }
+        if (lane == 0) row_len_c[I] = lenO;
         __syncthreads();
     }
 }
 
 // scratch rows -> SELL-64 (columns, values, diagonal offsets, padding)
-__global__ void galerkin_pack_k(SellDev Pc, const long long *__restrict__ row_off, const int *__restrict__ s_col, const double *__restrict__ s_val,
+__global__ void galerkin_pack_k(SellDev Pc, const long long *__restrict__ slice_base, const int *__restrict__ intra_off, const int *__restrict__ s_col,
+                                const double *__restrict__ s_val,
                                 int *__restrict__ col_c, double *__restrict__ val_c, int *__restrict__ diag_c) {
     for (int64_t I = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; I < Pc.n; I += (int64_t)gridDim.x * blockDim.x) {
         const int64_t base = Pc.slice_ptr[I >> 6] + (I & 63);
         const int width = (int)((Pc.slice_ptr[(I >> 6) + 1] - Pc.slice_ptr[I >> 6]) >> 6);
         const int len = Pc.row_len[I];
-        const long long off = row_off[I];
+        const long long off = slice_base[I >> 6] + intra_off[I];
         int d = -1;
         for (int q = 0; q < width; ++q) {
             const int64_t pos = base + (int64_t)q * 64;
@@ -534,21 +529,60 @@ __global__ void galerkin_pack_k(SellDev Pc, const long long *__restrict__ row_of
     }
 }
 
-// capacity bound for the candidate lists: sum of the lengths of the (<= 4) fine rows of each coarse row
-__global__ __launch_bounds__(kBlock) void galerkin_bound_k(SellDev P, const int *__restrict__ choice, int64_t n_coarse, int *__restrict__ out_max,
-                                                           unsigned long long *__restrict__ out_sum) {
-    __shared__ double lds[8];
-    double mx = 0., sm = 0.;
-    for (int64_t I = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; I < n_coarse; I += (int64_t)gridDim.x * blockDim.x) {
-        const RRow R = restriction_row(choice, I, P.n);
-        int s = 0;
-        for (int a = 0; a < R.n; ++a) s += P.row_len[R.idx[a]];
-        mx = fmax(mx, (double)s);
-        sm += (double)s;
+// Per coarse row: candidate count c = sum of the lengths of its (<= 4) fine rows.  2c bounds the row's coarse
+// entries (every candidate spawns <= 2 products), so the scratch offset of row I is the exclusive prefix sum of 2c:
+// computed here per 64-row slice (wave scan) + slice totals, finished by scan_i64_k.  No allocator atomics.
+__global__ __launch_bounds__(64) void galerkin_bound_k(SellDev P, const int *__restrict__ choice, int64_t n_coarse, int *__restrict__ out_max,
+                                                       unsigned long long *__restrict__ out_sum, int *__restrict__ intra_off,
+                                                       long long *__restrict__ slice_tot) {
+    const int lane = threadIdx.x;
+    const int64_t n_slices = (n_coarse + 63) / 64;
+    int mx = 0;
+    unsigned long long sm = 0;
+    for (int64_t s = blockIdx.x; s < n_slices; s += gridDim.x) {
+        const int64_t I = s * 64 + lane;
+        int c = 0;
+        if (I < n_coarse) {
+            const RRow R = restriction_row(choice, I, P.n);
+            for (int a = 0; a < R.n; ++a) c += P.row_len[R.idx[a]];
+        }
+        int tot;
+        const int ex = wave_excl_scan(2 * c, tot);
+        if (I < n_coarse) intra_off[I] = ex;
+        if (lane == 0) slice_tot[s] = tot;
+        mx = max(mx, c);
+        sm += (unsigned long long)c;
     }
-    const double m = block_max(mx, lds);
-    const double t = block_sum(sm, lds);
-    if (threadIdx.x == 0) { atomicMax(out_max, (int)m); atomicAdd(out_sum, (unsigned long long)t); }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        mx = max(mx, __shfl_down(mx, off, 64));
+        sm += __shfl_down(sm, off, 64);
+    }
+    if (lane == 0) { atomicMax(out_max, mx); atomicAdd(out_sum, sm); }
+}
+
+// exclusive scan of n int64 values by one workgroup (n = number of slices: tens of thousands)
+__global__ __launch_bounds__(1024) void scan_i64_k(const long long *__restrict__ in, int64_t n, long long *__restrict__ out) {
+    __shared__ long long carry;
+    __shared__ long long buf[1024];
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < n; base += 1024) {
+        const int64_t e = base + threadIdx.x;
+        const long long v = e < n ? in[e] : 0;
+        buf[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const long long t = threadIdx.x >= off ? buf[threadIdx.x - off] : 0;
+            __syncthreads();
+            buf[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (e < n) out[e] = carry + buf[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += buf[1023];
+        __syncthreads();
+    }
 }
 
 // slice widths -> slice_ptr (single workgroup scan; n_slices is n/64)
@@ -691,29 +725,33 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
 static int galerkin(const MatView &A, const int *choice, const int *chooser, Arena &arena, CoarseLevel &L) {
     const int64_t n = A.P.n, nc = n / 2 + n % 2;  // :13
     hipStream_t st = ctx().stream;
-    int *row_len, *diag, *flags, *ovf_list;  // flags[0] = max candidates, [1] = overflow, [2] = #rows for the wide launch
-    long long *row_off;
-    unsigned long long *counters;  // [0] = bump allocator, [1] = sum of candidates
+    int *row_len, *diag, *flags, *ovf_a, *ovf_b, *intra_off;  // flags[0] = max candidates, [1] = overflow, [2],[3] = overflow-list counts
+    long long *slice_tot, *slice_base;
+    unsigned long long *counters;  // [1] = sum of candidates
     int64_t *slice_ptr;
     const int n_slices = (int)((nc + 63) / 64);
     const size_t ncs = (size_t)std::max<int64_t>(nc, 1);
     ORC_TRY(arena.alloc(ncs, &row_len));
     ORC_TRY(arena.alloc(ncs, &diag));
-    ORC_TRY(arena.alloc(ncs, &ovf_list));
-    ORC_TRY(arena.alloc(ncs, &row_off));
+    ORC_TRY(arena.alloc(ncs, &ovf_a));
+    ORC_TRY(arena.alloc(ncs, &ovf_b));
+    ORC_TRY(arena.alloc(ncs, &intra_off));
+    ORC_TRY(arena.alloc((size_t)n_slices + 1, &slice_tot));
+    ORC_TRY(arena.alloc((size_t)n_slices + 1, &slice_base));
     ORC_TRY(arena.alloc((size_t)n_slices + 1, &slice_ptr));
     ORC_TRY(arena.alloc((size_t)4, &flags));
     ORC_TRY(arena.alloc((size_t)2, &counters));
     ORC_HIP(hipMemsetAsync(flags, 0, 4 * sizeof(int), st));
     ORC_HIP(hipMemsetAsync(counters, 0, 2 * sizeof(unsigned long long), st));
-    hipLaunchKernelGGL(galerkin_bound_k, dim3(grid_for(nc)), dim3(kBlock), 0, st, A.P, choice, nc, flags, counters + 1);
+    hipLaunchKernelGGL(galerkin_bound_k, dim3((unsigned)std::min<int64_t>(n_slices, 8192)), dim3(64), 0, st, A.P, choice, nc, flags, counters + 1, intra_off,
+                       slice_tot);
+    hipLaunchKernelGGL(scan_i64_k, dim3(1), dim3(1024), 0, st, slice_tot, (int64_t)n_slices, slice_base);
     int hflags[4];
     unsigned long long hcount[2];
     ORC_HIP(hipMemcpyAsync(hflags, flags, sizeof(hflags), hipMemcpyDeviceToHost, st));
     ORC_HIP(hipMemcpyAsync(hcount, counters, sizeof(hcount), hipMemcpyDeviceToHost, st));
     ORC_HIP(hipStreamSynchronize(st));
     const int max_cand = std::max(hflags[0], 1);
-    // every candidate of T spawns <= 2 products: 2 * sum bounds the coarse nnz (and the scratch area)
     const long long scratch_cap = (long long)std::max<unsigned long long>(2ull * hcount[1], 64ull);
     int *s_col;
     double *s_val;
@@ -724,18 +762,30 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&galerkin_wave_k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    // capacities: narrow launch 128 entries (4 KiB/wave), wide launch the bound rounded up to a power of two
+    // LDS tiers (32 B per list slot): 128 slots for the typical row, a middle tier around twice the mean candidate
+    // count, and the bound for the longest row; a row that does not fit a tier is queued for the next one.
     int cap_wide = 64;
     while (cap_wide < 2 * max_cand) cap_wide <<= 1;
     if ((size_t)cap_wide * 32 > (size_t)150 * 1024) return set_error(ORC_ERR_BAD_ARGUMENT, "Galerkin row too long for LDS (%d candidates)", max_cand);
-    const int cap_narrow = std::min(cap_wide, 128);
-    const int g1 = (int)std::min<int64_t>(nc, 256 * 16);
-    hipLaunchKernelGGL(galerkin_wave_k, dim3(g1), dim3(64), (size_t)cap_narrow * 32, st, A, choice, chooser, nc, cap_narrow, row_len, row_off, s_col, s_val,
-                       counters, scratch_cap, flags + 1, nullptr, nullptr, ovf_list, flags + 2);
-    if (cap_wide > cap_narrow) {
-        const int g2 = (int)std::min<int64_t>(nc, 256 * 4);
-        hipLaunchKernelGGL(galerkin_wave_k, dim3(g2), dim3(64), (size_t)cap_wide * 32, st, A, choice, chooser, nc, cap_wide, row_len, row_off, s_col, s_val,
-                           counters, scratch_cap, flags + 1, ovf_list, flags + 2, nullptr, nullptr);
+    const double mean_cand = (double)hcount[1] / (double)std::max<int64_t>(nc, 1);
+    int cap_mid = 128;
+    while (cap_mid < 2.5 * 2.0 * mean_cand) cap_mid <<= 1;
+    int tiers[3];
+    int n_tiers = 0;
+    tiers[n_tiers++] = std::min(128, cap_wide);
+    if (cap_mid > tiers[n_tiers - 1] && cap_mid < cap_wide) tiers[n_tiers++] = cap_mid;
+    if (cap_wide > tiers[n_tiers - 1]) tiers[n_tiers++] = cap_wide;
+    const int *in_list = nullptr, *in_count = nullptr;
+    int *lists[2] = {ovf_a, ovf_b};
+    for (int t = 0; t < n_tiers; ++t) {
+        const bool last = t == n_tiers - 1;
+        const size_t smem = (size_t)tiers[t] * 32;
+        const int waves_per_cu = (int)std::max<size_t>(1, std::min<size_t>(16, (size_t)(150 * 1024) / smem));
+        const int g = (int)std::min<int64_t>(nc, (int64_t)256 * waves_per_cu);
+        hipLaunchKernelGGL(galerkin_wave_k, dim3(g), dim3(64), smem, st, A, choice, chooser, nc, tiers[t], row_len, slice_base, intra_off, s_col, s_val,
+                           flags + 1, in_list, in_count, last ? nullptr : lists[t & 1], last ? nullptr : flags + 2 + (t & 1));
+        in_list = lists[t & 1];
+        in_count = flags + 2 + (t & 1);
     }
     hipLaunchKernelGGL(slice_ptr_k, dim3(1), dim3(1024), 0, st, row_len, nc, n_slices, slice_ptr);
     ORC_HIP(hipGetLastError());
@@ -751,7 +801,7 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
     ORC_TRY(arena.alloc((size_t)std::max<int64_t>(padded, 1), &val));
     SellDev Pc;
     Pc.n = nc; Pc.ncols = nc; Pc.n_slices = n_slices; Pc.slice_ptr = slice_ptr; Pc.row_len = row_len; Pc.col = col; Pc.diag_pos = diag;
-    hipLaunchKernelGGL(galerkin_pack_k, dim3(grid_for(nc)), dim3(kBlock), 0, st, Pc, row_off, s_col, s_val, col, val, diag);
+    hipLaunchKernelGGL(galerkin_pack_k, dim3(grid_for(nc)), dim3(kBlock), 0, st, Pc, slice_base, intra_off, s_col, s_val, col, val, diag);
     ORC_HIP(hipGetLastError());
     L.P = Pc; L.val = val; L.n = nc; L.padded = padded;
     return ORC_OK;
