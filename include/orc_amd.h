@@ -92,6 +92,10 @@ int orc_amg_coarsen(int64_t n, const int64_t *row_ptr, const int64_t *col_idx, c
                     int64_t *out_n_coarse, int64_t *out_nnz, int64_t *out_row_ptr, int64_t *out_col, double *out_val,
                     int *rounds);
 
+/* Test hook for the multicolour Gauss-Seidel extension: the distance-1 colouring (Jones-Plassmann, first fit) the device
+ * uses for a pattern; rows of one colour share no entry. */
+int orc_debug_coloring(int64_t n, const int64_t *row_ptr, const int64_t *col_idx, int32_t *colors /*[n]*/, int32_t *n_colors);
+
 /* ---------- discretization::* ---------- */
 /* build_momentum_diffusion_matrix (discretization.rs:39-48): values in pattern order + 3 RHS */
 int orc_build_momentum_diffusion_matrix(const OrcMesh *m, int diffusion_scheme, double mu,

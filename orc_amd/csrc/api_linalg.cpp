@@ -6,6 +6,7 @@
 namespace orc {
 int amg_debug_coarsen(const MatView &A, Arena &arena, std::vector<int> &choice_h, std::vector<int64_t> &row_ptr_h,
                       std::vector<int64_t> &col_h, std::vector<double> &val_h, int *rounds);
+int gs_debug_coloring(const SellDev &P, std::vector<int> &colors, int *n_colors);
 static SolveStats g_last_stats;
 SolveStats &last_stats() { return g_last_stats; }
 }  // namespace orc
@@ -105,6 +106,19 @@ int orc_amg_coarsen(int64_t n, const int64_t *row_ptr, const int64_t *col_idx, c
         std::copy(ci.begin(), ci.end(), out_col);
         std::copy(v.begin(), v.end(), out_val);
     }
+    return ORC_OK;
+}
+
+int orc_debug_coloring(int64_t n, const int64_t *row_ptr, const int64_t *col_idx, int32_t *colors, int32_t *n_colors) {
+    using namespace orc;
+    ORC_TRY(ensure_init());
+    SellMatrix pat;
+    ORC_TRY(sell_from_csr_host(n, n, row_ptr, col_idx, pat));
+    std::vector<int> c;
+    int nc = 0;
+    ORC_TRY(gs_debug_coloring(pat.dev(), c, &nc));
+    for (int64_t i = 0; i < n; ++i) colors[i] = c[(size_t)i];
+    if (n_colors) *n_colors = nc;
     return ORC_OK;
 }
 

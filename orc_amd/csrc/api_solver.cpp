@@ -7,6 +7,10 @@
 
 using namespace orc;
 
+namespace orc {
+void gs_forget_pattern(const void *col_ptr);  // gs.hip
+}
+
 namespace {
 
 int upload_csr_values(OrcMesh &m, const double *host_vals, DevBuf<double> &sell, DevBuf<double> &tmp) {
@@ -88,7 +92,10 @@ int orc_mesh_update_zones(OrcMesh *m, const int32_t *zone_type, const double *zo
     return ORC_OK;
 }
 
-void orc_mesh_destroy(OrcMesh *m) { delete m; }
+void orc_mesh_destroy(OrcMesh *m) {
+    if (m) orc::gs_forget_pattern((const void *)m->pat.col.p);
+    delete m;
+}
 int64_t orc_mesh_n_cells(const OrcMesh *m) { return m ? m->n_cells : 0; }
 int64_t orc_mesh_n_owned(const OrcMesh *m) { return m ? m->n_own : 0; }
 int64_t orc_mesh_nnz(const OrcMesh *m) { return m ? m->pat.nnz : 0; }

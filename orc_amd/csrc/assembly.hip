@@ -675,6 +675,7 @@ static int solve_field(SolverState &s, DevBuf<double> &a, DevBuf<double> &b, Dev
     A.val = a.p;
     A.symmetric = s.mesh->pat.symmetric;
     A.halo = s.mesh->halo.active() ? &s.mesh->halo : nullptr;
+    A.persistent_pattern = true;
     const OrcSettings &t = s.settings;
     ctx().breakdown_guard = t.breakdown_guard != 0;
     s.stats.cache = &s.amg_cache[eq];

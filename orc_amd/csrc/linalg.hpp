@@ -29,6 +29,7 @@ struct MatView {
     const double *s1 = nullptr;
     const double *s2 = nullptr;
     bool symmetric = true;  // structural symmetry of the pattern (aggregation fast path)
+    bool persistent_pattern = false;  // the pattern outlives the solve (mesh pattern): derived data such as a colouring may be cached
     HaloPlan *halo = nullptr;  // partitioned level-0 operator: x's ghost entries are refreshed before every product,
                                // reductions are summed over ranks; coarse AMG levels are per-rank (halo == nullptr)
 };

@@ -72,3 +72,15 @@ def amg_coarsen(a):
     orp, oci, ov = np.empty(nc.value + 1, np.int64), np.empty(nnz.value, np.int64), np.empty(nnz.value)
     check(lib().orc_amg_coarsen(*args, _p(orp, C.c_int64), _p(oci, C.c_int64), _p(ov, C.c_double), C.byref(rounds)))
     return partner, sp.csr_matrix((ov, oci, orp), shape=(nc.value, nc.value)), rounds.value
+
+
+def debug_coloring(a):
+    """Test hook: (colors[n], n_colors) of the multicolour Gauss-Seidel extension for the pattern of `a`."""
+    a = a.tocsr()
+    a.sort_indices()
+    n = a.shape[0]
+    rp, ci = _i64(a.indptr), _i64(a.indices)
+    colors = np.empty(n, np.int32)
+    nc = C.c_int32(0)
+    check(lib().orc_debug_coloring(C.c_int64(n), _p(rp, C.c_int64), _p(ci, C.c_int64), _p(colors, C.c_int32), C.byref(nc)))
+    return colors, nc.value
