@@ -248,7 +248,15 @@ __global__ void bicg_s_k(double *__restrict__ scal, int rho_idx, const double *_
         if (blockIdx.x == 0 && threadIdx.x == 0) scal[S_FROZEN] = 1.;
         return;
     }
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) s[i] = r[i] - alpha * nu[i];
+    // 16-byte accesses: two consecutive elements per lane (arena vectors are 256-byte aligned)
+    const int64_t n2 = n >> 1;
+    const double2 *r2 = reinterpret_cast<const double2 *>(r), *nu2 = reinterpret_cast<const double2 *>(nu);
+    double2 *s2 = reinterpret_cast<double2 *>(s);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (int64_t)gridDim.x * blockDim.x) {
+        const double2 a = r2[i], b = nu2[i];
+        s2[i] = make_double2(a.x - alpha * b.x, a.y - alpha * b.y);
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) s[n - 1] = r[n - 1] - alpha * nu[n - 1];
 }
 // h = x + alpha p ; x = h + omega s ; r = s - omega t ; partial sum(r)   (:258, :261-263, :265)
 __global__ __launch_bounds__(kBlock) void bicg_xr_k(double *__restrict__ scal, int rho_idx, double *__restrict__ x,
@@ -271,7 +279,20 @@ __global__ __launch_bounds__(kBlock) void bicg_xr_k(double *__restrict__ scal, i
         }
         if (blockIdx.x == 0 && threadIdx.x == 0) scal[S_FROZEN2] = 1.;
     } else {
-        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n2 = n >> 1;
+        double2 *x2 = reinterpret_cast<double2 *>(x), *r2 = reinterpret_cast<double2 *>(r);
+        const double2 *p2 = reinterpret_cast<const double2 *>(p), *s2 = reinterpret_cast<const double2 *>(s), *t2 = reinterpret_cast<const double2 *>(t);
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (int64_t)gridDim.x * blockDim.x) {
+            const double2 xv = x2[i], pv = p2[i], sv = s2[i], tv = t2[i];
+            const double h0 = xv.x + alpha * pv.x, h1 = xv.y + alpha * pv.y;
+            x2[i] = make_double2(h0 + omega * sv.x, h1 + omega * sv.y);
+            const double q0 = sv.x - omega * tv.x, q1 = sv.y - omega * tv.y;
+            r2[i] = make_double2(q0, q1);
+            acc += q0;
+            acc += q1;
+        }
+        if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+            const int64_t i = n - 1;
             const double h = x[i] + alpha * p[i];
             const double si = s[i];
             x[i] = h + omega * si;
@@ -295,8 +316,14 @@ __global__ void bicg_p_k(double *__restrict__ scal, int rho_prev_idx, int rho_id
         if (blockIdx.x == 0 && threadIdx.x == 0) scal[S_FROZEN] = 1.;
         return;
     }
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        p[i] = r[i] + beta * (p[i] - omega * nu[i]);
+    const int64_t n2 = n >> 1;
+    double2 *p2 = reinterpret_cast<double2 *>(p);
+    const double2 *r2 = reinterpret_cast<const double2 *>(r), *nu2 = reinterpret_cast<const double2 *>(nu);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (int64_t)gridDim.x * blockDim.x) {
+        const double2 rv = r2[i], pv = p2[i], nv = nu2[i];
+        p2[i] = make_double2(rv.x + beta * (pv.x - omega * nv.x), rv.y + beta * (pv.y - omega * nv.y));
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) p[n - 1] = r[n - 1] + beta * (p[n - 1] - omega * nu[n - 1]);
 }
 
 struct BicgWork {
@@ -318,7 +345,7 @@ static int bicg_alloc(Arena &arena, int64_t n, BicgWork &w) {  // n = vector len
 
 static int bicg_iteration(const MatView &A, double *x, const BicgWork &w, uint64_t it, int guard) {
     const int64_t n = A.P.n;
-    const int vg = grid_for(n);
+    const int vg = grid_for((n + 1) / 2);  // two elements per lane
     const int cur = (int)(it & 1), nxt = cur ^ 1;
     const double *skip = guard ? w.scal + S_FROZEN : nullptr;  // frozen solves skip their SpMVs too
     int g = 0;

@@ -57,13 +57,29 @@ __global__ __launch_bounds__(kBlock) void spmv_k(MatView A, const double *__rest
         const double s1 = (A.s1 && live) ? A.s1[row] : 1.;
         const double s2 = (A.s2 && live) ? A.s2[row] : 1.;
         double acc = 0.;
-        for (int k = 0; k < width; ++k) {
-            if (k < len) {
-                const int64_t pos = base + (int64_t)k * 64 + lane;
-                double v = A.val[pos];
-                if (A.s1) v = s1 * v;
-                if (A.s2) v = s2 * v;
-                acc += v * x[A.P.col[pos]];
+        // chunks of 8 entries: all column and value loads are issued first, then the dependent x gathers, then the
+        // products are added in ascending k — the association of the CPU product, just with the loads in flight together.
+        // Padding slots hold a valid column (the row itself) and are masked out of the sum.
+        for (int k0 = 0; k0 < width; k0 += 8) {
+            int c[8];
+            double v[8], xv[8];
+            const int64_t p0 = base + (int64_t)k0 * 64 + lane;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool in = k0 + u < width;
+                c[u] = in ? A.P.col[p0 + (int64_t)u * 64] : 0;
+                v[u] = in ? A.val[p0 + (int64_t)u * 64] : 0.;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xv[u] = (k0 + u < len) ? x[c[u]] : 0.;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (k0 + u < len) {
+                    double t = v[u];
+                    if (A.s1) t = s1 * t;
+                    if (A.s2) t = s2 * t;
+                    acc += t * xv[u];
+                }
             }
         }
         if (live) epi.apply(row, acc, r0, r1);

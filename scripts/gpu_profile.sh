@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: run_prof_tmp.sh <tag> <bench args...>
+# Run on the GPU box: kernel-trace stats of one bench.py run.  usage: scripts/gpu_profile.sh <tag> <bench args...>
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout -k 10 500 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$tag --output-format csv -- python bench.py "$@" > gpurun_out/prof_$tag.log 2>&1
