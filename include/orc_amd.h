@@ -69,6 +69,50 @@ int64_t orc_mesh_nnz(const OrcMesh *m);
 /* CSR pattern shared by a_di, a_u, a_v, a_w and the pressure-correction matrix */
 int orc_mesh_matrix_pattern(const OrcMesh *m, int64_t *row_ptr /*[n+1]*/, int64_t *col_idx /*[nnz]*/);
 
+/* ---------- io::read_mesh (io.rs:32-515) and Mesh::get_face_zone (mesh.rs:189-195): host only, no device needed ----------
+ * TGRID / Fluent ASCII .msh -> flat host image of mesh::Mesh with the reference's numbering and geometry rules
+ * (normal (n2-n1)x(n1-n0) normalised, flipped when cell 0 is absent; face centroid = node mean; area = triangle fan
+ * about the centroid; cell centroid = mean of face centroids; volume = sum A |(fc-cc).n| / dim; Cell.face_indices in
+ * ascending face id).  Reader quirks are kept: section items are read as hexadecimal (io.rs:47-54), zone-0 declaration
+ * sections are skipped (io.rs:24-30), a zone takes the last word of the preceding "(0 ...)" comment as its name
+ * (io.rs:83-90), the node count of a face line is "tokens - 2" also for mixed/polygonal zones (io.rs:232).
+ * Every expect()/panic! of the reference is ORC_ERR_MESH_FORMAT (ORC_ERR_IO when the file cannot be opened). */
+typedef struct OrcMeshData OrcMeshData;
+OrcMeshData *orc_read_mesh(const char *mesh_path, int *status);
+void orc_mesh_data_destroy(OrcMeshData *d);
+int orc_mesh_data_sizes(const OrcMeshData *d, int32_t *dimensions, int64_t *n_vertices, int64_t *n_cells, int64_t *n_faces,
+                        int64_t *n_cell_faces, int64_t *n_face_nodes, int32_t *n_zones);
+/* the argument arrays of orc_mesh_create; any pointer may be NULL */
+int orc_mesh_data_arrays(const OrcMeshData *d, int64_t *face_c0, int64_t *face_c1, int32_t *face_zone, double *face_area,
+                         double *face_normal, double *face_centroid, double *cell_centroid, double *cell_volume,
+                         int64_t *cell_face_ptr, int64_t *cell_faces);
+/* Mesh.vertices and Face.node_indices (0-based) */
+int orc_mesh_data_nodes(const OrcMeshData *d, double *vertices /*[3V]*/, int64_t *face_node_ptr /*[F+1]*/, int64_t *face_nodes);
+/* FaceZone k (order of first appearance in the file): TGRID zone id, type, values, name */
+int orc_mesh_data_zone(const OrcMeshData *d, int32_t k, uint64_t *zone_id, int32_t *zone_type, double *scalar_value,
+                       double *vector_value /*[3]*/, char *name, int64_t name_len);
+int orc_mesh_data_zone_index(const OrcMeshData *d, const char *name); /* -1 when absent */
+/* `let z = mesh.get_face_zone(name); z.zone_type = ..; z.scalar_value = ..; z.vector_value = ..` (tests.rs:60-76);
+ * ORC_ERR_ZONE_NOT_FOUND where the reference panics */
+int orc_mesh_data_set_zone(OrcMeshData *d, const char *name, int32_t zone_type, double scalar_value, const double *vector_value /*[3] or NULL*/);
+OrcMesh *orc_mesh_upload(const OrcMeshData *d, int *status);    /* = orc_mesh_create on the arrays above */
+int orc_mesh_sync_zones(OrcMesh *m, const OrcMeshData *d);      /* = orc_mesh_update_zones from d's zone table */
+
+/* ---------- io::read_data / write_data / write_data_with_precision / write_gradients (io.rs:519-662) ----------
+ * One line per cell: "{centroid}\t({u}, {v}, {w})\t{p}", centroid as Vector's Display "({:.2e}, {:.2e}, {:.2e})"
+ * (lib.rs:551-555), values in Rust LowerExp form (no '+', no exponent padding): shortest round-trip digits when
+ * decimal_precision < 0 (write_data's "{:.e}"), else that many fraction digits (write_data_with_precision). */
+int orc_write_data(const char *output_file_name, int64_t n_cells, const double *cell_centroid /*[3n]*/, const double *u,
+                   const double *v, const double *w, const double *p, int decimal_precision);
+/* Fills at most `capacity` rows, returns the row count of the file in n_read (capacity 0: count only).
+ * ORC_ERR_IO = the reference's Err("could not read data file"). */
+int orc_read_data(const char *data_file_path, int64_t capacity, double *u, double *v, double *w, double *p, int64_t *n_read);
+/* "{centroid}\t({9 velocity-gradient entries, row-major, each followed by ', '})\t({3 pressure-gradient entries, same})":
+ * the trailing ", " inside the parentheses is the reference's (its strip_suffix result is dropped, io.rs:644,654).
+ * Gradients come from the device Green-Gauss kernels (orc_calculate_gradients). */
+int orc_write_gradients(const OrcMesh *m, const double *cell_centroid, const double *u, const double *v, const double *w,
+                        const double *p, const char *output_file_name, int decimal_precision, const OrcSettings *settings);
+
 /* ---------- linear_algebra::iterative_solve (linear_algebra.rs:144-153) ---------- */
 int orc_iterative_solve(int64_t n, const int64_t *row_ptr, const int64_t *col_idx, const double *values,
                         const double *b, double *solution_vector /*in/out*/, uint64_t iteration_count,

@@ -106,7 +106,9 @@ enum OrcStatus {
     ORC_ERR_NO_DEVICE = 11,            /* HIP runtime/device missing: the product never falls back to a CPU path */
     ORC_ERR_HIP = 12,
     ORC_ERR_IO = 13,
-    ORC_ERR_COMM = 14
+    ORC_ERR_COMM = 14,
+    ORC_ERR_MESH_FORMAT = 15,          /* io.rs:32-515: any of read_mesh's expect()/panic! sites; orc_last_error() names file:line and the reference's message */
+    ORC_ERR_ZONE_NOT_FOUND = 16        /* mesh.rs:189-195 "face zone '{zone_name}' should exist in mesh" */
 };
 
 /* settings::NumericalSettings + settings::MatrixSolverSettings (lib.rs:14-56), flattened.
