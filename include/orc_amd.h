@@ -164,6 +164,19 @@ int orc_build_pressure_correction_matrices(const OrcMesh *m, const double *u, co
  * evaluated for every cell: grad_p[3n], grad_u[9n] (row = velocity component) */
 int orc_calculate_gradients(const OrcMesh *m, const double *u, const double *v, const double *w, const double *p,
                             const OrcSettings *settings, double *grad_p, double *grad_u);
+/* check_boundary_conditions (solver.rs:710-772): constraint_type 0 PressureOnly, 1 VelocityOnly, 2 Hybrid;
+ * ORC_ERR_NO_BOUNDARY_CONDITIONS for its "You must set boundary conditions." panic */
+int orc_check_boundary_conditions(const OrcMesh *m, int *constraint_type);
+/* initialize_pressure_field (solver.rs:414-509): Laplace system on the mesh pattern, 10 Jacobi sweeps; p in/out */
+int orc_initialize_pressure_field(const OrcMesh *m, double *p /*[n]*/);
+/* initialize_flow (solver.rs:246-352): pressure initialisation, UD / LinearWeighted momentum assembly at zero velocity,
+ * then the six-step diffusion -> advection ramp of Jacobi-preconditioned BiCGSTAB solves (iteration_count each).
+ * settings may be NULL; only q1_compat and breakdown_guard are read from it.  Outputs u, v, w, p [n]. */
+int orc_initialize_flow(const OrcMesh *m, double mu, double rho, uint64_t iteration_count, const OrcSettings *settings,
+                        double *u, double *v, double *w, double *p);
+/* initialize_flow_new (solver.rs:354-410), PressureOnly / Hybrid arms */
+int orc_initialize_flow_new(const OrcMesh *m, double mu, double rho, uint64_t iteration_count,
+                            double *u, double *v, double *w, double *p);
 /* solve_steady (solver.rs:26-37). report_cb is called every reporting_interval iterations with
  * what the reference prints (solver.rs:209-216): iteration, mean u/v/w, Peclet avg/min/max,
  * velocity- and pressure-correction norms, ms/iter.  May be NULL. */

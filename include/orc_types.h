@@ -108,7 +108,8 @@ enum OrcStatus {
     ORC_ERR_IO = 13,
     ORC_ERR_COMM = 14,
     ORC_ERR_MESH_FORMAT = 15,          /* io.rs:32-515: any of read_mesh's expect()/panic! sites; orc_last_error() names file:line and the reference's message */
-    ORC_ERR_ZONE_NOT_FOUND = 16        /* mesh.rs:189-195 "face zone '{zone_name}' should exist in mesh" */
+    ORC_ERR_ZONE_NOT_FOUND = 16,       /* mesh.rs:189-195 "face zone '{zone_name}' should exist in mesh" */
+    ORC_ERR_NO_BOUNDARY_CONDITIONS = 17 /* solver.rs:770 "You must set boundary conditions." */
 };
 
 /* settings::NumericalSettings + settings::MatrixSolverSettings (lib.rs:14-56), flattened.

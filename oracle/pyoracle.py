@@ -371,6 +371,18 @@ def pressure_gradient(mesh, p, q1=1):
     return g
 
 
+def velocity_gradient(mesh, u, v, w):
+    """calculate_velocity_gradient for every cell -> [n, 3, 3] (rows = Tensor.x, .y, .z)."""
+    u, v, w = _f64(u), _f64(v), _f64(w)
+    n = mesh.n_cells
+    g = np.zeros((n, 3, 3))
+    out = (_Vec3 * 3)()
+    for c in range(n):
+        _check(lib().or_calculate_velocity_gradient(mesh.ptr, _dp(u), _dp(v), _dp(w), C.c_int64(c), C.c_int(0), out))
+        g[c] = [(r.x, r.y, r.z) for r in out]
+    return g
+
+
 def solve_steady(mesh, u, v, w, p, settings, rho, mu, iteration_count, report=False):
     """solver::solve_steady; fields updated in place. Returns (status, report[iters,6] or None)."""
     for a in (u, v, w, p):

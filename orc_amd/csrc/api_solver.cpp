@@ -285,6 +285,64 @@ int orc_calculate_gradients(const OrcMesh *m, const double *u, const double *v, 
     return fetch_status(t);
 }
 
+// ---------------------------------------------------------------- solver::initialize_* (solver.rs:246-509)
+namespace {
+// the scheme triple initialize_flow hard-codes (solver.rs:301-304); q1_compat / breakdown_guard follow the caller
+OrcSettings initializer_settings(const OrcSettings *settings) {
+    OrcSettings t;
+    orc_settings_default(&t);
+    if (settings) { t.q1_compat = settings->q1_compat; t.breakdown_guard = settings->breakdown_guard; }
+    t.momentum = ORC_MOMENTUM_UD;
+    t.velocity_interpolation = ORC_VINTERP_LINEAR_WEIGHTED;
+    t.pressure_interpolation = ORC_PINTERP_LINEAR_WEIGHTED;
+    return t;
+}
+}  // namespace
+
+int orc_check_boundary_conditions(const OrcMesh *m, int *constraint_type) {
+    if (!m) return set_error(ORC_ERR_BAD_ARGUMENT, "null mesh");
+    const int kind = check_boundary_conditions(*m);
+    if (kind < 0) return set_error(-kind, "You must set boundary conditions.");
+    if (constraint_type) *constraint_type = kind;
+    return ORC_OK;
+}
+
+int orc_initialize_pressure_field(const OrcMesh *m, double *p) {
+    if (!m || !p) return set_error(ORC_ERR_BAD_ARGUMENT, "null argument");
+    const OrcSettings t = initializer_settings(nullptr);
+    auto s = std::make_unique<OrcSolver>();
+    ORC_TRY(solver_init(s->st, const_cast<OrcMesh *>(m), &t, 1.0, 1.0));
+    ORC_TRY(s->st.p.upload(p, (size_t)s->st.n));
+    int st = initialize_pressure_field_dev(s->st);
+    ORC_TRY(s->st.p.download(p, (size_t)s->st.n));
+    return st;
+}
+
+int orc_initialize_flow(const OrcMesh *m, double mu, double rho, uint64_t iteration_count, const OrcSettings *settings, double *u, double *v,
+                        double *w, double *p) {
+    if (!m || !u || !v || !w || !p) return set_error(ORC_ERR_BAD_ARGUMENT, "null argument");
+    const OrcSettings t = initializer_settings(settings);
+    auto s = std::make_unique<OrcSolver>();
+    ORC_TRY(solver_init(s->st, const_cast<OrcMesh *>(m), &t, rho, mu));  // fields start at zero (:273-277)
+    int st = initialize_flow_dev(s->st, iteration_count);
+    int st2 = orc_solver_get_fields(s.get(), u, v, w, p);
+    return st != ORC_OK ? st : st2;
+}
+
+// initialize_flow_new (solver.rs:354-410): PressureOnly | Hybrid -> initialize_pressure_field, velocities stay zero.
+// The VelocityOnly arm (initialize_velocity_field: potential-flow solve, dense least squares per cell, two files
+// written into ./examples) is outside SURVEY section 8 and reports ORC_ERR_UNSUPPORTED_SCHEME.
+int orc_initialize_flow_new(const OrcMesh *m, double mu, double rho, uint64_t iteration_count, double *u, double *v, double *w, double *p) {
+    (void)mu; (void)rho; (void)iteration_count;
+    if (!m || !u || !v || !w || !p) return set_error(ORC_ERR_BAD_ARGUMENT, "null argument");
+    int kind = 0;
+    ORC_TRY(orc_check_boundary_conditions(m, &kind));
+    if (kind == 1) return set_error(ORC_ERR_UNSUPPORTED_SCHEME, "initialize_velocity_field (VelocityOnly boundary conditions) is not provided");
+    const size_t n = (size_t)m->n_cells;
+    std::fill(u, u + n, 0.); std::fill(v, v + n, 0.); std::fill(w, w + n, 0.); std::fill(p, p + n, 0.);
+    return orc_initialize_pressure_field(m, p);
+}
+
 // ---------------------------------------------------------------- solver::solve_steady (solver.rs:26-244)
 int orc_solve_steady(OrcMesh *m, double *u, double *v, double *w, double *p, const OrcSettings *settings, double rho, double mu,
                      uint64_t iteration_count, uint64_t reporting_interval, OrcReportFn report_cb, void *user) {

@@ -89,6 +89,49 @@ __global__ void extract_diag_k(SellDev P, const double *__restrict__ a, double *
     GRID_STRIDE(c, P.n) d[c] = a[P.diag_pos[c]];
 }
 
+// ------------------------------------------------------------------ initialize_pressure_field's Laplace system
+// solver.rs:436-492 on the mesh pattern: interior faces couple the two cells with
+// a_nb = (cc - c_nb).reciprocal() . n_out * (A / V); pressure boundaries add a_nb to the diagonal and a_nb * P_bc to b;
+// every other zone type contributes nothing.  Sums run in Cell.face_indices order from 0.0 like the reference's.
+__device__ __forceinline__ V3 vreciprocal(V3 a) {  // lib.rs:246-252
+    return mk(a.x != 0. ? 1. / a.x : 0., a.y != 0. ? 1. / a.y : 0., a.z != 0. ? 1. / a.z : 0.);
+}
+
+__global__ void laplace_p_k(MeshDev M, SellDev P, double *__restrict__ a, double *__restrict__ b, int *status) {
+    GRID_STRIDE(c, M.n_own) {
+        const V3 cc = cell_centroid(M, (int)c);
+        const double vol = M.vol[c];
+        double a_p = 0., src = 0.;
+        for (int q = M.cfp[c]; q < M.cfp[c + 1]; ++q) {
+            const int f = M.cf[q];
+            const int z = M.fzone[f];
+            const int zt = M.ztype[z];
+            V3 nrm = mk(M.nx[f], M.ny[f], M.nz[f]);
+            if (M.c0[f] != c) nrm = vneg(nrm);  // get_outward_face_normal (mesh.rs:216-222)
+            double a_nb = 0., source = 0.;
+            if (zt == ORC_BC_INTERIOR) {  // :451-466
+                if (M.cfpos[q] < 0) { raise(status, ORC_ERR_BAD_ARGUMENT); continue; }  // cell_indices[1] out of bounds in the reference
+                const int nb = (M.c0[f] == c) ? M.c1[f] : M.c0[f];
+                a_nb = vdot(vreciprocal(vsub(cc, cell_centroid(M, nb))), nrm) * (M.area[f] / vol);
+                a[M.cfpos[q]] = -a_nb;  // :486
+            } else if (zt == ORC_BC_PRESSURE_INLET || zt == ORC_BC_PRESSURE_OUTLET) {  // :467-474
+                a_nb = vdot(vreciprocal(vsub(cc, face_centroid(M, f))), nrm) * (M.area[f] / vol);
+                source = a_nb * M.zscal[z];
+            }
+            src += source;  // :488
+            a_p += a_nb;    // :489
+        }
+        a[P.diag_pos[c]] = a_p;  // :491
+        b[c] = src;
+    }
+}
+
+// &a * (1. - f) + &a_di * f (solver.rs:319, 329, 339): CSR scale, CSR scale, CSR add — entry-wise on the shared pattern
+__global__ void blend_k(int64_t len, const double *__restrict__ a, const double *__restrict__ a_di, double one_minus_f, double f,
+                        double *__restrict__ out) {
+    GRID_STRIDE(i, len) out[i] = a[i] * one_minus_f + a_di[i] * f;
+}
+
 // ------------------------------------------------------------------ K9: Green-Gauss gradients
 // get_face_pressure with PressureInterpolation::Linear (solver.rs:1114-1128)
 __device__ __forceinline__ double face_pressure_linear(const MeshDev &M, const double *__restrict__ p, int f, int zt, int z) {
@@ -738,6 +781,84 @@ int solver_iterate(SolverState &s, uint64_t iterations, double *report) {
         if (std::isnan(u_avg) || std::isnan(v_avg) || std::isnan(w_avg)) return ORC_ERR_SOLUTION_DIVERGED;  // :217-221
     }
     return ORC_OK;
+}
+
+// ------------------------------------------------------------------ solver::initialize_* (solver.rs:246-509, 710-772)
+static MatView mesh_view(SolverState &s, double *values) {
+    MatView A;
+    A.P = s.mesh->pat.dev();
+    A.val = values;
+    A.symmetric = s.mesh->pat.symmetric;
+    A.halo = s.mesh->halo.active() ? &s.mesh->halo : nullptr;
+    A.persistent_pattern = true;
+    return A;
+}
+
+// check_boundary_conditions (solver.rs:710-772).  Its angle tolerance is 5*180/pi radians (:713), which no angle
+// exceeds, so the two "tangent" panics cannot fire; what remains is the count of velocity- and pressure-type zones.
+// A moving wall adds one count per mesh face (:722-723, a u16 that a release build wraps; not reproduced).
+// Returns 0 PressureOnly, 1 VelocityOnly, 2 Hybrid, or ORC_ERR_NO_BOUNDARY_CONDITIONS as a negative number.
+int check_boundary_conditions(const OrcMesh &m) {
+    std::vector<int32_t> zt((size_t)m.n_zones);
+    std::vector<double> zv((size_t)3 * m.n_zones);
+    if (m.ztype.download(zt.data(), zt.size()) != ORC_OK || m.zvec.download(zv.data(), zv.size()) != ORC_OK) return -ORC_ERR_HIP;
+    uint64_t pressure = 0, velocity = 0;
+    for (int z = 0; z < m.n_zones; ++z) {
+        const double *v = &zv[(size_t)3 * z];
+        if (zt[z] == ORC_BC_WALL) {
+            if (std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]) > 0.) velocity += (uint64_t)m.n_faces;
+        } else if (zt[z] == ORC_BC_VELOCITY_INLET) {
+            velocity += 1;
+        } else if (zt[z] == ORC_BC_PRESSURE_INLET || zt[z] == ORC_BC_PRESSURE_OUTLET) {
+            pressure += 1;
+        }
+    }
+    if (velocity > 0) return pressure > 1 ? 2 : 1;
+    if (pressure > 0) return 0;
+    return -ORC_ERR_NO_BOUNDARY_CONDITIONS;  // "You must set boundary conditions."
+}
+
+// initialize_pressure_field (solver.rs:414-509): Laplace system in s.a_p / s.b_p, 10 Jacobi sweeps (omega 0.1,
+// Jacobi-preconditioned) on s.p.
+int initialize_pressure_field_dev(SolverState &s) {
+    OrcMesh &m = *s.mesh;
+    ORC_TRY(s.a_p.zero());
+    hipLaunchKernelGGL(laplace_p_k, dim3(grid_for(s.n)), dim3(kBlock), 0, ctx().stream, m.dev(), m.pat.dev(), s.a_p.p, s.b_p.p, s.dev_status.p);
+    ORC_HIP(hipGetLastError());
+    s.stats.cache = nullptr;
+    ORC_TRY(iterative_solve_dev(mesh_view(s, s.a_p.p), s.b_p.p, s.p.p, 10, ORC_SOLVER_JACOBI, 0.1, 1e-6, ORC_PRECOND_JACOBI, s.arena, &s.stats));
+    return fetch_status(s);
+}
+
+// initialize_flow (solver.rs:246-352).  `s` must have been set up with UD / LinearWeighted / LinearWeighted
+// (:301-303) and zero fields; the blended matrix lives in s.a_p, which the pressure initialisation no longer needs.
+int initialize_flow_dev(SolverState &s, uint64_t iteration_count) {
+    const int kind = check_boundary_conditions(*s.mesh);  // :272 (result unused there, panics kept)
+    if (kind < 0) return set_error(-kind, "You must set boundary conditions.");
+    HaloPlan &H = s.mesh->halo;
+    const int64_t n = s.n;
+    ORC_TRY(initialize_pressure_field_dev(s));  // :287
+    if (H.active()) { double *f[4] = {s.u.p, s.v.p, s.w.p, s.p.p}; ORC_TRY(H.exchange(f, 4)); }
+    ORC_TRY(k_gradients(s, false));
+    if (H.active()) { double *g3[3] = {s.gp.p, s.gp.p + n, s.gp.p + 2 * n}; ORC_TRY(H.exchange(g3, 3)); }
+    ORC_TRY(k_face_flux(s, true));
+    ORC_TRY(k_momentum(s, nullptr));  // :288-309 (b += b_di inside)
+    ctx().breakdown_guard = s.settings.breakdown_guard != 0;
+    const int64_t len = std::max<int64_t>(s.mesh->pat.padded, 1);
+    double diffusion_fraction = 1.;
+    while (diffusion_fraction >= 0.) {  // :316-349
+        DevBuf<double> *mats[3] = {&s.a_u, &s.a_v, &s.a_w}, *rhs[3] = {&s.b_u, &s.b_v, &s.b_w}, *x[3] = {&s.u, &s.v, &s.w};
+        for (int k = 0; k < 3; ++k) {
+            hipLaunchKernelGGL(blend_k, dim3(grid_for(len)), dim3(kBlock), 0, ctx().stream, len, mats[k]->p, s.a_di.p, 1. - diffusion_fraction,
+                               diffusion_fraction, s.a_p.p);
+            ORC_HIP(hipGetLastError());
+            s.stats.cache = nullptr;
+            ORC_TRY(iterative_solve_dev(mesh_view(s, s.a_p.p), rhs[k]->p, x[k]->p, iteration_count, ORC_SOLVER_BICGSTAB, 0.5, 1e-6,
+                                        ORC_PRECOND_JACOBI, s.arena, &s.stats));
+        }
+        diffusion_fraction -= 0.2;
+    }
+    return fetch_status(s);
 }
 
 }  // namespace orc

@@ -85,6 +85,9 @@ int k_pressure_correction(SolverState &s);       // K12  discretization.rs:359-4
 int k_apply_correction(SolverState &s, double *sums_host /*5: p'^2, |dU|^2, sum u, sum v, sum w*/);  // K13 solver.rs:1170-1227
 int solver_iterate(SolverState &s, uint64_t iterations, double *report);
 int fetch_status(SolverState &s);
+int check_boundary_conditions(const OrcMesh &m);       // solver.rs:710-772: 0 PressureOnly, 1 VelocityOnly, 2 Hybrid, < 0 = -status
+int initialize_pressure_field_dev(SolverState &s);     // solver.rs:414-509
+int initialize_flow_dev(SolverState &s, uint64_t iteration_count);  // solver.rs:246-352
 
 }  // namespace orc
 

@@ -114,6 +114,7 @@ const char *orc_status_string(int st) {
     case ORC_ERR_IO: return "I/O error";
     case ORC_ERR_COMM: return "RCCL error";
     case ORC_ERR_MESH_FORMAT: return "malformed mesh or data file";                // io.rs:32-571
+    case ORC_ERR_NO_BOUNDARY_CONDITIONS: return "You must set boundary conditions."; // solver.rs:770
     case ORC_ERR_ZONE_NOT_FOUND: return "face zone should exist in mesh";          // mesh.rs:194
     default: return "unknown status";
     }

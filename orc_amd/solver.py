@@ -101,3 +101,38 @@ class Solver:
         ms = C.c_double(0.0)
         check(lib().orc_bench_bicgstab_iteration(self.ptr, C.c_int(reps), C.byref(ms)))
         return ms.value
+
+
+# ------------------------------------------------------------------ solver::initialize_* (solver.rs:246-509)
+PRESSURE_ONLY, VELOCITY_ONLY, HYBRID = 0, 1, 2
+
+
+def check_boundary_conditions(mesh):
+    """solver::check_boundary_conditions (solver.rs:710-772) -> PRESSURE_ONLY | VELOCITY_ONLY | HYBRID;
+    OrcError(ORC_ERR_NO_BOUNDARY_CONDITIONS) for "You must set boundary conditions."."""
+    kind = C.c_int(0)
+    check(lib().orc_check_boundary_conditions(mesh.ptr, C.byref(kind)))
+    return kind.value
+
+
+def initialize_pressure_field(mesh, p=None):
+    """solver::initialize_pressure_field (solver.rs:414-509); p defaults to zeros like the reference's callers."""
+    p = np.zeros(mesh.n_cells) if p is None else _f64(p).copy()
+    check(lib().orc_initialize_pressure_field(mesh.ptr, _p(p)))
+    return p
+
+
+def initialize_flow(mesh, mu, rho, iteration_count, settings=None):
+    """solver::initialize_flow (solver.rs:246-352) -> (u, v, w, p)."""
+    u, v, w, p = (np.zeros(mesh.n_cells) for _ in range(4))
+    check(lib().orc_initialize_flow(mesh.ptr, C.c_double(mu), C.c_double(rho), C.c_uint64(iteration_count),
+                                    C.byref(settings) if settings is not None else None, _p(u), _p(v), _p(w), _p(p)))
+    return u, v, w, p
+
+
+def initialize_flow_new(mesh, mu, rho, iteration_count):
+    """solver::initialize_flow_new (solver.rs:354-410), pressure-constrained arms -> (u, v, w, p)."""
+    u, v, w, p = (np.zeros(mesh.n_cells) for _ in range(4))
+    check(lib().orc_initialize_flow_new(mesh.ptr, C.c_double(mu), C.c_double(rho), C.c_uint64(iteration_count),
+                                        _p(u), _p(v), _p(w), _p(p)))
+    return u, v, w, p
