@@ -225,6 +225,9 @@ int orc_hex_channel_write_msh(const char *path, int64_t nx, int64_t ny, int64_t 
 int orc_comm_get_unique_id(unsigned char id[ORC_COMM_ID_BYTES]);          /* rank 0, then broadcast by the host launcher */
 int orc_comm_init(const unsigned char id[ORC_COMM_ID_BYTES], int rank, int world_size);
 int orc_comm_finalize(void);
+/* One-GPU self-check of the RCCL data path (single-rank communicator, rank 0 as its own neighbour): halo exchange of
+ * two fields, sum/max all-reduce, status agreement.  Needs an uninitialised communicator. */
+int orc_comm_selftest(void);
 /* Debug transport for tests where ranks share one GPU (RCCL refuses duplicate devices): halo exchange and all-reduce
  * are staged through host memory and carried by the caller's callbacks (e.g. torch.distributed/gloo).
  * exchange_fn: void(int n_peers, const int* peers, const double* send, const int64_t* send_off, const int64_t* send_cnt,

@@ -464,6 +464,8 @@ __global__ __launch_bounds__(kBlock) void correction_k(MeshDev M, const double *
     }
 }
 
+__global__ void negate_k(double *x) { if (threadIdx.x == 0 && blockIdx.x == 0) *x = -*x; }
+
 __global__ void reduce_minmax_k(const double *__restrict__ partials, int count, double *__restrict__ out) {
     // out[0] = sum(partials[0..count)), out[1] = min(partials[count..2count)), out[2] = max(partials[2count..3count))
     if (threadIdx.x != 0) return;
@@ -682,9 +684,15 @@ int k_momentum(SolverState &s, double *peclet_host) {
     hipLaunchKernelGGL(reduce_minmax_k, dim3(1), dim3(64), 0, ctx().stream, s.partials.p, g, s.scal.p + 8);
     ORC_HIP(hipGetLastError());
     if (peclet_host) {
+        if (s.mesh->halo.active()) {  // statistics over the whole mesh: sum; max of (-min, max)
+            hipLaunchKernelGGL(negate_k, dim3(1), dim3(1), 0, ctx().stream, s.scal.p + 9);
+            ORC_TRY(comm_allreduce_sum(s.scal.p + 8, 1));
+            ORC_TRY(comm_allreduce_max(s.scal.p + 9, 2));
+            hipLaunchKernelGGL(negate_k, dim3(1), dim3(1), 0, ctx().stream, s.scal.p + 9);
+        }
         ORC_HIP(hipMemcpyAsync(peclet_host, s.scal.p + 8, 3 * sizeof(double), hipMemcpyDeviceToHost, ctx().stream));
         ORC_HIP(hipStreamSynchronize(ctx().stream));
-        peclet_host[0] /= (double)s.n_own;  // discretization.rs:355 (per-rank statistics in a partitioned run)
+        peclet_host[0] /= (double)s.mesh->n_global;  // discretization.rs:355
     }
     return ORC_OK;
 }
@@ -777,6 +785,7 @@ int solver_iterate(SolverState &s, uint64_t iterations, double *report) {
         int st = 0;
         ORC_HIP(hipMemcpyAsync(&st, s.dev_status.p, sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
         ORC_HIP(hipStreamSynchronize(ctx().stream));
+        if (H.active()) st = comm_global_status(st);
         if (st) return st;
         if (std::isnan(u_avg) || std::isnan(v_avg) || std::isnan(w_avg)) return ORC_ERR_SOLUTION_DIVERGED;  // :217-221
     }

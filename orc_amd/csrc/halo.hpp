@@ -28,6 +28,9 @@ struct HaloPlan {
 
 int comm_allreduce_sum(double *dev, int n);
 int comm_allreduce_max(double *dev, int n);
+// The status word of a partitioned operation must be the same on every rank, or the ranks part ways at the next
+// collective: max over ranks of a host-side OrcStatus (no-op on a single rank).
+int comm_global_status(int status);
 void comm_set_host_transport(HostExchangeFn ex, HostAllreduceFn ar, void *user);
 
 }  // namespace orc

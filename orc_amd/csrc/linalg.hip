@@ -615,6 +615,7 @@ int iterative_solve_dev(const MatView &A_in, const double *b_in, double *x, uint
         st = ORC_ERR_UNSUPPORTED_SOLVER;  // :297
     }
     arena.release(mk);
+    if (A_in.halo) st = comm_global_status(st);  // partitioned operator: every rank leaves with the same verdict
     return st;
 }
 

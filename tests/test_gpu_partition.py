@@ -10,3 +10,10 @@ pytestmark = pytest.mark.gpu
 def test_two_ranks_match_single_rank(gpu):
     r = launch(2, "gpu", timeout=900)
     assert "MP_WORKER_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-4000:]
+
+
+def test_rccl_selftest_single_rank(gpu):
+    """The RCCL branch of HaloPlan::exchange / all-reduce / status agreement on one GPU: a single-rank communicator
+    with rank 0 as its own neighbour.  (Two real ranks need two GPUs: the driver's scaling run.)"""
+    from orc_amd._lib import check, lib
+    check(lib().orc_comm_selftest())
