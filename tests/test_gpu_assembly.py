@@ -27,7 +27,31 @@ def make(oracle, mesh_path, name):
 MESHES = ["3D_1x3", "3x3_cube", "hex6x5x4", "channel_flow"]
 
 
+_MIXED_CACHE = {}
+
+
+def mixed_mesh_file(kind):
+    """prism/hex fixture written once per session (tests/meshgen.py): "prism_hex" alternates columns, "prism_all" is all prisms"""
+    import os
+    import tempfile
+
+    import meshgen
+    if kind not in _MIXED_CACHE:
+        path = os.path.join(tempfile.mkdtemp(prefix="orc_mixed_"), kind + ".msh")
+        info = meshgen.write_mixed_channel_msh(path, 6, 4, 3, split="checker" if kind == "prism_hex" else "all")
+        _MIXED_CACHE[kind] = (path, info)
+    return _MIXED_CACHE[kind]
+
+
 def make_named(oracle, mesh_path, name):
+    if name in ("prism_hex", "prism_all"):
+        import meshgen
+        from orc_amd.mesh import Mesh, MeshArrays
+        path, info = mixed_mesh_file(name)
+        om = oracle.Mesh.read(path)
+        meshgen.mixed_channel_bcs(om.set_zone, info["zone_names"], top_wall_velocity=5e-4)
+        a = MeshArrays(om.arrays())
+        return om, Mesh(a), a
     if name == "3x3_cube_mixed":
         om = oracle.Mesh.read(mesh_path("3x3_cube"))
         H.cube_bcs_mixed(om)
@@ -37,7 +61,7 @@ def make_named(oracle, mesh_path, name):
     return make(oracle, mesh_path, name)
 
 
-@pytest.mark.parametrize("name", MESHES + ["3x3_cube_mixed"])
+@pytest.mark.parametrize("name", MESHES + ["3x3_cube_mixed", "prism_hex", "prism_all"])
 def test_pattern_diffusion_and_init_matrix(gpu, oracle, mesh_path, name):
     from orc_amd import discretization as D
     om, dm, a = make_named(oracle, mesh_path, name)
@@ -53,7 +77,7 @@ def test_pattern_diffusion_and_init_matrix(gpu, oracle, mesh_path, name):
 
 
 @pytest.mark.parametrize("q1", [1, 0])
-@pytest.mark.parametrize("name", ["3x3_cube", "hex6x5x4", "3x3_cube_mixed"])
+@pytest.mark.parametrize("name", ["3x3_cube", "hex6x5x4", "3x3_cube_mixed", "prism_hex"])
 def test_green_gauss_gradients(gpu, oracle, mesh_path, name, q1):
     from orc_amd.settings import NumericalSettings
     from orc_amd.solver import calculate_gradients
@@ -88,7 +112,7 @@ SCHEMES = [(UD, 2, 3), (CD1, 2, 3), (QUICK, 2, 3), (UMIST, 2, 3), (LUD, 0, 0), (
 
 @pytest.mark.parametrize("q1", [1, 0])
 @pytest.mark.parametrize("momentum,vinterp,pinterp", SCHEMES)
-@pytest.mark.parametrize("name", ["3x3_cube", "hex6x5x4", "3x3_cube_mixed", "channel_flow"])
+@pytest.mark.parametrize("name", ["3x3_cube", "hex6x5x4", "3x3_cube_mixed", "channel_flow", "prism_hex", "prism_all"])
 def test_momentum_and_pressure_assembly_bit_exact(gpu, oracle, mesh_path, name, momentum, vinterp, pinterp, q1):
     """build_momentum_advection_matrices + build_pressure_correction_matrices, every scheme combination,
     vs the oracle with frozen diagonals: identical bits (NaNs included, e.g. QUICK where a velocity

@@ -64,6 +64,22 @@ def test_synthetic_tgrid_round_trip(oracle, tmp_path):
     assert a["zone_names"] == g["zone_names"]
 
 
+@pytest.mark.parametrize("split", ["checker", "all", "none"])
+def test_mixed_prism_hex_mesh_matches_oracle_bitwise(oracle, tmp_path, split):
+    """Triangular + quadrilateral faces, prisms + hexahedra, skewed nodes (tests/meshgen.py)."""
+    import meshgen
+    path = str(tmp_path / "mixed.msh")
+    info = meshgen.write_mixed_channel_msh(path, 5, 4, 3, split=split, skew=0.2)
+    d = orc_io.read_mesh(path)
+    assert (d.n_cells, d.n_faces, d.n_vertices) == (info["n_cells"], info["n_faces"], info["n_nodes"])
+    a = d.arrays()
+    assert_same_mesh(a, oracle.Mesh.read(path).arrays())
+    assert a["zone_names"] == info["zone_names"]
+    out = a["face_centroid"] - a["cell_centroid"][a["face_c0"]]
+    assert np.all(np.einsum("ij,ij->i", out, a["face_normal"]) > 0)
+    assert np.isclose(a["cell_volume"].sum(), 0.002 * 0.001 * 3e-4, rtol=1e-12)
+
+
 def test_zone_lookup_and_assignment(mesh_path):
     d = orc_io.read_mesh(mesh_path("couette_flow_8x8x1"))
     names = [z[4] for z in d.zones()]
