@@ -43,9 +43,9 @@ def initial_fields(cc, dp_dx=5.0, h=1e-3, mu=1e-3, lx=0.002, seed=0x4F5243, x0=0
     return u, v, w, p
 
 
-def cpu_baseline(settings_kw, sample=(100, 40, 40), iters=2):
+def cpu_baseline(settings_kw, sample=(100, 40, 40), iters=6):
     """The CPU oracle (oracle/: single-threaded C restatement of ORC's Rust path) timed on a bounded sample of
-    the same workload: same generator, BCs, settings and initial-field recipe at 1/64 of the cells."""
+    the same workload: same generator, BCs, settings and initial-field recipe at 1/64 of the cells (about 12 s)."""
     from oracle import pyoracle as po
     from orc_amd.mesh import hex_channel, set_channel_bcs
     nx, ny, nz = sample
