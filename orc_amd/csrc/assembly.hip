@@ -13,6 +13,8 @@
 #include <algorithm>
 #include <cmath>
 
+#include <thread>
+
 #include "assembly.hpp"
 #include "linalg_kernels.hpp"
 
@@ -630,6 +632,7 @@ int solver_init(SolverState &s, OrcMesh *m, const OrcSettings *settings, double 
     s.mesh = m;
     s.settings = *settings;
     s.rho = rho; s.mu = mu; s.n = m->n_cells; s.n_own = m->n_own;
+    s.concurrent_momentum = !(getenv("ORC_CONCURRENT_MOMENTUM") && atoi(getenv("ORC_CONCURRENT_MOMENTUM")) == 0);
     ORC_TRY(validate_settings(s.settings));
     const size_t n = (size_t)s.n, pad = (size_t)std::max<int64_t>(m->pat.padded, 1), F = (size_t)m->n_faces;
     DevBuf<double> *nvec[] = {&s.u, &s.v, &s.w, &s.p, &s.p_prime, &s.b_u_di, &s.b_v_di, &s.b_w_di, &s.b_u, &s.b_v, &s.b_w, &s.b_p, &s.du, &s.dv, &s.dw};
@@ -720,7 +723,7 @@ int k_apply_correction(SolverState &s, double *sums_host) {
     return ORC_OK;
 }
 
-static int solve_field(SolverState &s, DevBuf<double> &a, DevBuf<double> &b, DevBuf<double> &x, int eq) {
+static int solve_field_on(SolverState &s, DevBuf<double> &a, DevBuf<double> &b, DevBuf<double> &x, int eq, Arena &arena, SolveStats &stats) {
     MatView A;
     A.P = s.mesh->pat.dev();
     A.val = a.p;
@@ -729,9 +732,50 @@ static int solve_field(SolverState &s, DevBuf<double> &a, DevBuf<double> &b, Dev
     A.persistent_pattern = true;
     const OrcSettings &t = s.settings;
     ctx().breakdown_guard = t.breakdown_guard != 0;
-    s.stats.cache = &s.amg_cache[eq];
+    stats.cache = &s.amg_cache[eq];
     return iterative_solve_dev(A, b.p, x.p, t.iterations, t.solver_type, t.relaxation, t.relative_convergence_threshold,
-                               t.preconditioner, s.arena, &s.stats);
+                               t.preconditioner, arena, &stats);
+}
+
+static int solve_field(SolverState &s, DevBuf<double> &a, DevBuf<double> &b, DevBuf<double> &x, int eq) {
+    return solve_field_on(s, a, b, x, eq, s.arena, s.stats);
+}
+
+SolverState::~SolverState() {
+    for (auto &l : lanes)
+        if (l.stream) (void)hipStreamDestroy(l.stream);
+}
+
+// The three momentum solves of one iteration on three streams, one host thread each (the set-up phases synchronise
+// their stream every few rounds).  Returns the first non-zero status in u, v, w order, like the sequential loop.
+static int solve_momentum_concurrently(SolverState &s) {
+    Ctx &g = ctx();
+    ORC_HIP(hipStreamSynchronize(g.stream));  // the assembled systems are complete
+    DevBuf<double> *mats[3] = {&s.a_u, &s.a_v, &s.a_w}, *rhs[3] = {&s.b_u, &s.b_v, &s.b_w}, *sol[3] = {&s.u, &s.v, &s.w};
+    int st[3] = {ORC_OK, ORC_OK, ORC_OK};
+    Ctx local[3];
+    std::thread th[3];
+    for (int k = 0; k < 3; ++k) {
+        if (!s.lanes[k].stream) ORC_HIP(hipStreamCreateWithFlags(&s.lanes[k].stream, hipStreamNonBlocking));
+        local[k] = g;
+        local[k].stream = s.lanes[k].stream;
+        local[k].last_error.clear();
+    }
+    for (int k = 0; k < 3; ++k)
+        th[k] = std::thread([&, k] {
+            CtxScope scope(&local[k]);
+            if (hipSetDevice(local[k].device) != hipSuccess) { st[k] = set_error(ORC_ERR_HIP, "hipSetDevice failed in a solve thread"); return; }
+            st[k] = solve_field_on(s, *mats[k], *rhs[k], *sol[k], k, s.lanes[k].arena, s.lanes[k].stats);
+            if (hipStreamSynchronize(local[k].stream) != hipSuccess && st[k] == ORC_OK) st[k] = set_error(ORC_ERR_HIP, "stream synchronisation failed in a solve thread");
+        });
+    for (int k = 0; k < 3; ++k) th[k].join();
+    s.stats = s.lanes[0].stats;
+    for (int k = 0; k < 3; ++k)
+        if (st[k] != ORC_OK) {
+            g.last_error = local[k].last_error;
+            return st[k];
+        }
+    return ORC_OK;
 }
 
 static void debug_field(SolverState &s, const char *name, const DevBuf<double> &f) {
@@ -759,12 +803,19 @@ int solver_iterate(SolverState &s, uint64_t iterations, double *report) {
         ORC_TRY(k_momentum(s, report ? peclet : nullptr));       // :61-82
         if (H.active()) { double *d3[3] = {s.du.p, s.dv.p, s.dw.p}; ORC_TRY(H.exchange(d3, 3)); }
         if (dbg) { debug_field(s, "b_u", s.b_u); debug_field(s, "b_v", s.b_v); debug_field(s, "b_w", s.b_w); }
-        ORC_TRY(solve_field(s, s.a_u, s.b_u, s.u, 0));              // :99-110
-        if (dbg) debug_field(s, "u", s.u);
-        ORC_TRY(solve_field(s, s.a_v, s.b_v, s.v, 1));              // :112-123
-        if (dbg) debug_field(s, "v", s.v);
-        ORC_TRY(solve_field(s, s.a_w, s.b_w, s.w, 2));              // :125-136
-        if (dbg) debug_field(s, "w", s.w);
+        const int method = s.settings.solver_type;
+        const bool lanes_ok = s.concurrent_momentum && !H.active() && !dbg && !ctx().profile &&
+                              (method == ORC_SOLVER_MULTIGRID || method == ORC_SOLVER_BICGSTAB || method == ORC_SOLVER_JACOBI);
+        if (lanes_ok) {
+            ORC_TRY(solve_momentum_concurrently(s));                    // :99-136, the three systems side by side
+        } else {
+            ORC_TRY(solve_field(s, s.a_u, s.b_u, s.u, 0));              // :99-110
+            if (dbg) debug_field(s, "u", s.u);
+            ORC_TRY(solve_field(s, s.a_v, s.b_v, s.v, 1));              // :112-123
+            if (dbg) debug_field(s, "v", s.v);
+            ORC_TRY(solve_field(s, s.a_w, s.b_w, s.w, 2));              // :125-136
+            if (dbg) debug_field(s, "w", s.w);
+        }
         if (H.active()) { double *f[3] = {s.u.p, s.v.p, s.w.p}; ORC_TRY(H.exchange(f, 3)); }
         ORC_TRY(k_pressure_correction(s));                       // :137-148
         ORC_TRY(vec_fill(s.p_prime.p, 0., s.n));                 // :167

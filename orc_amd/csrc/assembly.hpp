@@ -66,6 +66,16 @@ struct SolverState {
     Arena arena;
     SolveStats stats;
     AmgCache amg_cache[4];  // u, v, w, p' (warm start of the per-solve hierarchy set-up)
+    // The u, v and w systems of an iteration are independent (solver.rs:99-136 solves them one after the other, none
+    // reads another's result): each gets its own stream, arena and host thread, so the latency-bound set-up rounds of
+    // one hierarchy overlap the bandwidth-bound products of another.  Same kernels, same order per system: same bits.
+    struct Lane {
+        hipStream_t stream = nullptr;
+        Arena arena;
+        SolveStats stats;
+    } lanes[3];
+    bool concurrent_momentum = true;
+    ~SolverState();
     uint64_t iterations_done = 0;
 };
 

@@ -30,7 +30,13 @@ struct Ctx {
     int rank = 0, world = 1;
     void *nccl_comm = nullptr;
 };
-Ctx &ctx();
+Ctx &ctx();  // the process-wide context, or the calling thread's private copy while a CtxScope is alive
+// A worker thread that drives its own stream (concurrent momentum solves, assembly.hip) works on a private copy of
+// the context: every kernel launch, copy and error text of the code it calls goes through ctx().
+struct CtxScope {
+    explicit CtxScope(Ctx *local);
+    ~CtxScope();
+};
 
 int set_error(int code, const char *fmt, ...);
 

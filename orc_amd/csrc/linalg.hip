@@ -210,8 +210,11 @@ int spmv_dev(const MatView &A, const double *x, double *y) {
 
 int residual_dev(const MatView &A, const double *b, const double *x, double *r) {
     int g = 0;
-    static double *dummy = nullptr;
-    if (!dummy) ORC_HIP(hipMalloc((void **)&dummy, sizeof(double) * kMaxPartials));
+    static double *const dummy = [] {  // thread-safe one-time allocation (concurrent solves)
+        double *p = nullptr;
+        return hipMalloc((void **)&p, sizeof(double) * kMaxPartials) == hipSuccess ? p : nullptr;
+    }();
+    if (!dummy) return set_error(ORC_ERR_HIP, "hipMalloc of the residual scratch failed");
     return launch_spmv(A, x, EpiResidual{b, r, nullptr}, dummy, &g);
 }
 

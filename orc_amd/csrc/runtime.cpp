@@ -6,10 +6,15 @@
 
 namespace orc {
 
+static thread_local Ctx *t_ctx_override = nullptr;
+
 Ctx &ctx() {
     static Ctx c;
-    return c;
+    return t_ctx_override ? *t_ctx_override : c;
 }
+
+CtxScope::CtxScope(Ctx *local) { t_ctx_override = local; }
+CtxScope::~CtxScope() { t_ctx_override = nullptr; }
 
 int set_error(int code, const char *fmt, ...) {
     char buf[1024];
