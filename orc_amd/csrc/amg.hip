@@ -813,12 +813,44 @@ struct MgParams {
     double relaxation, threshold;
 };
 
+// Runs the enclosed calls on the solve-side stream (see SolveSide) by making it the context's current stream.
+struct StreamSwitch {
+    hipStream_t saved;
+    bool on;
+    StreamSwitch(SolveSide *side) : saved(ctx().stream), on(side != nullptr) { if (on) ctx().stream = side->stream; }
+    ~StreamSwitch() { if (on) ctx().stream = saved; }
+};
+// B waits for what A has queued so far / A waits for what B has queued so far
+static int side_wait_setup(SolveSide *side, hipStream_t setup_stream) {
+    if (!side) return ORC_OK;
+    ORC_HIP(hipEventRecord(side->ev_setup, setup_stream));
+    ORC_HIP(hipStreamWaitEvent(side->stream, side->ev_setup, 0));
+    return ORC_OK;
+}
+static int setup_wait_side(SolveSide *side, hipStream_t setup_stream) {
+    if (!side) return ORC_OK;
+    ORC_HIP(hipEventRecord(side->ev_solve, side->stream));
+    ORC_HIP(hipStreamWaitEvent(setup_stream, side->ev_solve, 0));
+    return ORC_OK;
+}
+
 // linear_algebra.rs:66-141.  `add_to`: the fine vector the prolonged correction is added to.
+// With a SolveSide the vector work of a level (restriction, smoothing solves, residual check, prolongation) is queued
+// on the side stream in exactly the order below, and the recursion's set-up overlaps this level's smoothing.
 static int multigrid_solve_dev(const MatView &A, const double *r, uint64_t level, const MgParams &mp, double threshold, Arena &arena,
-                               SolveStats *stats, int *dev_status, double *out, double *add_to) {
+                               SolveStats *stats, int *dev_status, double *out, double *add_to, SolveSide *side) {
     const int64_t n = A.P.n;
     hipStream_t st = ctx().stream;
+    Arena &varena = side ? *side->arena : arena;  // vectors and solver work space
     Arena::Mark mk = arena.mark();
+    Arena::Mark vmk = varena.mark();
+    auto leave = [&](int code) {
+        // what the side stream still reads (choice, chooser, the coarse matrix) must outlive it
+        if (side) (void)setup_wait_side(side, st);
+        if (side) varena.release(vmk);
+        arena.release(mk);
+        return code;
+    };
     int *choice, *chooser;
     ORC_TRY(arena.alloc((size_t)std::max<int64_t>(n, 1), &choice));
     ORC_TRY(arena.alloc((size_t)std::max<int64_t>(n, 1), &chooser));
@@ -840,34 +872,42 @@ static int multigrid_solve_dev(const MatView &A, const double *r, uint64_t level
         stats->amg_nnz[level] = L.padded;
         stats->amg_rounds[level] = L.rounds;
     }
-    double *r_prime, *e_prime, *partials, *scal;
-    ORC_TRY(arena.alloc((size_t)std::max<int64_t>(nc, 1), &r_prime));
-    ORC_TRY(arena.alloc((size_t)std::max<int64_t>(nc, 1), &e_prime));
-    ORC_TRY(arena.alloc((size_t)kMaxPartials, &partials));
-    ORC_TRY(arena.alloc((size_t)4, &scal));
-    hipLaunchKernelGGL(restrict_k, dim3(grid_for(nc)), dim3(kBlock), 0, st, choice, n, nc, r, r_prime);  // :82
-    ORC_HIP(hipGetLastError());
-    ORC_TRY(vec_fill(e_prime, 0., nc));  // :86
+    ORC_TRY(side_wait_setup(side, st));  // the coarse matrix and the pairing are complete
     MatView Ac;
     Ac.P = L.P;
     Ac.val = L.val;
     Ac.symmetric = A.symmetric;  // halo stays null: coarse levels are solved per rank
-    int stt = iterative_solve_dev(Ac, r_prime, e_prime, mp.iters, mp.smoother, mp.relaxation, threshold, mp.preconditioner, arena, stats);  // :87-96
-    if (stt != ORC_OK) { arena.release(mk); return stt; }
-    // :97-105  |r' - a' e'| is NaN -> "Multigrid diverged"
-    ORC_TRY(residual_norm2_dev(Ac, r_prime, e_prime, partials, scal));
-    hipLaunchKernelGGL(nan_to_status_k, dim3(1), dim3(64), 0, st, scal, dev_status, (int)ORC_ERR_MULTIGRID_DIVERGED);
-    if (level < mp.max_levels && nc > 16) {  // :109
-        // :110-121 — the recursion receives r', not the residual
-        stt = multigrid_solve_dev(Ac, r_prime, level + 1, mp, threshold, arena, stats, dev_status, nullptr, e_prime);
-        if (stt != ORC_OK) { arena.release(mk); return stt; }
-        stt = iterative_solve_dev(Ac, r_prime, e_prime, mp.iters, mp.smoother, mp.relaxation, threshold / 10., mp.preconditioner, arena, stats);  // :123-132
-        if (stt != ORC_OK) { arena.release(mk); return stt; }
+    double *r_prime, *e_prime, *partials, *scal;
+    {
+        StreamSwitch sw(side);
+        hipStream_t vs = ctx().stream;
+        ORC_TRY(varena.alloc((size_t)std::max<int64_t>(nc, 1), &r_prime));
+        ORC_TRY(varena.alloc((size_t)std::max<int64_t>(nc, 1), &e_prime));
+        ORC_TRY(varena.alloc((size_t)kMaxPartials, &partials));
+        ORC_TRY(varena.alloc((size_t)4, &scal));
+        hipLaunchKernelGGL(restrict_k, dim3(grid_for(nc)), dim3(kBlock), 0, vs, choice, n, nc, r, r_prime);  // :82
+        ORC_HIP(hipGetLastError());
+        ORC_TRY(vec_fill(e_prime, 0., nc));  // :86
+        int stt = iterative_solve_dev(Ac, r_prime, e_prime, mp.iters, mp.smoother, mp.relaxation, threshold, mp.preconditioner, varena, stats);  // :87-96
+        if (stt != ORC_OK) return leave(stt);
+        // :97-105  |r' - a' e'| is NaN -> "Multigrid diverged"
+        ORC_TRY(residual_norm2_dev(Ac, r_prime, e_prime, partials, scal));
+        hipLaunchKernelGGL(nan_to_status_k, dim3(1), dim3(64), 0, vs, scal, dev_status, (int)ORC_ERR_MULTIGRID_DIVERGED);
     }
-    hipLaunchKernelGGL(prolong_k, dim3(grid_for(n)), dim3(kBlock), 0, st, choice, chooser, n, e_prime, out, add_to);  // :140
-    ORC_HIP(hipGetLastError());
-    arena.release(mk);
-    return ORC_OK;
+    if (level < mp.max_levels && nc > 16) {  // :109
+        // :110-121 — the recursion receives r', not the residual; its set-up runs beside the smoothing above
+        int stt = multigrid_solve_dev(Ac, r_prime, level + 1, mp, threshold, arena, stats, dev_status, nullptr, e_prime, side);
+        if (stt != ORC_OK) return leave(stt);
+        StreamSwitch sw(side);
+        stt = iterative_solve_dev(Ac, r_prime, e_prime, mp.iters, mp.smoother, mp.relaxation, threshold / 10., mp.preconditioner, varena, stats);  // :123-132
+        if (stt != ORC_OK) return leave(stt);
+    }
+    {
+        StreamSwitch sw(side);
+        hipLaunchKernelGGL(prolong_k, dim3(grid_for(n)), dim3(kBlock), 0, ctx().stream, choice, chooser, n, e_prime, out, add_to);  // :140
+        ORC_HIP(hipGetLastError());
+    }
+    return leave(ORC_OK);
 }
 
 // Multigrid arm of iterative_solve (:270-296); A and b are already the preconditioned system.
@@ -876,26 +916,43 @@ int multigrid_arm_dev(const MatView &A, const double *b, double *x, uint64_t ite
     const int64_t n = A.P.n;
     if (n == 0) return ORC_OK;
     hipStream_t st = ctx().stream;
+    // two streams only where no host-synchronised smoother (colouring) is involved; on a partitioned operator the
+    // level-0 work (halo exchanges, all-reduces) stays on the library stream — every RCCL call keeps its stream — and
+    // only the rank-local coarse levels use the side stream
+    SolveSide *side = (stats && stats->side && stats->side->stream && smoother == ORC_SOLVER_BICGSTAB) ? stats->side : nullptr;
+    SolveSide *side0 = A.halo ? nullptr : side;
+    Arena &varena = side0 ? *side0->arena : arena;
     Arena::Mark mk = arena.mark();
-    // :273-282 — the smoother is called with the same preconditioner: the scaled system is scaled again (Q4)
-    int stt = iterative_solve_dev(A, b, x, iteration_count, smoother, relaxation_factor, convergence_threshold, preconditioner, arena, stats);
-    if (stt != ORC_OK) { arena.release(mk); return stt; }
+    Arena::Mark vmk = varena.mark();
+    auto leave = [&](int code) {
+        if (side) (void)setup_wait_side(side, st);
+        if (side0) varena.release(vmk);
+        arena.release(mk);
+        return code;
+    };
+    ORC_TRY(side_wait_setup(side0, st));  // the preconditioned system (scaling vectors, b) was prepared on the set-up stream
     double *r;
     int *dev_status;
-    ORC_TRY(arena.alloc((size_t)n, &r));
-    ORC_TRY(arena.alloc((size_t)1, &dev_status));
-    ORC_HIP(hipMemsetAsync(dev_status, 0, sizeof(int), st));
-    ORC_TRY(residual_dev(A, b, x, r));  // :283
+    {
+        StreamSwitch sw(side0);
+        // :273-282 — the smoother is called with the same preconditioner: the scaled system is scaled again (Q4)
+        int stt = iterative_solve_dev(A, b, x, iteration_count, smoother, relaxation_factor, convergence_threshold, preconditioner, varena, stats);
+        if (stt != ORC_OK) return leave(stt);
+        ORC_TRY(varena.alloc((size_t)n, &r));
+        ORC_TRY(varena.alloc((size_t)1, &dev_status));
+        ORC_HIP(hipMemsetAsync(dev_status, 0, sizeof(int), ctx().stream));
+        ORC_TRY(residual_dev(A, b, x, r));  // :283
+    }
     MgParams mp{3 /* MULTIGRID_COARSENING_LEVELS, :10 */, iteration_count, smoother, preconditioner, relaxation_factor, convergence_threshold};
-    stt = multigrid_solve_dev(A, r, 1, mp, convergence_threshold, arena, stats, dev_status, nullptr, x);  // :284-295
+    int stt = multigrid_solve_dev(A, r, 1, mp, convergence_threshold, arena, stats, dev_status, nullptr, x, side);  // :284-295
     if (stt == ORC_OK) {
+        ORC_TRY(setup_wait_side(side, st));
         int h = 0;
         ORC_HIP(hipMemcpyAsync(&h, dev_status, sizeof(int), hipMemcpyDeviceToHost, st));
         ORC_HIP(hipStreamSynchronize(st));
         stt = h;
     }
-    arena.release(mk);
-    return stt;
+    return leave(stt);
 }
 
 }  // namespace orc

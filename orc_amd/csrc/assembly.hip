@@ -633,6 +633,7 @@ int solver_init(SolverState &s, OrcMesh *m, const OrcSettings *settings, double 
     s.settings = *settings;
     s.rho = rho; s.mu = mu; s.n = m->n_cells; s.n_own = m->n_own;
     s.concurrent_momentum = !(getenv("ORC_CONCURRENT_MOMENTUM") && atoi(getenv("ORC_CONCURRENT_MOMENTUM")) == 0);
+    s.two_stream_multigrid = !(getenv("ORC_TWO_STREAM_MULTIGRID") && atoi(getenv("ORC_TWO_STREAM_MULTIGRID")) == 0);
     ORC_TRY(validate_settings(s.settings));
     const size_t n = (size_t)s.n, pad = (size_t)std::max<int64_t>(m->pat.padded, 1), F = (size_t)m->n_faces;
     DevBuf<double> *nvec[] = {&s.u, &s.v, &s.w, &s.p, &s.p_prime, &s.b_u_di, &s.b_v_di, &s.b_w_di, &s.b_u, &s.b_v, &s.b_w, &s.b_p, &s.du, &s.dv, &s.dw};
@@ -723,7 +724,8 @@ int k_apply_correction(SolverState &s, double *sums_host) {
     return ORC_OK;
 }
 
-static int solve_field_on(SolverState &s, DevBuf<double> &a, DevBuf<double> &b, DevBuf<double> &x, int eq, Arena &arena, SolveStats &stats) {
+static int solve_field_on(SolverState &s, DevBuf<double> &a, DevBuf<double> &b, DevBuf<double> &x, int eq, Arena &arena, SolveStats &stats,
+                          SolveSide *side, Arena *side_arena) {
     MatView A;
     A.P = s.mesh->pat.dev();
     A.val = a.p;
@@ -733,17 +735,37 @@ static int solve_field_on(SolverState &s, DevBuf<double> &a, DevBuf<double> &b, 
     const OrcSettings &t = s.settings;
     ctx().breakdown_guard = t.breakdown_guard != 0;
     stats.cache = &s.amg_cache[eq];
+    stats.side = nullptr;
+    if (side && s.two_stream_multigrid && t.solver_type == ORC_SOLVER_MULTIGRID) {
+        if (!side->stream) {
+            ORC_HIP(hipStreamCreateWithFlags(&side->stream, hipStreamNonBlocking));
+            ORC_HIP(hipEventCreateWithFlags(&side->ev_setup, hipEventDisableTiming));
+            ORC_HIP(hipEventCreateWithFlags(&side->ev_solve, hipEventDisableTiming));
+            side->arena = side_arena;
+        }
+        stats.side = side;
+    }
     return iterative_solve_dev(A, b.p, x.p, t.iterations, t.solver_type, t.relaxation, t.relative_convergence_threshold,
                                t.preconditioner, arena, &stats);
 }
 
 static int solve_field(SolverState &s, DevBuf<double> &a, DevBuf<double> &b, DevBuf<double> &x, int eq) {
-    return solve_field_on(s, a, b, x, eq, s.arena, s.stats);
+    return solve_field_on(s, a, b, x, eq, s.arena, s.stats, &s.side, &s.side_arena);
+}
+
+static void destroy_side(SolveSide &d) {
+    if (d.stream) (void)hipStreamDestroy(d.stream);
+    if (d.ev_setup) (void)hipEventDestroy(d.ev_setup);
+    if (d.ev_solve) (void)hipEventDestroy(d.ev_solve);
+    d = SolveSide();
 }
 
 SolverState::~SolverState() {
-    for (auto &l : lanes)
+    for (auto &l : lanes) {
         if (l.stream) (void)hipStreamDestroy(l.stream);
+        destroy_side(l.side);
+    }
+    destroy_side(side);
 }
 
 // The three momentum solves of one iteration on three streams, one host thread each (the set-up phases synchronise
@@ -765,7 +787,7 @@ static int solve_momentum_concurrently(SolverState &s) {
         th[k] = std::thread([&, k] {
             CtxScope scope(&local[k]);
             if (hipSetDevice(local[k].device) != hipSuccess) { st[k] = set_error(ORC_ERR_HIP, "hipSetDevice failed in a solve thread"); return; }
-            st[k] = solve_field_on(s, *mats[k], *rhs[k], *sol[k], k, s.lanes[k].arena, s.lanes[k].stats);
+            st[k] = solve_field_on(s, *mats[k], *rhs[k], *sol[k], k, s.lanes[k].arena, s.lanes[k].stats, &s.lanes[k].side, &s.lanes[k].side_arena);
             if (hipStreamSynchronize(local[k].stream) != hipSuccess && st[k] == ORC_OK) st[k] = set_error(ORC_ERR_HIP, "stream synchronisation failed in a solve thread");
         });
     for (int k = 0; k < 3; ++k) th[k].join();

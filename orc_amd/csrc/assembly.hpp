@@ -73,7 +73,12 @@ struct SolverState {
         hipStream_t stream = nullptr;
         Arena arena;
         SolveStats stats;
+        SolveSide side;   // second stream of the lane's Multigrid solves (set-up beside smoothing, linalg.hpp)
+        Arena side_arena;
     } lanes[3];
+    SolveSide side;       // the same for the solves on the library stream (p', or all four when the lanes are off)
+    Arena side_arena;
+    bool two_stream_multigrid = true;
     bool concurrent_momentum = true;
     ~SolverState();
     uint64_t iterations_done = 0;

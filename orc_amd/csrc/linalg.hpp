@@ -62,8 +62,19 @@ struct AmgCache {
     int64_t size[8] = {0};
 };
 
+// Optional second stream of a solve (Multigrid arm): the hierarchy set-up of level l+1 — host-synchronised rounds,
+// latency-bound — needs only the level-l matrix, while the smoothing solve of level l — 100 products, bandwidth-bound,
+// no host interaction — needs the matrix and the restricted residual.  Set-up work stays on ctx().stream, everything
+// that touches vectors goes to `stream` with its temporaries in `arena`; two events order the hand-overs.
+struct SolveSide {
+    hipStream_t stream = nullptr;
+    Arena *arena = nullptr;
+    hipEvent_t ev_setup = nullptr, ev_solve = nullptr;
+};
+
 struct SolveStats {
     AmgCache *cache = nullptr;  // optional, owned by the caller (one per equation)
+    SolveSide *side = nullptr;  // optional, owned by the caller
     int64_t jacobi_sweeps = 0;
     int amg_levels = 0;
     int64_t amg_rows[8] = {0};
