@@ -336,8 +336,8 @@ __global__ void vec_add_k(double *__restrict__ x, const double *__restrict__ y, 
 //   3. the first lane of every run adds it up sequentially       -> T = (R A)[I,:], sorted by j,
 //   4. expand T through R^T into (J, T_j * R^T_jJ) in j order, sort by (J << 32 | sequence), add runs.
 // Every sum therefore associates exactly like nalgebra-sparse's spmm_csr (c += a_ik * b_kj, k in
-// row order), which keeps the coarse operators bit-identical to the CPU oracle.  Rows whose
-// candidate count exceeds the launch's LDS capacity go to an overflow list for a wider launch.
+// row order), which keeps the coarse operators bit-identical to the CPU oracle.  galerkin_bound_k sorts the
+// rows into LDS tiers (list capacity 128 << t) by their candidate bound, one launch per non-empty tier.
 // Output goes to a scratch area through an atomic bump allocator; a second kernel packs it into
 // SELL-64 once the slice widths are known (single pass: no symbolic/numeric duplication).
 __device__ __forceinline__ void bitonic_sort_wave(unsigned long long *__restrict__ key, double *__restrict__ val, int P) {
@@ -532,9 +532,10 @@ __global__ void galerkin_pack_k(SellDev Pc, const long long *__restrict__ slice_
 // Per coarse row: candidate count c = sum of the lengths of its (<= 4) fine rows.  2c bounds the row's coarse
 // entries (every candidate spawns <= 2 products), so the scratch offset of row I is the exclusive prefix sum of 2c:
 // computed here per 64-row slice (wave scan) + slice totals, finished by scan_i64_k.  No allocator atomics.
+constexpr int kGalerkinTiers = 7;  // LDS list capacities 64 << t, t = 0..6 (2 KB .. 128 KB per wavefront)
 __global__ __launch_bounds__(64) void galerkin_bound_k(SellDev P, const int *__restrict__ choice, int64_t n_coarse, int *__restrict__ out_max,
                                                        unsigned long long *__restrict__ out_sum, int *__restrict__ intra_off,
-                                                       long long *__restrict__ slice_tot) {
+                                                       long long *__restrict__ slice_tot, int *__restrict__ tier_count, int *__restrict__ tier_list) {
     const int lane = threadIdx.x;
     const int64_t n_slices = (n_coarse + 63) / 64;
     int mx = 0;
@@ -552,6 +553,20 @@ __global__ __launch_bounds__(64) void galerkin_bound_k(SellDev P, const int *__r
         if (lane == 0) slice_tot[s] = tot;
         mx = max(mx, c);
         sm += (unsigned long long)c;
+        // the row's list never exceeds 2c entries: it goes to the narrowest tier that holds them (no overflow passes)
+        int tier = -1;
+        if (I < n_coarse) {
+            tier = 1;  // 128 slots (4 KB) is the smallest list: 16 wavefronts per CU already saturate the narrow rows
+            while (tier < kGalerkinTiers - 1 && (64 << tier) < 2 * c) ++tier;
+        }
+        for (int t = 0; t < kGalerkinTiers; ++t) {
+            const unsigned long long m = __ballot(tier == t);
+            if (m == 0ull) continue;
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&tier_count[t], __popcll(m));
+            base = __shfl(base, 0, 64);
+            if (tier == t) tier_list[(int64_t)t * n_coarse + base + __popcll(m & ((1ull << lane) - 1ull))] = (int)I;
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -725,7 +740,7 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
 static int galerkin(const MatView &A, const int *choice, const int *chooser, Arena &arena, CoarseLevel &L) {
     const int64_t n = A.P.n, nc = n / 2 + n % 2;  // :13
     hipStream_t st = ctx().stream;
-    int *row_len, *diag, *flags, *ovf_a, *ovf_b, *intra_off;  // flags[0] = max candidates, [1] = overflow, [2],[3] = overflow-list counts
+    int *row_len, *diag, *flags, *intra_off;  // flags[0] = max candidates, [1] = overflow (cannot happen: rows are pre-sorted into tiers)
     long long *slice_tot, *slice_base;
     unsigned long long *counters;  // [1] = sum of candidates
     int64_t *slice_ptr;
@@ -733,8 +748,6 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
     const size_t ncs = (size_t)std::max<int64_t>(nc, 1);
     ORC_TRY(arena.alloc(ncs, &row_len));
     ORC_TRY(arena.alloc(ncs, &diag));
-    ORC_TRY(arena.alloc(ncs, &ovf_a));
-    ORC_TRY(arena.alloc(ncs, &ovf_b));
     ORC_TRY(arena.alloc(ncs, &intra_off));
     ORC_TRY(arena.alloc((size_t)n_slices + 1, &slice_tot));
     ORC_TRY(arena.alloc((size_t)n_slices + 1, &slice_base));
@@ -743,13 +756,19 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
     ORC_TRY(arena.alloc((size_t)2, &counters));
     ORC_HIP(hipMemsetAsync(flags, 0, 4 * sizeof(int), st));
     ORC_HIP(hipMemsetAsync(counters, 0, 2 * sizeof(unsigned long long), st));
+    int *tier_count, *tier_list;
+    ORC_TRY(arena.alloc((size_t)kGalerkinTiers + 1, &tier_count));
+    ORC_TRY(arena.alloc((size_t)kGalerkinTiers * ncs, &tier_list));
+    ORC_HIP(hipMemsetAsync(tier_count, 0, (kGalerkinTiers + 1) * sizeof(int), st));
     hipLaunchKernelGGL(galerkin_bound_k, dim3((unsigned)std::min<int64_t>(n_slices, 8192)), dim3(64), 0, st, A.P, choice, nc, flags, counters + 1, intra_off,
-                       slice_tot);
+                       slice_tot, tier_count, tier_list);
     hipLaunchKernelGGL(scan_i64_k, dim3(1), dim3(1024), 0, st, slice_tot, (int64_t)n_slices, slice_base);
     int hflags[4];
     unsigned long long hcount[2];
     ORC_HIP(hipMemcpyAsync(hflags, flags, sizeof(hflags), hipMemcpyDeviceToHost, st));
+    int htier[kGalerkinTiers];
     ORC_HIP(hipMemcpyAsync(hcount, counters, sizeof(hcount), hipMemcpyDeviceToHost, st));
+    ORC_HIP(hipMemcpyAsync(htier, tier_count, sizeof(htier), hipMemcpyDeviceToHost, st));
     ORC_HIP(hipStreamSynchronize(st));
     const int max_cand = std::max(hflags[0], 1);
     const long long scratch_cap = (long long)std::max<unsigned long long>(2ull * hcount[1], 64ull);
@@ -762,30 +781,16 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&galerkin_wave_k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    // LDS tiers (32 B per list slot): 128 slots for the typical row, a middle tier around twice the mean candidate
-    // count, and the bound for the longest row; a row that does not fit a tier is queued for the next one.
-    int cap_wide = 64;
-    while (cap_wide < 2 * max_cand) cap_wide <<= 1;
-    if ((size_t)cap_wide * 32 > (size_t)150 * 1024) return set_error(ORC_ERR_BAD_ARGUMENT, "Galerkin row too long for LDS (%d candidates)", max_cand);
-    const double mean_cand = (double)hcount[1] / (double)std::max<int64_t>(nc, 1);
-    int cap_mid = 128;
-    while (cap_mid < 2.5 * 2.0 * mean_cand) cap_mid <<= 1;
-    int tiers[3];
-    int n_tiers = 0;
-    tiers[n_tiers++] = std::min(128, cap_wide);
-    if (cap_mid > tiers[n_tiers - 1] && cap_mid < cap_wide) tiers[n_tiers++] = cap_mid;
-    if (cap_wide > tiers[n_tiers - 1]) tiers[n_tiers++] = cap_wide;
-    const int *in_list = nullptr, *in_count = nullptr;
-    int *lists[2] = {ovf_a, ovf_b};
-    for (int t = 0; t < n_tiers; ++t) {
-        const bool last = t == n_tiers - 1;
-        const size_t smem = (size_t)tiers[t] * 32;
+    // LDS tiers (32 B per list slot): every row was assigned to the narrowest list that is guaranteed to hold it
+    if ((size_t)2 * max_cand > (size_t)(64 << (kGalerkinTiers - 1))) return set_error(ORC_ERR_BAD_ARGUMENT, "Galerkin row too long for LDS (%d candidates)", max_cand);
+    for (int t = 0; t < kGalerkinTiers; ++t) {
+        if (htier[t] == 0) continue;
+        const int cap = 64 << t;
+        const size_t smem = (size_t)cap * 32;
         const int waves_per_cu = (int)std::max<size_t>(1, std::min<size_t>(16, (size_t)(150 * 1024) / smem));
-        const int g = (int)std::min<int64_t>(nc, (int64_t)256 * waves_per_cu);
-        hipLaunchKernelGGL(galerkin_wave_k, dim3(g), dim3(64), smem, st, A, choice, chooser, nc, tiers[t], row_len, slice_base, intra_off, s_col, s_val,
-                           flags + 1, in_list, in_count, last ? nullptr : lists[t & 1], last ? nullptr : flags + 2 + (t & 1));
-        in_list = lists[t & 1];
-        in_count = flags + 2 + (t & 1);
+        const int g = (int)std::min<int64_t>(htier[t], (int64_t)256 * waves_per_cu);
+        hipLaunchKernelGGL(galerkin_wave_k, dim3(g), dim3(64), smem, st, A, choice, chooser, nc, cap, row_len, slice_base, intra_off, s_col, s_val,
+                           flags + 1, (const int *)(tier_list + (int64_t)t * nc), (const int *)(tier_count + t), (int *)nullptr, (int *)nullptr);
     }
     hipLaunchKernelGGL(slice_ptr_k, dim3(1), dim3(1024), 0, st, row_len, nc, n_slices, slice_ptr);
     ORC_HIP(hipGetLastError());
