@@ -857,19 +857,27 @@ static int multigrid_solve_dev(const MatView &A, const double *r, uint64_t level
         return code;
     };
     int *choice, *chooser;
-    ORC_TRY(arena.alloc((size_t)std::max<int64_t>(n, 1), &choice));
-    ORC_TRY(arena.alloc((size_t)std::max<int64_t>(n, 1), &chooser));
     CoarseLevel L;
-    AmgCache *cache = stats ? stats->cache : nullptr;
-    const int *warm = nullptr;
-    static const bool warm_enabled = getenv("ORC_AMG_WARM") != nullptr && atoi(getenv("ORC_AMG_WARM")) != 0;
-    if (warm_enabled && cache && level < 8 && cache->size[level] == n) warm = cache->choice[level].p;
-    ORC_TRY(aggregate(A, arena, choice, chooser, &L.rounds, warm));  // :80 (scratch is released with the level)
-    if (cache && level < 8) {
-        if (cache->size[level] != n) { ORC_TRY(cache->choice[level].alloc((size_t)std::max<int64_t>(n, 1))); cache->size[level] = n; }
-        ORC_HIP(hipMemcpyAsync(cache->choice[level].p, choice, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, st));
+    const AmgHierarchy *hier = stats ? stats->hierarchy : nullptr;
+    if (hier && (int)level <= hier->n_levels && (level == 1 ? hier->n_fine : hier->level[level - 2].n) == n) {
+        // :80, :84 were done ahead of time (multigrid_prepare_dev) for exactly this matrix
+        const AmgHierarchy::Level &h = hier->level[level - 1];
+        choice = h.choice; chooser = h.chooser;
+        L.P = h.P; L.val = h.val; L.n = h.n; L.padded = h.padded; L.rounds = h.rounds;
+    } else {
+        ORC_TRY(arena.alloc((size_t)std::max<int64_t>(n, 1), &choice));
+        ORC_TRY(arena.alloc((size_t)std::max<int64_t>(n, 1), &chooser));
+        AmgCache *cache = stats ? stats->cache : nullptr;
+        const int *warm = nullptr;
+        static const bool warm_enabled = getenv("ORC_AMG_WARM") != nullptr && atoi(getenv("ORC_AMG_WARM")) != 0;
+        if (warm_enabled && cache && level < 8 && cache->size[level] == n) warm = cache->choice[level].p;
+        ORC_TRY(aggregate(A, arena, choice, chooser, &L.rounds, warm));  // :80 (scratch is released with the level)
+        if (cache && level < 8) {
+            if (cache->size[level] != n) { ORC_TRY(cache->choice[level].alloc((size_t)std::max<int64_t>(n, 1))); cache->size[level] = n; }
+            ORC_HIP(hipMemcpyAsync(cache->choice[level].p, choice, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, st));
+        }
+        ORC_TRY(galerkin(A, choice, chooser, arena, L));  // :84
     }
-    ORC_TRY(galerkin(A, choice, chooser, arena, L));  // :84
     const int64_t nc = L.n;
     if (stats && level < 8) {
         stats->amg_levels = std::max(stats->amg_levels, (int)level);
@@ -915,6 +923,45 @@ static int multigrid_solve_dev(const MatView &A, const double *r, uint64_t level
     return leave(ORC_OK);
 }
 
+// The set-up half of the Multigrid arm on its own: levels 1..3 of the hierarchy for `A_in` seen through the arm's
+// preconditioner (linear_algebra.rs:159-166 then :80, :84 per level, recursion rule of :109).
+int multigrid_prepare_dev(const MatView &A_in, int preconditioner, Arena &arena, AmgHierarchy &H) {
+    H = AmgHierarchy();
+    const int64_t n = A_in.P.n;
+    H.n_fine = n;
+    if (n == 0) return ORC_OK;
+    MatView views[4];
+    views[0] = A_in;
+    if (preconditioner == ORC_PRECOND_JACOBI) {
+        double *dinv;
+        ORC_TRY(arena.alloc((size_t)n, &dinv));
+        ORC_TRY(diag_inverse_dev(A_in, dinv));
+        if (!views[0].s1) views[0].s1 = dinv;
+        else if (!views[0].s2) views[0].s2 = dinv;
+        else return set_error(ORC_ERR_BAD_ARGUMENT, "more than two nested Jacobi scalings");
+    }
+    const uint64_t max_levels = 3;  // MULTIGRID_COARSENING_LEVELS, :10
+    for (uint64_t level = 1; level <= max_levels; ++level) {
+        const MatView &A = views[level - 1];
+        const int64_t nf = A.P.n;
+        AmgHierarchy::Level &h = H.level[level - 1];
+        ORC_TRY(arena.alloc((size_t)std::max<int64_t>(nf, 1), &h.choice));
+        ORC_TRY(arena.alloc((size_t)std::max<int64_t>(nf, 1), &h.chooser));
+        CoarseLevel L;
+        ORC_TRY(aggregate(A, arena, h.choice, h.chooser, &L.rounds));
+        ORC_TRY(galerkin(A, h.choice, h.chooser, arena, L));
+        h.P = L.P; h.val = L.val; h.n = L.n; h.padded = L.padded; h.rounds = L.rounds;
+        H.n_levels = (int)level;
+        if (!(level < max_levels && L.n > 16)) break;  // :109
+        MatView Ac;
+        Ac.P = L.P;
+        Ac.val = L.val;
+        Ac.symmetric = A.symmetric;
+        views[level] = Ac;
+    }
+    return ORC_OK;
+}
+
 // Multigrid arm of iterative_solve (:270-296); A and b are already the preconditioned system.
 int multigrid_arm_dev(const MatView &A, const double *b, double *x, uint64_t iteration_count, double relaxation_factor,
                       double convergence_threshold, int preconditioner, Arena &arena, SolveStats *stats, int smoother) {
@@ -924,7 +971,7 @@ int multigrid_arm_dev(const MatView &A, const double *b, double *x, uint64_t ite
     // two streams only where no host-synchronised smoother (colouring) is involved; on a partitioned operator the
     // level-0 work (halo exchanges, all-reduces) stays on the library stream — every RCCL call keeps its stream — and
     // only the rank-local coarse levels use the side stream
-    SolveSide *side = (stats && stats->side && stats->side->stream && smoother == ORC_SOLVER_BICGSTAB) ? stats->side : nullptr;
+    SolveSide *side = (stats && stats->side && stats->side->stream && smoother == ORC_SOLVER_BICGSTAB && !stats->hierarchy) ? stats->side : nullptr;
     SolveSide *side0 = A.halo ? nullptr : side;
     Arena &varena = side0 ? *side0->arena : arena;
     Arena::Mark mk = arena.mark();

@@ -286,6 +286,23 @@ __global__ void face_k(MeshDev M, FaceArgs A, double *__restrict__ flux, double 
     }
 }
 
+// the coefficient half of face_k<1> alone: what the p' MATRIX needs (no velocity is read)
+__global__ void face_coef_k(MeshDev M, const double *__restrict__ du, const double *__restrict__ dv, const double *__restrict__ dw, double rho,
+                            double *__restrict__ coef) {
+    GRID_STRIDE(f, M.n_faces) {
+        const V3 n = face_normal(M, (int)f);
+        const int i = M.c0[f], j = M.c1[f];
+        const double ar = M.area[f];
+        if (j >= 0) {
+            const double a_int = 0.5 * vnorm(mk((du[i] + du[j]) * -n.x, (dv[i] + dv[j]) * -n.y, (dw[i] + dw[j]) * -n.z));
+            coef[f] = rho * (ar * ar) / a_int;
+        } else {
+            const double a_ii = vnorm(mk(du[i] * -n.x, dv[i] * -n.y, dw[i] * -n.z));
+            coef[f] = rho * (ar * ar) / a_ii;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ K11: momentum matrices
 __device__ __forceinline__ double psi_eval(int momentum, double r) {  // lib.rs:107-118
     switch (momentum) {
@@ -634,6 +651,7 @@ int solver_init(SolverState &s, OrcMesh *m, const OrcSettings *settings, double 
     s.rho = rho; s.mu = mu; s.n = m->n_cells; s.n_own = m->n_own;
     s.concurrent_momentum = !(getenv("ORC_CONCURRENT_MOMENTUM") && atoi(getenv("ORC_CONCURRENT_MOMENTUM")) == 0);
     s.two_stream_multigrid = !(getenv("ORC_TWO_STREAM_MULTIGRID") && atoi(getenv("ORC_TWO_STREAM_MULTIGRID")) == 0);
+    s.early_p_hierarchy = !(getenv("ORC_EARLY_P_HIERARCHY") && atoi(getenv("ORC_EARLY_P_HIERARCHY")) == 0);
     ORC_TRY(validate_settings(s.settings));
     const size_t n = (size_t)s.n, pad = (size_t)std::max<int64_t>(m->pat.padded, 1), F = (size_t)m->n_faces;
     DevBuf<double> *nvec[] = {&s.u, &s.v, &s.w, &s.p, &s.p_prime, &s.b_u_di, &s.b_v_di, &s.b_w_di, &s.b_u, &s.b_v, &s.b_w, &s.b_p, &s.du, &s.dv, &s.dw};
@@ -736,6 +754,7 @@ static int solve_field_on(SolverState &s, DevBuf<double> &a, DevBuf<double> &b, 
     ctx().breakdown_guard = t.breakdown_guard != 0;
     stats.cache = &s.amg_cache[eq];
     stats.side = nullptr;
+    stats.hierarchy = (eq == 3 && s.p_hierarchy.n_levels > 0) ? &s.p_hierarchy : nullptr;
     if (side && s.two_stream_multigrid && t.solver_type == ORC_SOLVER_MULTIGRID) {
         if (!side->stream) {
             ORC_HIP(hipStreamCreateWithFlags(&side->stream, hipStreamNonBlocking));
@@ -766,7 +785,55 @@ SolverState::~SolverState() {
         destroy_side(l.side);
     }
     destroy_side(side);
+    if (prep_stream) (void)hipStreamDestroy(prep_stream);
 }
+
+// Runs in a host thread of its own beside the momentum solves: the p' matrix from the fresh momentum diagonals (the
+// RHS it also writes is recomputed after the solves), then the Multigrid hierarchy for it.  No rank-to-rank traffic.
+static int prepare_p_hierarchy(SolverState &s) {
+    OrcMesh &m = *s.mesh;
+    hipStream_t st = ctx().stream;
+    hipLaunchKernelGGL(face_coef_k, dim3(grid_for(m.n_faces)), dim3(kBlock), 0, st, m.dev(), s.du.p, s.dv.p, s.dw.p, s.rho, s.coef.p);
+    hipLaunchKernelGGL(pressure_k, dim3(grid_for(s.n)), dim3(kBlock), 0, st, m.dev(), m.pat.dev(), s.flux.p, s.coef.p, s.rho, s.a_p.p, s.b_p.p);
+    ORC_HIP(hipGetLastError());
+    MatView A;
+    A.P = m.pat.dev();
+    A.val = s.a_p.p;
+    A.symmetric = m.pat.symmetric;
+    A.halo = m.halo.active() ? &m.halo : nullptr;  // level 1 pairs owned rows only; nothing is exchanged
+    A.persistent_pattern = true;
+    s.hier_arena.release(Arena::Mark{0, 0});
+    ORC_TRY(multigrid_prepare_dev(A, s.settings.preconditioner, s.hier_arena, s.p_hierarchy));
+    ORC_HIP(hipStreamSynchronize(st));
+    return ORC_OK;
+}
+
+struct PrepareThread {
+    std::thread th;
+    Ctx local;
+    int status = ORC_OK;
+    bool running = false;
+    void start(SolverState &s) {
+        Ctx &g = ctx();
+        local = g;
+        local.stream = s.prep_stream;
+        local.last_error.clear();
+        running = true;
+        th = std::thread([this, &s] {
+            CtxScope scope(&local);
+            if (hipSetDevice(local.device) != hipSuccess) { status = set_error(ORC_ERR_HIP, "hipSetDevice failed in the set-up thread"); return; }
+            status = prepare_p_hierarchy(s);
+        });
+    }
+    int join() {
+        if (!running) return ORC_OK;
+        th.join();
+        running = false;
+        if (status != ORC_OK) ctx().last_error = local.last_error;
+        return status;
+    }
+    ~PrepareThread() { if (running) th.join(); }
+};
 
 // The three momentum solves of one iteration on three streams, one host thread each (the set-up phases synchronise
 // their stream every few rounds).  Returns the first non-zero status in u, v, w order, like the sequential loop.
@@ -826,6 +893,13 @@ int solver_iterate(SolverState &s, uint64_t iterations, double *report) {
         if (H.active()) { double *d3[3] = {s.du.p, s.dv.p, s.dw.p}; ORC_TRY(H.exchange(d3, 3)); }
         if (dbg) { debug_field(s, "b_u", s.b_u); debug_field(s, "b_v", s.b_v); debug_field(s, "b_w", s.b_w); }
         const int method = s.settings.solver_type;
+        PrepareThread prep;
+        s.p_hierarchy.n_levels = 0;
+        if (s.early_p_hierarchy && method == ORC_SOLVER_MULTIGRID && !dbg && !ctx().profile) {
+            if (!s.prep_stream) ORC_HIP(hipStreamCreateWithFlags(&s.prep_stream, hipStreamNonBlocking));
+            ORC_HIP(hipStreamSynchronize(ctx().stream));  // the diagonals (and their ghosts) are in place
+            prep.start(s);
+        }
         const bool lanes_ok = s.concurrent_momentum && !H.active() && !dbg && !ctx().profile &&
                               (method == ORC_SOLVER_MULTIGRID || method == ORC_SOLVER_BICGSTAB || method == ORC_SOLVER_JACOBI);
         if (lanes_ok) {
@@ -838,8 +912,9 @@ int solver_iterate(SolverState &s, uint64_t iterations, double *report) {
             ORC_TRY(solve_field(s, s.a_w, s.b_w, s.w, 2));              // :125-136
             if (dbg) debug_field(s, "w", s.w);
         }
+        ORC_TRY(prep.join());
         if (H.active()) { double *f[3] = {s.u.p, s.v.p, s.w.p}; ORC_TRY(H.exchange(f, 3)); }
-        ORC_TRY(k_pressure_correction(s));                       // :137-148
+        ORC_TRY(k_pressure_correction(s));                       // :137-148 (the matrix comes out as in the early pass)
         ORC_TRY(vec_fill(s.p_prime.p, 0., s.n));                 // :167
         if (dbg) debug_field(s, "b_p", s.b_p);
         ORC_TRY(solve_field(s, s.a_p, s.b_p, s.p_prime, 3));        // :168-179

@@ -76,6 +76,13 @@ struct SolverState {
         SolveSide side;   // second stream of the lane's Multigrid solves (set-up beside smoothing, linalg.hpp)
         Arena side_arena;
     } lanes[3];
+    // The pressure-correction matrix depends on the momentum diagonals and the geometry only (discretization.rs:401-438;
+    // the new velocities enter its RHS), so its Multigrid hierarchy is built on a stream of its own while the momentum
+    // systems are being solved, and the p' solve finds it ready.
+    AmgHierarchy p_hierarchy;
+    Arena hier_arena;
+    hipStream_t prep_stream = nullptr;
+    bool early_p_hierarchy = true;
     SolveSide side;       // the same for the solves on the library stream (p', or all four when the lanes are off)
     Arena side_arena;
     bool two_stream_multigrid = true;

@@ -144,6 +144,12 @@ __global__ void diag_inverse_k(MatView A, double *__restrict__ dinv) {
         dinv[r] = d >= 0 ? 1. / view_value(A, r, d) : 0.;
     }
 }
+int diag_inverse_dev(const MatView &A, double *dinv) {
+    if (A.P.n == 0) return ORC_OK;
+    hipLaunchKernelGGL(diag_inverse_k, dim3(grid_for(A.P.n)), dim3(kBlock), 0, ctx().stream, A, dinv);
+    ORC_HIP(hipGetLastError());
+    return ORC_OK;
+}
 // out = 0 + s * b   (p_inv * b as a one-entry-per-row SpMV, linear_algebra.rs:165)
 __global__ void scale_vec_k(const double *__restrict__ s, const double *__restrict__ b, double *__restrict__ out, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = 0. + s[i] * b[i];

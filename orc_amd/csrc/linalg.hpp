@@ -72,9 +72,25 @@ struct SolveSide {
     hipEvent_t ev_setup = nullptr, ev_solve = nullptr;
 };
 
+// A Multigrid hierarchy built ahead of the solve that uses it (multigrid_prepare_dev): per level the pairing of the
+// finer rows and the Galerkin operator.  It is a function of the matrix values alone, so it can be built as soon as
+// they exist — for the pressure correction that is before the momentum solves, whose results only enter its RHS.
+struct AmgHierarchy {
+    struct Level {
+        int *choice = nullptr, *chooser = nullptr;  // partner of / chosen-by, per row of the finer level
+        SellDev P;                                  // coarse operator
+        double *val = nullptr;
+        int64_t n = 0, padded = 0;
+        int rounds = 0;
+    } level[4];
+    int n_levels = 0;
+    int64_t n_fine = 0;
+};
+
 struct SolveStats {
     AmgCache *cache = nullptr;  // optional, owned by the caller (one per equation)
     SolveSide *side = nullptr;  // optional, owned by the caller
+    const AmgHierarchy *hierarchy = nullptr;  // optional: a hierarchy prepared for exactly this matrix
     int64_t jacobi_sweeps = 0;
     int amg_levels = 0;
     int64_t amg_rows[8] = {0};
@@ -88,6 +104,12 @@ struct SolveStats {
 int iterative_solve_dev(const MatView &A, const double *b, double *x, uint64_t iteration_count, int method,
                         double relaxation_factor, double convergence_threshold, int preconditioner, Arena &arena,
                         SolveStats *stats);
+
+// Builds the hierarchy the Multigrid arm of iterative_solve_dev(A, ..., preconditioner) would build for itself (same
+// kernels, same results); all of its memory comes from `arena` and stays valid until the caller releases it.
+int multigrid_prepare_dev(const MatView &A, int preconditioner, Arena &arena, AmgHierarchy &H);
+// dinv[i] = 1 / A(i,i) through the view (the Jacobi preconditioner's p_inv, linear_algebra.rs:159-166)
+int diag_inverse_dev(const MatView &A, double *dinv);
 
 // y = A x (K1).  Exposed for bench/tests.
 int spmv_dev(const MatView &A, const double *x, double *y);
