@@ -258,30 +258,43 @@ struct RRow {
     double w[4];
     int n;
 };
+// Every array index below is a compile-time constant (fixed sorting network, unrolled merges), so the row lives in
+// registers; a dynamically indexed idx[]/w[] would be spilled to scratch memory.
 __device__ __forceinline__ RRow restriction_row(const int *__restrict__ choice, int64_t I, int64_t n_fine) {
-    RRow r;
-    r.n = 0;
+    constexpr int kNone = 0x7fffffff;
+    int v[4] = {kNone, kNone, kNone, kNone};
+#pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int64_t i = 2 * I + t;
-        if (i >= n_fine) break;
-        const int c = choice[i];
-        if (c < 0) continue;
-        r.idx[r.n] = (int)i; r.w[r.n] = 1.; r.n++;
-        r.idx[r.n] = c; r.w[r.n] = 1.; r.n++;
+        if (i < n_fine) {
+            const int c = choice[i];
+            if (c >= 0) { v[2 * t] = (int)i; v[2 * t + 1] = c; }
+        }
     }
-    // insertion sort (<= 4), then merge equal indices
-    for (int a = 1; a < r.n; ++a) {
-        const int key = r.idx[a];
-        int b = a - 1;
-        while (b >= 0 && r.idx[b] > key) { r.idx[b + 1] = r.idx[b]; --b; }
-        r.idx[b + 1] = key;
+    // sorting network for 4 keys (absent entries sort last)
+#define ORC_CSWAP(x, y) { const int lo__ = min(v[x], v[y]), hi__ = max(v[x], v[y]); v[x] = lo__; v[y] = hi__; }
+    ORC_CSWAP(0, 1) ORC_CSWAP(2, 3) ORC_CSWAP(0, 2) ORC_CSWAP(1, 3) ORC_CSWAP(1, 2)
+#undef ORC_CSWAP
+    // merge equal indices: out[m-1] absorbs a repeat (weights 1 -> 2; a fine row can appear at most twice)
+    RRow r;
+    r.n = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { r.idx[q] = 0; r.w[q] = 0.; }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const bool present = v[a] != kNone;
+        const bool repeat = present && a > 0 && v[a] == v[a > 0 ? a - 1 : 0];
+        if (present && !repeat) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (q == r.n) { r.idx[q] = v[a]; r.w[q] = 1.; }
+            r.n++;
+        } else if (repeat) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (q == r.n - 1) r.w[q] += 1.;
+        }
     }
-    int m = 0;
-    for (int a = 0; a < r.n; ++a) {
-        if (m > 0 && r.idx[m - 1] == r.idx[a]) r.w[m - 1] += 1.;
-        else { r.idx[m] = r.idx[a]; r.w[m] = 1.; m++; }
-    }
-    r.n = m;
     return r;
 }
 
@@ -290,7 +303,9 @@ __global__ void restrict_k(const int *__restrict__ choice, int64_t n_fine, int64
     for (int64_t I = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; I < n_coarse; I += (int64_t)gridDim.x * blockDim.x) {
         const RRow R = restriction_row(choice, I, n_fine);
         double acc = 0.;
-        for (int a = 0; a < R.n; ++a) acc += R.w[a] * r[R.idx[a]];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+            if (a < R.n) acc += R.w[a] * r[R.idx[a]];
         rc[I] = acc;
     }
 }
@@ -392,12 +407,16 @@ __global__ __launch_bounds__(64) void galerkin_wave_k(MatView A, const int *__re
         const RRow R = restriction_row(choice, I, A.P.n);
         // ---- 1. candidates of T = (R A)[I,:]
         int cnt = 0;
-        for (int a = 0; a < R.n; ++a) cnt += A.P.row_len[R.idx[a]];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+            if (a < R.n) cnt += A.P.row_len[R.idx[a]];
         bool fits = cnt <= cap;
         int cntT = 0, cnt2 = 0, lenO = 0;
         if (fits) {
             int base = 0;
-            for (int a = 0; a < R.n; ++a) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                if (a >= R.n) continue;
                 const int i = R.idx[a];
                 const double w = R.w[a];
                 const int len = A.P.row_len[i];
@@ -545,7 +564,9 @@ __global__ __launch_bounds__(64) void galerkin_bound_k(SellDev P, const int *__r
         int c = 0;
         if (I < n_coarse) {
             const RRow R = restriction_row(choice, I, P.n);
-            for (int a = 0; a < R.n; ++a) c += P.row_len[R.idx[a]];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+                if (a < R.n) c += P.row_len[R.idx[a]];
         }
         int tot;
         const int ex = wave_excl_scan(2 * c, tot);
