@@ -204,7 +204,11 @@ static int launch_spmv(const MatView &A, const double *x, const Epi &epi, double
     if (grid_out) *grid_out = g;
     if (A.P.n == 0) return ORC_OK;
     if (A.halo) ORC_TRY(A.halo->exchange(const_cast<double *>(x)));  // C1: refresh the ghost entries of x
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
+    static const bool ragged_enabled = !(getenv("ORC_SPMV_RAGGED") && atoi(getenv("ORC_SPMV_RAGGED")) == 0);
+    if (ragged_enabled && !A.persistent_pattern)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi, false>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
     ORC_HIP(hipGetLastError());
     return ORC_OK;
 }

@@ -40,7 +40,7 @@ struct SliceWalk {
 // Generic thread-per-row SELL-64 SpMV.  Epi::apply(row, acc, r0, r1) consumes the row result and
 // may accumulate up to two per-thread reduction terms; partial sums per workgroup go to
 // partials[q * gridDim.x + blockIdx.x] and are folded by reduce_partials_k.
-template <class Epi>
+template <class Epi, bool kRagged = false>
 __global__ __launch_bounds__(kBlock) void spmv_k(MatView A, const double *__restrict__ x, Epi epi, double *__restrict__ partials,
                                                  const double *__restrict__ skip_flags /* 2 doubles or null: non-zero = no-op */) {
     __shared__ double lds[8];
@@ -66,7 +66,9 @@ __global__ __launch_bounds__(kBlock) void spmv_k(MatView A, const double *__rest
             const int64_t p0 = base + (int64_t)k0 * 64 + lane;
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const bool in = k0 + u < width;
+                // kRagged (coarse AMG levels, 11-49 % padding): padding slots are not fetched, so a cache line whose lanes
+                // are all past their rows' ends stays in HBM; otherwise the loads stay wave-uniform (cheaper to issue)
+                const bool in = k0 + u < (kRagged ? len : width);
                 c[u] = in ? A.P.col[p0 + (int64_t)u * 64] : 0;
                 v[u] = in ? A.val[p0 + (int64_t)u * 64] : 0.;
             }
