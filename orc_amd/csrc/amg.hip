@@ -685,7 +685,7 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
     const int all_active = sym ? 0 : 1;  // activation needs "rows holding column j" = columns of row j
     unsigned char *cur = act_a, *nxt = act_b;
     // ---- bulk phase: slice-sequential sweeps (all of the work on structurally asymmetric patterns)
-    static const int bulk_sym = getenv("ORC_AMG_BULK") ? atoi(getenv("ORC_AMG_BULK")) : 3;
+    static const int bulk_sym = getenv("ORC_AMG_BULK") ? atoi(getenv("ORC_AMG_BULK")) : 1;
     const int kBulk = sym ? bulk_sym : 4;
     static const int warm_mode = getenv("ORC_AMG_WARM") ? atoi(getenv("ORC_AMG_WARM")) : 0;
     bool done = sym && warm != nullptr && warm_mode == 1;  // mode 1: straight to the certifying row-level rounds; 2: sweeps first
