@@ -355,21 +355,20 @@ __global__ void vec_add_k(double *__restrict__ x, const double *__restrict__ y, 
 // rows into LDS tiers (list capacity 128 << t) by their candidate bound, one launch per non-empty tier.
 // Output goes to a scratch area through an atomic bump allocator; a second kernel packs it into
 // SELL-64 once the slice widths are known (single pass: no symbolic/numeric duplication).
-__device__ __forceinline__ void bitonic_sort_wave(unsigned long long *__restrict__ key, double *__restrict__ val, int P) {
+// Only the keys move: their low 32 bits are the slot the entry was generated in, so the value of the entry at sorted
+// position e is val[(unsigned)key[e]] and the value array is never permuted.
+__device__ __forceinline__ void bitonic_sort_wave(unsigned long long *__restrict__ key, int P) {
     // P: power of two >= 64; executed by one wavefront (blockDim.x == 64): __syncthreads is a wave barrier
     const int lane = threadIdx.x;
     for (int k = 2; k <= P; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int e = lane; e < P; e += 64) {
-                const int partner = e ^ j;
-                if (partner > e) {
-                    const bool up = (e & k) == 0;
-                    const unsigned long long a = key[e], b = key[partner];
-                    if ((a > b) == up) {
-                        key[e] = b; key[partner] = a;
-                        const double t = val[e]; val[e] = val[partner]; val[partner] = t;
-                    }
-                }
+            // one lane per comparator (P/2 of them): element e has bit log2(j) clear, its partner has it set
+            for (int c = lane; c < (P >> 1); c += 64) {
+                const int e = ((c & ~(j - 1)) << 1) | (c & (j - 1));
+                const int partner = e | j;
+                const bool up = (e & k) == 0;
+                const unsigned long long a = key[e], b = key[partner];
+                if ((a > b) == up) { key[e] = b; key[partner] = a; }
             }
             __syncthreads();
         }
@@ -439,9 +438,9 @@ __global__ __launch_bounds__(64) void galerkin_wave_k(MatView A, const int *__re
             cnt = base;
             int P = 64;
             while (P < cnt) P <<= 1;
-            for (int e = cnt + lane; e < P; e += 64) { key[e] = ~0ull; val[e] = 0.; }
+            for (int e = cnt + lane; e < P; e += 64) key[e] = ~0ull;
             __syncthreads();
-            bitonic_sort_wave(key, val, P);
+            bitonic_sort_wave(key, P);
             // ---- 2. runs of equal j -> T (compact, sorted by j) into key2/val2
             for (int b0 = 0; b0 < cnt; b0 += 64) {
                 const int e = b0 + lane;
@@ -451,8 +450,8 @@ __global__ __launch_bounds__(64) void galerkin_wave_k(MatView A, const int *__re
                 const int slot = cntT + wave_excl_scan(head, tot);
                 if (head) {
                     const unsigned j = (unsigned)(key[e] >> 32);
-                    double acc = 0. + val[e];
-                    for (int q = e + 1; q < cnt && (unsigned)(key[q] >> 32) == j; ++q) acc += val[q];
+                    double acc = 0. + val[(unsigned)key[e]];
+                    for (int q = e + 1; q < cnt && (unsigned)(key[q] >> 32) == j; ++q) acc += val[(unsigned)key[q]];
                     key2[slot] = j;
                     val2[slot] = acc;
                 }
@@ -493,9 +492,9 @@ __global__ __launch_bounds__(64) void galerkin_wave_k(MatView A, const int *__re
         {
             int P = 64;
             while (P < cnt2) P <<= 1;
-            for (int e = cnt2 + lane; e < P; e += 64) { key[e] = ~0ull; val[e] = 0.; }
+            for (int e = cnt2 + lane; e < P; e += 64) key[e] = ~0ull;
             __syncthreads();
-            bitonic_sort_wave(key, val, P);
+            bitonic_sort_wave(key, P);
             // ---- 4. runs of equal J -> the coarse row (compact, sorted) into key2/val2
             for (int b0 = 0; b0 < cnt2; b0 += 64) {
                 const int e = b0 + lane;
@@ -505,8 +504,8 @@ __global__ __launch_bounds__(64) void galerkin_wave_k(MatView A, const int *__re
                 const int slot = lenO + wave_excl_scan(head, tot);
                 if (head) {
                     const unsigned Jc = (unsigned)(key[e] >> 32);
-                    double acc = 0. + val[e];
-                    for (int q = e + 1; q < cnt2 && (unsigned)(key[q] >> 32) == Jc; ++q) acc += val[q];
+                    double acc = 0. + val[(unsigned)key[e]];
+                    for (int q = e + 1; q < cnt2 && (unsigned)(key[q] >> 32) == Jc; ++q) acc += val[(unsigned)key[q]];
                     key2[slot] = Jc;
                     val2[slot] = acc;
                 }
