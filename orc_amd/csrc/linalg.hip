@@ -84,6 +84,7 @@ int sell_from_csr_host(int64_t n, int64_t ncols, const int64_t *row_ptr, const i
         for (int64_t k = e - b; k < width; ++k) scol[base + k * 64] = (int32_t)r;
     }
     out.n = n; out.ncols = ncols; out.nnz = nnz; out.padded = padded; out.n_slices = n_slices; out.symmetric = symmetric;
+    out.ragged = (double)padded > 1.08 * (double)std::max<int64_t>(nnz, 1);
     ORC_TRY(out.slice_ptr.upload(slice_ptr.data(), slice_ptr.size()));
     ORC_TRY(out.row_len.upload(row_len.data(), (size_t)n));
     ORC_TRY(out.col.upload(scol.data(), (size_t)padded));
@@ -205,7 +206,7 @@ static int launch_spmv(const MatView &A, const double *x, const Epi &epi, double
     if (A.P.n == 0) return ORC_OK;
     if (A.halo) ORC_TRY(A.halo->exchange(const_cast<double *>(x)));  // C1: refresh the ghost entries of x
     static const bool ragged_enabled = !(getenv("ORC_SPMV_RAGGED") && atoi(getenv("ORC_SPMV_RAGGED")) == 0);
-    if (ragged_enabled && !A.persistent_pattern)
+    if (ragged_enabled && A.P.ragged)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi, false>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
