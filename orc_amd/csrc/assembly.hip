@@ -836,12 +836,17 @@ struct PrepareThread {
         local = g;
         local.stream = s.prep_stream;
         local.last_error.clear();
-        running = true;
-        th = std::thread([this, &s] {
+        auto work = [this, &s] {
             CtxScope scope(&local);
             if (hipSetDevice(local.device) != hipSuccess) { status = set_error(ORC_ERR_HIP, "hipSetDevice failed in the set-up thread"); return; }
             status = prepare_p_hierarchy(s);
-        });
+        };
+        try {
+            th = std::thread(work);
+            running = true;
+        } catch (...) {  // no thread to be had: build the hierarchy right here
+            work();
+        }
     }
     int join() {
         if (!running) return ORC_OK;
@@ -868,14 +873,21 @@ static int solve_momentum_concurrently(SolverState &s) {
         local[k].stream = s.lanes[k].stream;
         local[k].last_error.clear();
     }
+    auto work = [&](int k) {
+        CtxScope scope(&local[k]);
+        if (hipSetDevice(local[k].device) != hipSuccess) { st[k] = set_error(ORC_ERR_HIP, "hipSetDevice failed in a solve thread"); return; }
+        st[k] = solve_field_on(s, *mats[k], *rhs[k], *sol[k], k, s.lanes[k].arena, s.lanes[k].stats, &s.lanes[k].side, &s.lanes[k].side_arena);
+        if (hipStreamSynchronize(local[k].stream) != hipSuccess && st[k] == ORC_OK) st[k] = set_error(ORC_ERR_HIP, "stream synchronisation failed in a solve thread");
+    };
+    for (int k = 0; k < 3; ++k) {
+        try {
+            th[k] = std::thread(work, k);
+        } catch (...) {  // no thread to be had: this lane runs here, after the ones already started (nothing crosses the C ABI)
+            work(k);
+        }
+    }
     for (int k = 0; k < 3; ++k)
-        th[k] = std::thread([&, k] {
-            CtxScope scope(&local[k]);
-            if (hipSetDevice(local[k].device) != hipSuccess) { st[k] = set_error(ORC_ERR_HIP, "hipSetDevice failed in a solve thread"); return; }
-            st[k] = solve_field_on(s, *mats[k], *rhs[k], *sol[k], k, s.lanes[k].arena, s.lanes[k].stats, &s.lanes[k].side, &s.lanes[k].side_arena);
-            if (hipStreamSynchronize(local[k].stream) != hipSuccess && st[k] == ORC_OK) st[k] = set_error(ORC_ERR_HIP, "stream synchronisation failed in a solve thread");
-        });
-    for (int k = 0; k < 3; ++k) th[k].join();
+        if (th[k].joinable()) th[k].join();
     s.stats = s.lanes[0].stats;
     for (int k = 0; k < 3; ++k)
         if (st[k] != ORC_OK) {
