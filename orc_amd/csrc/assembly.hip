@@ -849,9 +849,10 @@ struct PrepareThread {
         }
     }
     int join() {
-        if (!running) return ORC_OK;
-        th.join();
-        running = false;
+        if (running) {
+            th.join();
+            running = false;
+        }
         if (status != ORC_OK) ctx().last_error = local.last_error;
         return status;
     }
