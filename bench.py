@@ -195,6 +195,10 @@ def main():
     spmv_bytes = 12.0 * nnz_local + 20.0 * n_local  # f64 value + i32 column per nnz; row_ptr, x, y per row
     achieved = spmv_bytes / (spmv_ms * 1e-3) / 1e9
     bicg_ms = solver.bench_bicgstab_iteration(10)
+    import ctypes
+    free_b, total_b = ctypes.c_int64(0), ctypes.c_int64(0)
+    orc_amd._lib.check(orc_amd._lib.lib().orc_device_memory(ctypes.byref(free_b), ctypes.byref(total_b)))
+    hbm_used_gb = (total_b.value - free_b.value) / 1e9
     bicg_bytes = 2.0 * spmv_bytes + 104.0 * n_local
     # HBM traffic per launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes,
     # MI355X_MICROARCH.md §HBM): bench.py cannot collect counters itself, so it quotes the committed profile of the
@@ -233,6 +237,7 @@ def main():
                 "cells_total": int(n_cells_total),
                 "parallelism": "cell slabs x%d, RCCL halo + all-reduce" % world if world > 1 else "single GPU",
                 "setup_s": round(t_setup, 2),
+                "hbm_used_gb": round(hbm_used_gb, 1),
             },
             "roofline": {
                 "kernel": "spmv_k<EpiStore> (CSR/SELL-64 SpMV, a_u of the momentum system)",

@@ -34,6 +34,7 @@ int orc_device_count(void);                    /* 0 when no HIP device is visibl
 int orc_synchronize(void);                     /* hipStreamSynchronize on the library stream */
 const char *orc_status_string(int status);     /* the reference's panic text for the code */
 const char *orc_last_error(void);              /* detail of the last ORC_ERR_HIP / BAD_ARGUMENT */
+int orc_device_memory(int64_t *free_bytes, int64_t *total_bytes); /* hipMemGetInfo of the library's device */
 void orc_settings_default(OrcSettings *s);     /* NumericalSettings::default() + MatrixSolverSettings::default(), lib.rs:58-86 */
 
 /* ---------- mesh::Mesh (mesh.rs:140-187) ---------- */

@@ -101,6 +101,15 @@ int orc_synchronize(void) {
 
 const char *orc_last_error(void) { return orc::ctx().last_error.c_str(); }
 
+int orc_device_memory(int64_t *free_bytes, int64_t *total_bytes) {
+    ORC_TRY(orc::ensure_init());
+    size_t f = 0, t = 0;
+    ORC_HIP(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = (int64_t)f;
+    if (total_bytes) *total_bytes = (int64_t)t;
+    return ORC_OK;
+}
+
 const char *orc_status_string(int st) {
     switch (st) {
     case ORC_OK: return "ok";
