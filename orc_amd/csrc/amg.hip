@@ -983,6 +983,15 @@ int multigrid_prepare_dev(const MatView &A_in, int preconditioner, Arena &arena,
     return ORC_OK;
 }
 
+int multigrid_coarse_part_dev(const MatView &A, const double *r, double *x, uint64_t iteration_count, double relaxation_factor,
+                              double convergence_threshold, int preconditioner, Arena &arena, SolveStats *stats, int *dev_status) {
+    if (A.P.n == 0) return ORC_OK;
+    if (!stats || !stats->hierarchy || stats->hierarchy->n_levels < 1 || stats->hierarchy->n_fine != A.P.n)
+        return set_error(ORC_ERR_BAD_ARGUMENT, "the coarse part of the Multigrid arm needs a hierarchy prepared for this matrix");
+    MgParams mp{3 /* MULTIGRID_COARSENING_LEVELS, :10 */, iteration_count, ORC_SOLVER_BICGSTAB, preconditioner, relaxation_factor, convergence_threshold};
+    return multigrid_solve_dev(A, r, 1, mp, convergence_threshold, arena, stats, dev_status, nullptr, x, nullptr);
+}
+
 // Multigrid arm of iterative_solve (:270-296); A and b are already the preconditioned system.
 int multigrid_arm_dev(const MatView &A, const double *b, double *x, uint64_t iteration_count, double relaxation_factor,
                       double convergence_threshold, int preconditioner, Arena &arena, SolveStats *stats, int smoother) {

@@ -13,6 +13,8 @@
 #include <algorithm>
 #include <cmath>
 
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 
 #include "assembly.hpp"
@@ -800,6 +802,7 @@ static void destroy_side(SolveSide &d) {
 SolverState::~SolverState() {
     for (auto &l : lanes) {
         if (l.stream) (void)hipStreamDestroy(l.stream);
+        if (l.level0_done) (void)hipEventDestroy(l.level0_done);
         destroy_side(l.side);
     }
     destroy_side(side);
@@ -858,6 +861,142 @@ struct PrepareThread {
     }
     ~PrepareThread() { if (running) th.join(); }
 };
+
+// Partitioned runs (one rank of several): the same overlap with every RCCL call left where it was — on the library
+// stream, issued by the calling thread, in an order that is the same on all ranks.  Per momentum system the Multigrid
+// arm falls into (1) the Jacobi scaling, the level-0 smoothing solve and the residual, which exchange halos and
+// all-reduce scalars, (2) the hierarchy set-up, which needs the matrix only, (3) the V-recursion from level 1 on, and
+// (4) the status agreement.  (2) and (3) are rank-local: a lane (thread + streams) per system builds the hierarchy from
+// the start and runs (3) as soon as the library stream has finished that system's (1); the calling thread does
+// (1) for u, v, w in turn and (4) for u, v, w at the end.  Per system the operations and their order are those of the
+// sequential path, so the fields are identical.
+static int solve_momentum_partitioned(SolverState &s) {
+    Ctx &g = ctx();
+    const OrcSettings &t = s.settings;
+    OrcMesh &m = *s.mesh;
+    const int64_t n = m.n_own;
+    DevBuf<double> *mats[3] = {&s.a_u, &s.a_v, &s.a_w}, *rhs[3] = {&s.b_u, &s.b_v, &s.b_w}, *sol[3] = {&s.u, &s.v, &s.w};
+    Arena::Mark mk = s.arena.mark();
+    MatView plain[3], view[3];
+    const double *b_used[3];
+    double *r[3];
+    int *dev_status;
+    ORC_TRY(s.arena.alloc((size_t)4, &dev_status));
+    ORC_HIP(hipMemsetAsync(dev_status, 0, 4 * sizeof(int), g.stream));
+    for (int k = 0; k < 3; ++k) {
+        MatView A;
+        A.P = m.pat.dev();
+        A.val = mats[k]->p;
+        A.symmetric = m.pat.symmetric;
+        A.halo = &m.halo;
+        A.persistent_pattern = true;
+        plain[k] = view[k] = A;
+        b_used[k] = rhs[k]->p;
+        ORC_TRY(s.arena.alloc((size_t)std::max<int64_t>(n, 1), &r[k]));
+        if (t.preconditioner == ORC_PRECOND_JACOBI) {  // linear_algebra.rs:159-166, as iterative_solve_dev does it
+            double *dinv, *bt;
+            ORC_TRY(s.arena.alloc((size_t)std::max<int64_t>(n, 1), &dinv));
+            ORC_TRY(s.arena.alloc((size_t)std::max<int64_t>(n, 1), &bt));
+            ORC_TRY(diag_inverse_dev(A, dinv));
+            ORC_TRY(scale_vec_dev(dinv, rhs[k]->p, bt, n));
+            view[k].s1 = dinv;
+            b_used[k] = bt;
+        }
+        if (!s.lanes[k].stream) ORC_TRY(create_stream(&s.lanes[k].stream, kSetupStream, k));
+        if (!s.lanes[k].side.stream) {
+            ORC_TRY(create_stream(&s.lanes[k].side.stream, kSolveStream, k));
+            ORC_HIP(hipEventCreateWithFlags(&s.lanes[k].side.ev_setup, hipEventDisableTiming));
+            ORC_HIP(hipEventCreateWithFlags(&s.lanes[k].side.ev_solve, hipEventDisableTiming));
+            s.lanes[k].side.arena = &s.lanes[k].side_arena;
+        }
+        if (!s.lanes[k].level0_done) ORC_HIP(hipEventCreateWithFlags(&s.lanes[k].level0_done, hipEventDisableTiming));
+    }
+    ORC_HIP(hipStreamSynchronize(g.stream));  // the assembled systems and the scalings are complete
+    g.breakdown_guard = t.breakdown_guard != 0;
+
+    std::mutex mu;
+    std::condition_variable cv;
+    bool ready[3] = {false, false, false};
+    bool abort_all = false;
+    int st_lane[3] = {ORC_OK, ORC_OK, ORC_OK};
+    Ctx local[3];
+    std::thread th[3];
+    for (int k = 0; k < 3; ++k) {
+        local[k] = g;
+        local[k].stream = s.lanes[k].stream;
+        local[k].last_error.clear();
+    }
+    auto lane_work = [&](int k) {
+        SolverState::Lane &L = s.lanes[k];
+        CtxScope scope(&local[k]);
+        if (hipSetDevice(local[k].device) != hipSuccess) { st_lane[k] = set_error(ORC_ERR_HIP, "hipSetDevice failed in a solve thread"); return; }
+        L.arena.release(Arena::Mark{0, 0});
+        int st = multigrid_prepare_dev(plain[k], t.preconditioner, L.arena, L.hierarchy);  // (2)
+        if (st == ORC_OK && hipStreamSynchronize(local[k].stream) != hipSuccess) st = set_error(ORC_ERR_HIP, "stream synchronisation failed in a solve thread");
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return ready[k] || abort_all; });
+            if (abort_all) { st_lane[k] = st; return; }
+        }
+        if (st == ORC_OK) {  // (3) on the lane's solve stream, behind the library stream's level-0 work for this system
+            local[k].stream = L.side.stream;
+            if (hipStreamWaitEvent(L.side.stream, L.level0_done, 0) != hipSuccess) st = set_error(ORC_ERR_HIP, "hipStreamWaitEvent failed");
+            L.stats = SolveStats();
+            L.stats.hierarchy = &L.hierarchy;
+            L.side_arena.release(Arena::Mark{0, 0});
+            if (st == ORC_OK)
+                st = multigrid_coarse_part_dev(view[k], r[k], sol[k]->p, t.iterations, t.relaxation, t.relative_convergence_threshold, t.preconditioner,
+                                               L.side_arena, &L.stats, dev_status + k);
+            if (hipStreamSynchronize(L.side.stream) != hipSuccess && st == ORC_OK) st = set_error(ORC_ERR_HIP, "stream synchronisation failed in a solve thread");
+        }
+        st_lane[k] = st;
+    };
+    for (int k = 0; k < 3; ++k) {
+        try {
+            th[k] = std::thread(lane_work, k);
+        } catch (...) {
+            // without a thread the lane's work is done further down, after the level-0 section of its system
+        }
+    }
+    // (1) on the library stream, one system after the other
+    int st_main = ORC_OK;
+    for (int k = 0; k < 3 && st_main == ORC_OK; ++k) {
+        s.stats.cache = nullptr; s.stats.side = nullptr; s.stats.hierarchy = nullptr;
+        st_main = iterative_solve_dev(view[k], b_used[k], sol[k]->p, t.iterations, ORC_SOLVER_BICGSTAB, t.relaxation, t.relative_convergence_threshold,
+                                      t.preconditioner, s.arena, &s.stats);  // :273-282 (nested scaling, Q4)
+        if (st_main == ORC_OK) st_main = residual_dev(view[k], b_used[k], sol[k]->p, r[k]);  // :283
+        if (st_main == ORC_OK && hipEventRecord(s.lanes[k].level0_done, g.stream) != hipSuccess) st_main = set_error(ORC_ERR_HIP, "hipEventRecord failed");
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (st_main == ORC_OK) ready[k] = true;
+            else abort_all = true;
+        }
+        cv.notify_all();
+        if (st_main == ORC_OK && !th[k].joinable()) lane_work(k);  // no thread was to be had for this lane
+    }
+    if (st_main != ORC_OK) {
+        { std::lock_guard<std::mutex> lk(mu); abort_all = true; }
+        cv.notify_all();
+    }
+    for (int k = 0; k < 3; ++k)
+        if (th[k].joinable()) th[k].join();
+    // (4) the verdicts, agreed between the ranks in u, v, w order (a rank whose lane failed locally still takes part)
+    int result = st_main;
+    if (st_main == ORC_OK) {
+        int h[4] = {0, 0, 0, 0};
+        ORC_HIP(hipMemcpyAsync(h, dev_status, sizeof(h), hipMemcpyDeviceToHost, g.stream));
+        ORC_HIP(hipStreamSynchronize(g.stream));
+        for (int k = 0; k < 3; ++k) {
+            int stk = st_lane[k] != ORC_OK ? st_lane[k] : h[k];
+            if (st_lane[k] != ORC_OK) g.last_error = local[k].last_error;
+            stk = comm_global_status(stk);
+            if (result == ORC_OK && stk != ORC_OK) result = stk;
+        }
+    }
+    s.stats = s.lanes[0].stats;
+    s.arena.release(mk);
+    return result;
+}
 
 // The three momentum solves of one iteration on three streams, one host thread each (the set-up phases synchronise
 // their stream every few rounds).  Returns the first non-zero status in u, v, w order, like the sequential loop.
@@ -933,8 +1072,11 @@ int solver_iterate(SolverState &s, uint64_t iterations, double *report) {
         }
         const bool lanes_ok = s.concurrent_momentum && !H.active() && !dbg && !ctx().profile &&
                               (method == ORC_SOLVER_MULTIGRID || method == ORC_SOLVER_BICGSTAB || method == ORC_SOLVER_JACOBI);
+        const bool lanes_partitioned = s.concurrent_momentum && H.active() && !dbg && !ctx().profile && method == ORC_SOLVER_MULTIGRID;
         if (lanes_ok) {
             ORC_TRY(solve_momentum_concurrently(s));                    // :99-136, the three systems side by side
+        } else if (lanes_partitioned) {
+            ORC_TRY(solve_momentum_partitioned(s));                     // the same with every RCCL call on the library stream
         } else {
             ORC_TRY(solve_field(s, s.a_u, s.b_u, s.u, 0));              // :99-110
             if (dbg) debug_field(s, "u", s.u);

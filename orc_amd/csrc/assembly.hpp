@@ -75,6 +75,8 @@ struct SolverState {
         SolveStats stats;
         SolveSide side;   // second stream of the lane's Multigrid solves (set-up beside smoothing, linalg.hpp)
         Arena side_arena;
+        AmgHierarchy hierarchy;        // partitioned runs: built by the lane while the library stream does the level-0 work
+        hipEvent_t level0_done = nullptr;
     } lanes[3];
     // The pressure-correction matrix depends on the momentum diagonals and the geometry only (discretization.rs:401-438;
     // the new velocities enter its RHS), so its Multigrid hierarchy is built on a stream of its own while the momentum

@@ -156,6 +156,13 @@ __global__ void scale_vec_k(const double *__restrict__ s, const double *__restri
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = 0. + s[i] * b[i];
 }
 
+int scale_vec_dev(const double *sv, const double *b, double *out, int64_t n) {
+    if (n == 0) return ORC_OK;
+    hipLaunchKernelGGL(scale_vec_k, dim3(grid_for(n)), dim3(kBlock), 0, ctx().stream, sv, b, out, n);
+    ORC_HIP(hipGetLastError());
+    return ORC_OK;
+}
+
 // ------------------------------------------------------------------ SpMV epilogues
 struct EpiStore {  // y = A x
     static constexpr int kReductions = 0;

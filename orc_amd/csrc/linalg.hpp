@@ -112,6 +112,13 @@ int iterative_solve_dev(const MatView &A, const double *b, double *x, uint64_t i
 int multigrid_prepare_dev(const MatView &A, int preconditioner, Arena &arena, AmgHierarchy &H);
 // dinv[i] = 1 / A(i,i) through the view (the Jacobi preconditioner's p_inv, linear_algebra.rs:159-166)
 int diag_inverse_dev(const MatView &A, double *dinv);
+// out = 0 + s * b  (p_inv * b, linear_algebra.rs:165)
+int scale_vec_dev(const double *s, const double *b, double *out, int64_t n);
+// The rank-local remainder of the Multigrid arm once its level-0 smoothing and residual are done (:284-295): the
+// V-recursion from level 1 on a prepared hierarchy (stats->hierarchy), x += correction.  No rank-to-rank traffic, no
+// host synchronisation; *dev_status collects ORC_ERR_MULTIGRID_DIVERGED.
+int multigrid_coarse_part_dev(const MatView &A, const double *r, double *x, uint64_t iteration_count, double relaxation_factor,
+                              double convergence_threshold, int preconditioner, Arena &arena, SolveStats *stats, int *dev_status);
 
 // y = A x (K1).  Exposed for bench/tests.
 int spmv_dev(const MatView &A, const double *x, double *y);

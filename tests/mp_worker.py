@@ -127,6 +127,25 @@ def gpu_checks(rank, world, a, halo, gids, ag):
         if rank == 0:
             print("  %-10s status %d/%d  max rel err vs single rank %.3e  %s" % (name, st, st_ref, err, "ok" if good else "FAIL"), flush=True)
         results[name] = good
+        if name == "multigrid":
+            # the partitioned momentum lanes (hierarchies built beside the level-0 work, every collective still issued by
+            # this thread on the library stream) against everything on one stream: identical bits
+            os.environ["ORC_CONCURRENT_MOMENTUM"] = "0"
+            os.environ["ORC_EARLY_P_HIERARCHY"] = "0"
+            os.environ["ORC_TWO_STREAM_MULTIGRID"] = "0"
+            try:
+                seq = Solver(pm, s, 1000.0, 1e-3)
+                seq.set_fields(*[f[gids] for f in ug])
+                st_seq = seq.iterate(2, raise_on_error=False)
+                same = st_seq == st and all(np.array_equal(x[:n_own], y[:n_own]) for x, y in zip(seq.get_fields(), loc))
+            finally:
+                for k in ("ORC_CONCURRENT_MOMENTUM", "ORC_EARLY_P_HIERARCHY", "ORC_TWO_STREAM_MULTIGRID"):
+                    del os.environ[k]
+            flags = [None] * world
+            dist.all_gather_object(flags, bool(same))
+            if rank == 0:
+                print("  %-10s lanes vs one stream, per rank: %s  %s" % (name, flags, "ok" if all(flags) else "FAIL"), flush=True)
+            results["multigrid_lanes"] = all(flags)
     parallel.finalize()
     return all(results.values())
 

@@ -9,6 +9,7 @@ pytestmark = pytest.mark.gpu
 
 def test_two_ranks_match_single_rank(gpu):
     r = launch(2, "gpu", timeout=900)
+    print(r.stdout[-1500:])
     assert "MP_WORKER_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-4000:]
 
 
