@@ -1065,13 +1065,14 @@ int solver_iterate(SolverState &s, uint64_t iterations, double *report) {
         const int method = s.settings.solver_type;
         PrepareThread prep;
         s.p_hierarchy.n_levels = 0;
-        if (s.early_p_hierarchy && method == ORC_SOLVER_MULTIGRID && !dbg && !ctx().profile) {
+        if (s.early_p_hierarchy && (method == ORC_SOLVER_MULTIGRID || method == ORC_SOLVER_MULTIGRID_GS) && !dbg && !ctx().profile) {
             if (!s.prep_stream) ORC_TRY(create_stream(&s.prep_stream, kSetupStream, 2));
             ORC_HIP(hipStreamSynchronize(ctx().stream));  // the diagonals (and their ghosts) are in place
             prep.start(s);
         }
         const bool lanes_ok = s.concurrent_momentum && !H.active() && !dbg && !ctx().profile &&
-                              (method == ORC_SOLVER_MULTIGRID || method == ORC_SOLVER_BICGSTAB || method == ORC_SOLVER_JACOBI);
+                              (method == ORC_SOLVER_MULTIGRID || method == ORC_SOLVER_BICGSTAB || method == ORC_SOLVER_JACOBI ||
+                               method == ORC_SOLVER_MULTIGRID_GS || method == ORC_SOLVER_BICGSTAB_GS_PRECOND || method == ORC_SOLVER_MULTICOLOR_GS);
         const bool lanes_partitioned = s.concurrent_momentum && H.active() && !dbg && !ctx().profile && method == ORC_SOLVER_MULTIGRID;
         if (lanes_ok) {
             ORC_TRY(solve_momentum_concurrently(s));                    // :99-136, the three systems side by side

@@ -13,16 +13,45 @@
 #include <cmath>
 #include <map>
 #include <memory>
+#include <mutex>
 
 #include "linalg_kernels.hpp"
 
 namespace orc {
 
+// Colour-sorted copy of a pattern (persistent patterns only: it is built on the host once): the rows of a colour are
+// contiguous, every colour starts on a slice boundary, columns keep their original numbering.  A sweep over one colour
+// is then a product-like pass over a contiguous slice range with fully coalesced matrix reads; with the rows left in
+// mesh order every colour's kernel touches every cache line of the matrix (n_colors times the traffic).
+struct ColorSell {
+    bool built = false;
+    int64_t n_slots = 0, padded = 0;
+    int n_slices = 0;
+    DevBuf<int64_t> slice_ptr;          // [n_slices + 1]
+    DevBuf<int> row_len, rowid, diag_off;  // per slot: entries, original row (-1: padding slot), element offset of the diagonal (-1: none)
+    DevBuf<int> col;                    // [padded] original column indices
+    DevBuf<int> slot_of_row;            // [n]
+    std::vector<int> color_slice;       // [n_colors + 1] first slice of every colour
+};
+
 struct Coloring {
     int n_colors = 0;
-    DevBuf<int> color;       // [n]
+    DevBuf<int> color;       // [n]   (owned when the colouring is cached; per-solve colourings live in the solve's arena)
     DevBuf<int> rows;        // rows grouped by colour
+    int *color_p = nullptr, *rows_p = nullptr;
+    bool has_rows = false;
     std::vector<int> start;  // [n_colors + 1]
+    ColorSell sorted;
+};
+
+// what a sorted sweep reads: the cached ColorSell of a persistent pattern plus per-solve values, or a layout built on the
+// device in the solve's arena (coarse AMG levels)
+struct SortedView {
+    const int64_t *sp = nullptr;
+    const int *row_len = nullptr, *rowid = nullptr, *diag_off = nullptr, *col = nullptr;
+    const double *val = nullptr;
+    std::vector<int> color_slice;
+    bool ok() const { return val != nullptr; }
 };
 
 __device__ __forceinline__ unsigned hash32(unsigned x) {
@@ -58,49 +87,68 @@ __global__ void jp_round_k(SellDev P, const int *__restrict__ color_in, int *__r
 }
 
 __global__ void color_count_k(const int *__restrict__ color, int64_t n, int *__restrict__ counts) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) atomicAdd(&counts[color[i]], 1);
+    __shared__ int local[64];  // per-workgroup histogram: 64 global atomics per workgroup instead of one per row
+    if (threadIdx.x < 64) local[threadIdx.x] = 0;
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) atomicAdd(&local[color[i]], 1);
+    __syncthreads();
+    if (threadIdx.x < 64 && local[threadIdx.x]) atomicAdd(&counts[threadIdx.x], local[threadIdx.x]);
 }
 __global__ void color_fill_k(const int *__restrict__ color, int64_t n, int *__restrict__ cursor, int *__restrict__ rows) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) rows[atomicAdd(&cursor[color[i]], 1)] = (int)i;
 }
 
-static int build_coloring(const SellDev &P, Coloring &C) {
+static int build_coloring(const SellDev &P, Coloring &C, Arena *arena = nullptr, bool want_row_lists = true) {
     const int64_t n = P.n;
+    const size_t nn = (size_t)std::max<int64_t>(n, 1);
     hipStream_t st = ctx().stream;
-    ORC_TRY(C.color.alloc((size_t)std::max<int64_t>(n, 1)));
-    DevBuf<int> tmp, flags, counts;
-    ORC_TRY(tmp.alloc((size_t)std::max<int64_t>(n, 1)));
-    ORC_TRY(flags.alloc(2));
-    ORC_TRY(counts.alloc(128));
-    ORC_HIP(hipMemsetAsync(C.color.p, 0xff, sizeof(int) * (size_t)n, st));
-    int *in = C.color.p, *out = tmp.p;
+    DevBuf<int> tmp_b, flags_b, counts_b;
+    int *tmp, *flags, *counts;
+    if (arena) {  // per-solve colouring: no hipMalloc / hipFree inside the SIMPLE loop
+        ORC_TRY(arena->alloc(nn, &C.color_p));
+        ORC_TRY(arena->alloc(nn, &C.rows_p));
+        ORC_TRY(arena->alloc(nn, &tmp));
+        ORC_TRY(arena->alloc((size_t)2, &flags));
+        ORC_TRY(arena->alloc((size_t)128, &counts));
+    } else {
+        ORC_TRY(C.color.alloc(nn));
+        ORC_TRY(C.rows.alloc(nn));
+        ORC_TRY(tmp_b.alloc(nn));
+        ORC_TRY(flags_b.alloc(2));
+        ORC_TRY(counts_b.alloc(128));
+        C.color_p = C.color.p; C.rows_p = C.rows.p; tmp = tmp_b.p; flags = flags_b.p; counts = counts_b.p;
+    }
+    ORC_HIP(hipMemsetAsync(C.color_p, 0xff, sizeof(int) * (size_t)n, st));
+    int *in = C.color_p, *out = tmp;
     const int g = grid_for(n);
     for (int round = 0; round < 10000; ++round) {
-        ORC_HIP(hipMemsetAsync(flags.p, 0, 2 * sizeof(int), st));
-        hipLaunchKernelGGL(jp_round_k, dim3(g), dim3(kBlock), 0, st, P, in, out, flags.p, flags.p + 1);
+        ORC_HIP(hipMemsetAsync(flags, 0, 2 * sizeof(int), st));
+        hipLaunchKernelGGL(jp_round_k, dim3(g), dim3(kBlock), 0, st, P, in, out, flags, flags + 1);
         ORC_HIP(hipGetLastError());
         int h[2];
-        ORC_HIP(hipMemcpyAsync(h, flags.p, sizeof(h), hipMemcpyDeviceToHost, st));
+        ORC_HIP(hipMemcpyAsync(h, flags, sizeof(h), hipMemcpyDeviceToHost, st));
         ORC_HIP(hipStreamSynchronize(st));
         std::swap(in, out);
         if (h[1]) return set_error(ORC_ERR_BAD_ARGUMENT, "colouring needs more than 64 colours");
         if (h[0] == 0) break;
     }
-    if (in != C.color.p) ORC_HIP(hipMemcpyAsync(C.color.p, in, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, st));
-    ORC_HIP(hipMemsetAsync(counts.p, 0, 128 * sizeof(int), st));
-    hipLaunchKernelGGL(color_count_k, dim3(g), dim3(kBlock), 0, st, C.color.p, n, counts.p);
+    if (in != C.color_p) ORC_HIP(hipMemcpyAsync(C.color_p, in, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, st));
+    ORC_HIP(hipMemsetAsync(counts, 0, 128 * sizeof(int), st));
+    hipLaunchKernelGGL(color_count_k, dim3(g), dim3(kBlock), 0, st, C.color_p, n, counts);
     int hc[64];
-    ORC_HIP(hipMemcpyAsync(hc, counts.p, sizeof(hc), hipMemcpyDeviceToHost, st));
+    ORC_HIP(hipMemcpyAsync(hc, counts, sizeof(hc), hipMemcpyDeviceToHost, st));
     ORC_HIP(hipStreamSynchronize(st));
     C.n_colors = 0;
     for (int c = 0; c < 64; ++c) if (hc[c] > 0) C.n_colors = c + 1;
     C.start.assign((size_t)C.n_colors + 1, 0);
     for (int c = 0; c < C.n_colors; ++c) C.start[(size_t)c + 1] = C.start[(size_t)c] + hc[c];
-    ORC_TRY(C.rows.alloc((size_t)std::max<int64_t>(n, 1)));
-    ORC_HIP(hipMemcpyAsync(counts.p + 64, C.start.data(), sizeof(int) * (size_t)C.n_colors, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(color_fill_k, dim3(g), dim3(kBlock), 0, st, C.color.p, n, counts.p + 64, C.rows.p);
-    ORC_HIP(hipGetLastError());
-    ORC_HIP(hipStreamSynchronize(st));
+    if (want_row_lists) {  // only the unsorted sweeps walk row lists
+        ORC_HIP(hipMemcpyAsync(counts + 64, C.start.data(), sizeof(int) * (size_t)C.n_colors, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(color_fill_k, dim3(g), dim3(kBlock), 0, st, C.color_p, n, counts + 64, C.rows_p);
+        ORC_HIP(hipGetLastError());
+        ORC_HIP(hipStreamSynchronize(st));
+        C.has_rows = true;
+    }
     return ORC_OK;
 }
 
@@ -130,11 +178,281 @@ __global__ void gs_color_k(MatView A, const double *__restrict__ b, double *__re
     }
 }
 
-static int gs_sweep(const MatView &A, const Coloring &C, const double *b, double *x, double omega, int *status) {
+// ---- colour-sorted layout
+static int build_color_sell(const SellDev &P, Coloring &C) {
+    const int64_t n = P.n;
+    hipStream_t st = ctx().stream;
+    std::vector<int> color((size_t)n), row_len((size_t)n), diag((size_t)n);
+    std::vector<int64_t> sp((size_t)P.n_slices + 1);
+    ORC_HIP(hipMemcpyAsync(color.data(), C.color_p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, st));
+    ORC_HIP(hipMemcpyAsync(row_len.data(), P.row_len, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, st));
+    ORC_HIP(hipMemcpyAsync(diag.data(), P.diag_pos, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, st));
+    ORC_HIP(hipMemcpyAsync(sp.data(), P.slice_ptr, sizeof(int64_t) * sp.size(), hipMemcpyDeviceToHost, st));
+    ORC_HIP(hipStreamSynchronize(st));
+    const int64_t padded_in = sp[(size_t)P.n_slices];
+    std::vector<int> col((size_t)std::max<int64_t>(padded_in, 1));
+    ORC_HIP(hipMemcpy(col.data(), P.col, sizeof(int) * (size_t)padded_in, hipMemcpyDeviceToHost));
+    ColorSell &S = C.sorted;
+    // slots: colour after colour, rows ascending inside a colour, every colour padded to whole slices
+    std::vector<int64_t> cursor((size_t)C.n_colors + 1, 0);
+    S.color_slice.assign((size_t)C.n_colors + 1, 0);
+    for (int c = 0; c < C.n_colors; ++c) {
+        const int64_t cnt = C.start[(size_t)c + 1] - C.start[(size_t)c];
+        S.color_slice[(size_t)c + 1] = S.color_slice[(size_t)c] + (int)((cnt + 63) / 64);
+        cursor[(size_t)c] = (int64_t)S.color_slice[(size_t)c] * 64;
+    }
+    S.n_slices = S.color_slice[(size_t)C.n_colors];
+    S.n_slots = (int64_t)S.n_slices * 64;
+    std::vector<int> slot_of_row((size_t)n), rowid((size_t)std::max<int64_t>(S.n_slots, 1), -1), len_p((size_t)std::max<int64_t>(S.n_slots, 1), 0);
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t slot = cursor[(size_t)color[(size_t)i]]++;
+        slot_of_row[(size_t)i] = (int)slot;
+        rowid[(size_t)slot] = (int)i;
+        len_p[(size_t)slot] = row_len[(size_t)i];
+    }
+    std::vector<int64_t> sp_p((size_t)S.n_slices + 1, 0);
+    for (int sidx = 0; sidx < S.n_slices; ++sidx) {
+        int w = 0;
+        for (int l = 0; l < 64; ++l) w = std::max(w, len_p[(size_t)sidx * 64 + l]);
+        sp_p[(size_t)sidx + 1] = sp_p[(size_t)sidx] + (int64_t)w * 64;
+    }
+    S.padded = sp_p[(size_t)S.n_slices];
+    if (S.padded >= ((int64_t)1 << 31)) return set_error(ORC_ERR_BAD_ARGUMENT, "colour-sorted matrix too large for 32-bit offsets");
+    std::vector<int> col_p((size_t)std::max<int64_t>(S.padded, 1), 0), diag_p((size_t)std::max<int64_t>(S.n_slots, 1), -1);
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t slot = slot_of_row[(size_t)i];
+        const int64_t src = sp[(size_t)(i >> 6)] + (i & 63), dst = sp_p[(size_t)(slot >> 6)] + (slot & 63);
+        for (int k = 0; k < row_len[(size_t)i]; ++k) {
+            col_p[(size_t)(dst + (int64_t)k * 64)] = col[(size_t)(src + (int64_t)k * 64)];
+            if (diag[(size_t)i] == (int)(src + (int64_t)k * 64)) diag_p[(size_t)slot] = (int)(dst + (int64_t)k * 64);
+        }
+    }
+    ORC_TRY(S.slice_ptr.upload(sp_p.data(), sp_p.size()));
+    ORC_TRY(S.row_len.upload(len_p.data(), len_p.size()));
+    ORC_TRY(S.rowid.upload(rowid.data(), rowid.size()));
+    ORC_TRY(S.diag_off.upload(diag_p.data(), diag_p.size()));
+    ORC_TRY(S.col.upload(col_p.data(), col_p.size()));
+    ORC_TRY(S.slot_of_row.upload(slot_of_row.data(), slot_of_row.size()));
+    S.built = true;
+    return ORC_OK;
+}
+
+// values of the matrix view -> colour-sorted storage: thread per original row (coalesced reads), the scalings applied
+__global__ void gs_permute_values_k(MatView A, const int *__restrict__ slot_of_row, const int64_t *__restrict__ sp_p, double *__restrict__ val_p) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < A.P.n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int len = A.P.row_len[i];
+        const int64_t src = A.P.slice_ptr[i >> 6] + (i & 63);
+        const int64_t slot = slot_of_row[i];
+        const int64_t dst = sp_p[slot >> 6] + (slot & 63);
+        for (int k = 0; k < len; ++k) val_p[dst + (int64_t)k * 64] = view_value(A, i, src + (int64_t)k * 64);
+    }
+}
+
+// the row update of gs_color_k for the slices [slice_lo, slice_hi) of one colour: one lane per slot
+__global__ __launch_bounds__(kBlock) void gs_color_sorted_k(const int64_t *__restrict__ sp, const int *__restrict__ row_len, const int *__restrict__ rowid,
+                                                            const int *__restrict__ diag_off, const int *__restrict__ col, const double *__restrict__ val,
+                                                            const double *__restrict__ b, double *__restrict__ x, int slice_lo, int slice_hi, double omega,
+                                                            int *__restrict__ status) {
+    const int lane = threadIdx.x & 63;
+    const int waves = blockDim.x >> 6;
+    for (int sidx = slice_lo + blockIdx.x * waves + (threadIdx.x >> 6); sidx < slice_hi; sidx += gridDim.x * waves) {
+        const int64_t slot = (int64_t)sidx * 64 + lane;
+        const int i = rowid[slot];
+        const int len = i >= 0 ? row_len[slot] : 0;
+        const int64_t base = sp[sidx] + lane;
+        const int width = (int)((sp[sidx + 1] - sp[sidx]) >> 6);
+        double sum = 0.;
+        // chunks of 8 like the product: column and value loads first, then the x gathers, then the ordered additions
+        for (int k0 = 0; k0 < width; k0 += 8) {
+            int c[8];
+            double v[8], xv[8];
+            const int64_t p0 = base + (int64_t)k0 * 64;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool in = k0 + u < len;
+                c[u] = in ? col[p0 + (int64_t)u * 64] : 0;
+                v[u] = in ? val[p0 + (int64_t)u * 64] : 0.;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xv[u] = (k0 + u < len) ? x[c[u]] : 0.;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (k0 + u < len) sum += (c[u] == i) ? 0. : v[u] * xv[u];
+        }
+        if (i < 0) continue;
+        const int d = diag_off[slot];
+        if (d < 0) {
+            if (len > 0) atomicCAS(status, 0, (int)ORC_ERR_STRUCTURAL_ZERO);
+            continue;
+        }
+        const double xi = x[i] * (1. - omega) + omega * (b[i] - sum) / val[d];
+        x[i] = xi;
+        if (xi != xi) atomicCAS(status, 0, (int)ORC_ERR_SOLUTION_DIVERGED);  // :240-242
+    }
+}
+
+static int gs_sweep_sorted(const Coloring &C, const SortedView &V, const double *b, double *x, double omega, int *status) {
+    for (int c = 0; c < C.n_colors; ++c) {
+        const int lo = V.color_slice[(size_t)c], hi = V.color_slice[(size_t)c + 1];
+        if (hi <= lo) continue;
+        const int g = std::min(kMaxGrid, (hi - lo + 3) / 4);
+        hipLaunchKernelGGL(gs_color_sorted_k, dim3(g), dim3(kBlock), 0, ctx().stream, V.sp, V.row_len, V.rowid, V.diag_off, V.col, V.val, b, x, lo, hi, omega,
+                           status);
+    }
+    ORC_HIP(hipGetLastError());
+    return ORC_OK;
+}
+
+// ---- the same layout built on the device, in the solve's arena, for patterns that live for one solve (coarse AMG
+// levels).  Rank of a row inside its colour = rows of that colour in earlier 64-row blocks (column scan of a
+// [blocks x colours] count table) + rows of that colour before it in its own block (ballot).
+__global__ __launch_bounds__(64) void gs_block_counts_k(const int *__restrict__ color, int64_t n, int n_colors, int *__restrict__ table,
+                                                        int *__restrict__ intra) {
+    const int lane = threadIdx.x;
+    const int64_t n_blocks = (n + 63) / 64;
+    for (int64_t bidx = blockIdx.x; bidx < n_blocks; bidx += gridDim.x) {
+        const int64_t i = bidx * 64 + lane;
+        const int c = i < n ? color[i] : -1;
+        for (int q = 0; q < n_colors; ++q) {
+            const unsigned long long m = __ballot(c == q);
+            if (c == q) intra[i] = __popcll(m & ((1ull << lane) - 1ull));
+            if (lane == 0) table[bidx * n_colors + q] = __popcll(m);
+        }
+    }
+}
+// exclusive scan down every column of the table: one workgroup per colour
+__global__ __launch_bounds__(1024) void gs_column_scan_k(int *__restrict__ table, int64_t n_blocks, int n_colors) {
+    __shared__ int carry;
+    __shared__ int buf[1024];
+    const int q = blockIdx.x;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < n_blocks; base += 1024) {
+        const int64_t e = base + threadIdx.x;
+        const int v = e < n_blocks ? table[e * n_colors + q] : 0;
+        buf[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const int t = threadIdx.x >= off ? buf[threadIdx.x - off] : 0;
+            __syncthreads();
+            buf[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (e < n_blocks) table[e * n_colors + q] = carry + buf[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += buf[1023];
+        __syncthreads();
+    }
+}
+__global__ void gs_assign_slots_k(SellDev P, const int *__restrict__ color, const int *__restrict__ table, const int *__restrict__ intra, int n_colors,
+                                  const int *__restrict__ color_first_slot, int *__restrict__ slot_of_row, int *__restrict__ rowid, int *__restrict__ len_p) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P.n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = color[i];
+        const int slot = color_first_slot[c] + table[(i >> 6) * n_colors + c] + intra[i];
+        slot_of_row[i] = slot;
+        rowid[slot] = (int)i;
+        len_p[slot] = P.row_len[i];
+    }
+}
+__global__ __launch_bounds__(1024) void gs_slice_ptr_k(const int *__restrict__ len_p, int n_slices, int64_t *__restrict__ slice_ptr) {
+    __shared__ long long carry;
+    __shared__ long long buf[1024];
+    if (threadIdx.x == 0) { carry = 0; slice_ptr[0] = 0; }
+    __syncthreads();
+    for (int base = 0; base < n_slices; base += 1024) {
+        const int sidx = base + threadIdx.x;
+        long long w = 0;
+        if (sidx < n_slices) {
+            int mx = 0;
+            for (int l = 0; l < 64; ++l) mx = max(mx, len_p[(int64_t)sidx * 64 + l]);
+            w = (long long)mx * 64;
+        }
+        buf[threadIdx.x] = w;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const long long t = threadIdx.x >= off ? buf[threadIdx.x - off] : 0;
+            __syncthreads();
+            buf[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (sidx < n_slices) slice_ptr[sidx + 1] = carry + buf[threadIdx.x];
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += buf[1023];
+        __syncthreads();
+    }
+}
+// pattern and values of the view -> colour-sorted storage (thread per original row), diagonal offsets on the way
+__global__ void gs_permute_all_k(MatView A, const int *__restrict__ slot_of_row, const int64_t *__restrict__ sp_p, int *__restrict__ col_p,
+                                 double *__restrict__ val_p, int *__restrict__ diag_p) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < A.P.n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int len = A.P.row_len[i];
+        const int64_t src = A.P.slice_ptr[i >> 6] + (i & 63);
+        const int64_t slot = slot_of_row[i];
+        const int64_t dst = sp_p[slot >> 6] + (slot & 63);
+        int d = -1;
+        for (int k = 0; k < len; ++k) {
+            const int j = A.P.col[src + (int64_t)k * 64];
+            col_p[dst + (int64_t)k * 64] = j;
+            val_p[dst + (int64_t)k * 64] = view_value(A, i, src + (int64_t)k * 64);
+            if (j == i) d = (int)(dst + (int64_t)k * 64);
+        }
+        diag_p[slot] = d;
+    }
+}
+
+static int build_sorted_on_device(const MatView &A, const Coloring &C, Arena &arena, SortedView &V) {
+    const int64_t n = A.P.n;
+    hipStream_t st = ctx().stream;
+    const int nc = C.n_colors;
+    V.color_slice.assign((size_t)nc + 1, 0);
+    std::vector<int> first_slot((size_t)std::max(nc, 1), 0);
+    for (int c = 0; c < nc; ++c) {
+        const int64_t cnt = C.start[(size_t)c + 1] - C.start[(size_t)c];
+        first_slot[(size_t)c] = V.color_slice[(size_t)c] * 64;
+        V.color_slice[(size_t)c + 1] = V.color_slice[(size_t)c] + (int)((cnt + 63) / 64);
+    }
+    const int n_slices = V.color_slice[(size_t)nc];
+    const int64_t n_slots = (int64_t)n_slices * 64, n_blocks = (n + 63) / 64;
+    if (n_slices == 0) return ORC_OK;
+    int *table, *intra, *first_dev, *slot_of_row, *rowid, *len_p, *diag_p, *col_p;
+    int64_t *sp_p;
+    double *val_p;
+    ORC_TRY(arena.alloc((size_t)(n_blocks * nc), &table));
+    ORC_TRY(arena.alloc((size_t)n, &intra));
+    ORC_TRY(arena.alloc((size_t)nc, &first_dev));
+    ORC_TRY(arena.alloc((size_t)n, &slot_of_row));
+    ORC_TRY(arena.alloc((size_t)n_slots, &rowid));
+    ORC_TRY(arena.alloc((size_t)n_slots, &len_p));
+    ORC_TRY(arena.alloc((size_t)n_slots, &diag_p));
+    ORC_TRY(arena.alloc((size_t)n_slices + 1, &sp_p));
+    ORC_HIP(hipMemcpyAsync(first_dev, first_slot.data(), sizeof(int) * (size_t)nc, hipMemcpyHostToDevice, st));
+    ORC_HIP(hipMemsetAsync(rowid, 0xff, sizeof(int) * (size_t)n_slots, st));
+    ORC_HIP(hipMemsetAsync(len_p, 0, sizeof(int) * (size_t)n_slots, st));
+    ORC_HIP(hipMemsetAsync(diag_p, 0xff, sizeof(int) * (size_t)n_slots, st));
+    hipLaunchKernelGGL(gs_block_counts_k, dim3((unsigned)std::min<int64_t>(n_blocks, 8192)), dim3(64), 0, st, C.color_p, n, nc, table, intra);
+    hipLaunchKernelGGL(gs_column_scan_k, dim3(nc), dim3(1024), 0, st, table, n_blocks, nc);
+    hipLaunchKernelGGL(gs_assign_slots_k, dim3(grid_for(n)), dim3(kBlock), 0, st, A.P, C.color_p, table, intra, nc, first_dev, slot_of_row, rowid, len_p);
+    hipLaunchKernelGGL(gs_slice_ptr_k, dim3(1), dim3(1024), 0, st, len_p, n_slices, sp_p);
+    ORC_HIP(hipGetLastError());
+    int64_t padded = 0;
+    ORC_HIP(hipMemcpyAsync(&padded, sp_p + n_slices, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    ORC_HIP(hipStreamSynchronize(st));
+    if (padded >= ((int64_t)1 << 31)) return set_error(ORC_ERR_BAD_ARGUMENT, "colour-sorted matrix too large for 32-bit offsets");
+    ORC_TRY(arena.alloc((size_t)std::max<int64_t>(padded, 1), &col_p));
+    ORC_TRY(arena.alloc((size_t)std::max<int64_t>(padded, 1), &val_p));
+    hipLaunchKernelGGL(gs_permute_all_k, dim3(grid_for(n)), dim3(kBlock), 0, st, A, slot_of_row, sp_p, col_p, val_p, diag_p);
+    ORC_HIP(hipGetLastError());
+    V.sp = sp_p; V.row_len = len_p; V.rowid = rowid; V.diag_off = diag_p; V.col = col_p; V.val = val_p;
+    return ORC_OK;
+}
+
+static int gs_sweep(const MatView &A, const Coloring &C, const double *b, double *x, double omega, int *status, const SortedView *sorted = nullptr) {
+    if (sorted && sorted->ok()) return gs_sweep_sorted(C, *sorted, b, x, omega, status);
+    if (!C.has_rows) return set_error(ORC_ERR_BAD_ARGUMENT, "colouring without row lists: the colour-sorted layout is missing");
     for (int c = 0; c < C.n_colors; ++c) {
         const int cnt = C.start[(size_t)c + 1] - C.start[(size_t)c];
         if (cnt == 0) continue;
-        hipLaunchKernelGGL(gs_color_k, dim3(grid_for(cnt)), dim3(kBlock), 0, ctx().stream, A, b, x, C.rows.p + C.start[(size_t)c], cnt, omega, status);
+        hipLaunchKernelGGL(gs_color_k, dim3(grid_for(cnt)), dim3(kBlock), 0, ctx().stream, A, b, x, C.rows_p + C.start[(size_t)c], cnt, omega, status);
     }
     ORC_HIP(hipGetLastError());
     return ORC_OK;
@@ -147,20 +465,25 @@ static std::map<const void *, std::unique_ptr<Coloring>> &color_cache() {
 }
 void gs_forget_pattern(const void *col_ptr) { color_cache().erase(col_ptr); }
 
-static int get_coloring(const MatView &A, std::unique_ptr<Coloring> &owned, const Coloring **out) {
+static int get_coloring(const MatView &A, std::unique_ptr<Coloring> &owned, const Coloring **out, Arena *arena) {
     if (A.persistent_pattern) {
+        static std::mutex cache_mutex;  // the momentum lanes solve on the same (mesh) pattern at the same time
+        std::lock_guard<std::mutex> lock(cache_mutex);
         auto &cache = color_cache();
         auto it = cache.find((const void *)A.P.col);
         if (it == cache.end()) {
             auto c = std::make_unique<Coloring>();
             ORC_TRY(build_coloring(A.P, *c));
+            static const bool sorted_enabled = !(getenv("ORC_GS_SORTED") && atoi(getenv("ORC_GS_SORTED")) == 0);
+            if (sorted_enabled) ORC_TRY(build_color_sell(A.P, *c));
             it = cache.emplace((const void *)A.P.col, std::move(c)).first;
         }
         *out = it->second.get();
         return ORC_OK;
     }
     owned = std::make_unique<Coloring>();
-    ORC_TRY(build_coloring(A.P, *owned));
+    static const bool sorted_on = !(getenv("ORC_GS_SORTED") && atoi(getenv("ORC_GS_SORTED")) == 0);
+    ORC_TRY(build_coloring(A.P, *owned, arena, !sorted_on));
     *out = owned.get();
     return ORC_OK;
 }
@@ -252,13 +575,27 @@ int gs_arm_dev(const MatView &A, const double *b, double *x, uint64_t iteration_
     hipStream_t st = ctx().stream;
     std::unique_ptr<Coloring> owned;
     const Coloring *C = nullptr;
-    ORC_TRY(get_coloring(A, owned, &C));
     Arena::Mark mk = arena.mark();
+    ORC_TRY(get_coloring(A, owned, &C, &arena));
     int *status;
     ORC_TRY(arena.alloc((size_t)1, &status));
     ORC_HIP(hipMemsetAsync(status, 0, sizeof(int), st));
+    // the matrix in colour-sorted storage: cached layout + this solve's values, or all of it built now (coarse levels)
+    static const bool sorted_enabled = !(getenv("ORC_GS_SORTED") && atoi(getenv("ORC_GS_SORTED")) == 0);
+    SortedView view;
+    if (C->sorted.built) {
+        double *vals;
+        ORC_TRY(arena.alloc((size_t)std::max<int64_t>(C->sorted.padded, 1), &vals));
+        hipLaunchKernelGGL(gs_permute_values_k, dim3(grid_for(n)), dim3(kBlock), 0, st, A, C->sorted.slot_of_row.p, C->sorted.slice_ptr.p, vals);
+        ORC_HIP(hipGetLastError());
+        view.sp = C->sorted.slice_ptr.p; view.row_len = C->sorted.row_len.p; view.rowid = C->sorted.rowid.p; view.diag_off = C->sorted.diag_off.p;
+        view.col = C->sorted.col.p; view.val = vals; view.color_slice = C->sorted.color_slice;
+    } else if (sorted_enabled && !A.persistent_pattern) {
+        ORC_TRY(build_sorted_on_device(A, *C, arena, view));
+    }
+    const SortedView *sv = &view;
     if (method == ORC_SOLVER_MULTICOLOR_GS) {
-        for (uint64_t it = 0; it < iteration_count; ++it) ORC_TRY(gs_sweep(A, *C, b, x, relaxation_factor, status));
+        for (uint64_t it = 0; it < iteration_count; ++it) ORC_TRY(gs_sweep(A, *C, b, x, relaxation_factor, status, sv));
     } else {  // ORC_SOLVER_BICGSTAB_GS_PRECOND: linear_algebra.rs:247-269 with p^ = M^-1 p, s^ = M^-1 s, M^-1 = one GS sweep from 0
         const size_t nn = (size_t)n;
         double *r, *p, *nu, *s, *t, *ph, *sh, *partials, *scal;
@@ -277,12 +614,12 @@ int gs_arm_dev(const MatView &A, const double *b, double *x, uint64_t iteration_
         for (uint64_t it = 0; it < iteration_count; ++it) {
             const int cur = (int)(it & 1), nxt = cur ^ 1;
             ORC_TRY(vec_fill(ph, 0., n));
-            ORC_TRY(gs_sweep(A, *C, p, ph, 1.0, status));
+            ORC_TRY(gs_sweep(A, *C, p, ph, 1.0, status, sv));
             ORC_TRY(spmv_launch(A, ph, EpiSum{nu}, partials, &g, skip));
             ORC_TRY(reduce_partials(partials, g, 1, scal + SUM_NU));
             hipLaunchKernelGGL(bicg_s_pre_k, dim3(vg), dim3(kBlock), 0, st, scal, RHO0 + cur, SUM_NU, r, nu, s, n, guard);
             ORC_TRY(vec_fill(sh, 0., n));
-            ORC_TRY(gs_sweep(A, *C, s, sh, 1.0, status));
+            ORC_TRY(gs_sweep(A, *C, s, sh, 1.0, status, sv));
             ORC_TRY(spmv_launch(A, sh, EpiTsPre{s, t}, partials, &g, skip));
             ORC_TRY(reduce_partials(partials, g, 2, scal + TS));
             hipLaunchKernelGGL(bicg_xr_pre_k, dim3(vg), dim3(kBlock), 0, st, scal, RHO0 + cur, SUM_NU, TS, TT, x, ph, sh, s, t, r, n, partials, guard);
@@ -303,7 +640,7 @@ int gs_debug_coloring(const SellDev &P, std::vector<int> &colors, int *n_colors)
     Coloring C;
     ORC_TRY(build_coloring(P, C));
     colors.resize((size_t)P.n);
-    ORC_TRY(C.color.download(colors.data(), (size_t)P.n));
+    ORC_HIP(hipMemcpy(colors.data(), C.color_p, sizeof(int) * (size_t)P.n, hipMemcpyDeviceToHost));
     *n_colors = C.n_colors;
     return ORC_OK;
 }

@@ -154,7 +154,7 @@ def test_default_stack_is_reproducible_run_to_run(gpu, oracle, mesh_path):
         assert np.array_equal(x, y)
 
 
-@pytest.mark.parametrize("solver", [MULTIGRID, BICGSTAB])
+@pytest.mark.parametrize("solver", [MULTIGRID, BICGSTAB, 17, 18])  # 17 / 18: GS-preconditioned BiCGSTAB / Multigrid with GS smoother
 def test_stream_scheduling_does_not_change_a_bit(gpu, oracle, mesh_path, monkeypatch, solver):
     """The momentum lanes (u, v, w on three streams / host threads), the two-stream Multigrid arm (set-up beside
     smoothing) and the early p' hierarchy (built beside the momentum solves) only reorder independent work: three
