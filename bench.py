@@ -199,6 +199,9 @@ def main():
     free_b, total_b = ctypes.c_int64(0), ctypes.c_int64(0)
     orc_amd._lib.check(orc_amd._lib.lib().orc_device_memory(ctypes.byref(free_b), ctypes.byref(total_b)))
     hbm_used_gb = (total_b.value - free_b.value) / 1e9
+    key = (args.nx, args.ny, args.nz, args.momentum, args.solver)
+    workload_name = ("BASELINE configs[3]" if key == (400, 160, 160, "umist", "multigrid")
+                     else "BASELINE configs[2]" if key == (512, 2016, 1, "quick", "bicgstab_gs") else "custom")
     bicg_bytes = 2.0 * spmv_bytes + 104.0 * n_local
     # HBM traffic per launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes,
     # MI355X_MICROARCH.md §HBM): bench.py cannot collect counters itself, so it quotes the committed profile of the
@@ -230,9 +233,9 @@ def main():
             "status": int(st),
             "reseeds": int(reseeds),
             "config": {
-                "workload": "BASELINE configs[3]: synthetic hex channel %dx%dx%d per GPU (%d cells total), TVD-%s momentum, "
+                "workload": "%s: synthetic hex channel %dx%dx%d per GPU (%d cells total), TVD-%s momentum, "
                             "Rhie-Chow + SecondOrder, solver=%s (%d inner iterations) + Jacobi preconditioner, relaxation u %.3g / p %.3g, "
-                            "full SIMPLE iteration" % (nx, ny, nz, n_cells_total, args.momentum.upper(), args.solver, args.inner,
+                            "full SIMPLE iteration" % (workload_name, nx, ny, nz, n_cells_total, args.momentum.upper(), args.solver, args.inner,
                                                        args.momentum_relaxation, args.pressure_relaxation),
                 "cells_total": int(n_cells_total),
                 "parallelism": "cell slabs x%d, RCCL halo + all-reduce" % world if world > 1 else "single GPU",
