@@ -8,7 +8,8 @@
 //   ORC_SOLVER_MULTIGRID_GS         the Multigrid arm with GS sweeps as its smoother (amg.hip).
 // Rows of one colour share no matrix entry, so a colour is one fully parallel kernel and the sweep is a true
 // Gauss-Seidel in colour order; the row sum runs in ascending-column order like everything else.
-// Colouring: Jones-Plassmann with a deterministic hash priority and first-fit colours (64-bit mask), on the device.
+// Colouring: speculative first-fit with conflict resolution by a deterministic hash priority (64-bit colour mask), on
+// the device; the one-class-per-round Jones-Plassmann variant is kept behind ORC_GS_JONES_PLASSMANN=1.
 #include <algorithm>
 #include <cmath>
 #include <map>
@@ -63,6 +64,8 @@ __device__ __forceinline__ bool prio_greater(int a, int b) {  // strict total or
     return ha > hb || (ha == hb && a > b);
 }
 
+__device__ __forceinline__ int64_t row_base_sell(const SellDev &P, int64_t i) { return P.slice_ptr[i >> 6] + (i & 63); }
+
 // one Jones-Plassmann round: an uncoloured row whose priority beats all its uncoloured neighbours takes the smallest
 // colour none of its coloured neighbours has.  Reads the colours committed by earlier rounds only (colour_in).
 __global__ void jp_round_k(SellDev P, const int *__restrict__ color_in, int *__restrict__ color_out, int *__restrict__ remaining, int *__restrict__ overflow) {
@@ -86,6 +89,49 @@ __global__ void jp_round_k(SellDev P, const int *__restrict__ color_in, int *__r
     }
 }
 
+// Speculative first-fit colouring with conflict resolution (Gebremedhin-Manne), two kernels per round, Jacobi style so
+// that the result does not depend on scheduling: every uncoloured row takes the smallest colour none of its neighbours
+// holds in the previous round's state (tentative), then a row that shares its tentative colour with a neighbour coloured
+// in the same round gives it up if the neighbour has the higher priority.  A handful of rounds whatever the row
+// lengths, where one Jones-Plassmann colour per round needs ~160 rounds on the coarse AMG levels (150 neighbours).
+__global__ void spec_assign_k(SellDev P, const int *__restrict__ color_in, int *__restrict__ color_out, int *__restrict__ overflow) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P.n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ci = color_in[i];
+        if (ci >= 0) { color_out[i] = ci; continue; }
+        const int len = P.row_len[i];
+        const int64_t base = row_base_sell(P, i);
+        unsigned long long used = 0ull;
+        for (int k = 0; k < len; ++k) {
+            const int j = P.col[base + (int64_t)k * 64];
+            if (j == i || j >= P.n) continue;
+            const int cj = color_in[j];
+            if (cj >= 0) used |= 1ull << cj;
+        }
+        const unsigned long long freec = ~used;
+        if (freec == 0ull) { atomicExch(overflow, 1); color_out[i] = -1; continue; }
+        color_out[i] = __ffsll((long long)freec) - 1;
+    }
+}
+// color_prev: state before this round (-1 = was uncoloured), color_tent: after the tentative assignment; the outcome
+// goes to a third array, so every row sees the same tentative state whatever the scheduling.
+__global__ void spec_resolve_k(SellDev P, const int *__restrict__ color_prev, const int *__restrict__ color_tent, int *__restrict__ color_out,
+                               int *__restrict__ remaining) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P.n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ci = color_tent[i];
+        if (color_prev[i] >= 0 || ci < 0) { color_out[i] = ci; if (ci < 0) atomicAdd(remaining, 1); continue; }
+        const int len = P.row_len[i];
+        const int64_t base = row_base_sell(P, i);
+        bool lose = false;
+        for (int k = 0; k < len && !lose; ++k) {
+            const int j = P.col[base + (int64_t)k * 64];
+            if (j == i || j >= P.n) continue;
+            if (color_prev[j] < 0 && color_tent[j] == ci && prio_greater(j, (int)i)) lose = true;
+        }
+        color_out[i] = lose ? -1 : ci;
+        if (lose) atomicAdd(remaining, 1);
+    }
+}
+
 __global__ void color_count_k(const int *__restrict__ color, int64_t n, int *__restrict__ counts) {
     __shared__ int local[64];  // per-workgroup histogram: 64 global atomics per workgroup instead of one per row
     if (threadIdx.x < 64) local[threadIdx.x] = 0;
@@ -102,28 +148,36 @@ static int build_coloring(const SellDev &P, Coloring &C, Arena *arena = nullptr,
     const int64_t n = P.n;
     const size_t nn = (size_t)std::max<int64_t>(n, 1);
     hipStream_t st = ctx().stream;
-    DevBuf<int> tmp_b, flags_b, counts_b;
-    int *tmp, *flags, *counts;
+    DevBuf<int> tmp_b, tent_b, flags_b, counts_b;
+    int *tmp, *tent, *flags, *counts;
     if (arena) {  // per-solve colouring: no hipMalloc / hipFree inside the SIMPLE loop
         ORC_TRY(arena->alloc(nn, &C.color_p));
         ORC_TRY(arena->alloc(nn, &C.rows_p));
         ORC_TRY(arena->alloc(nn, &tmp));
+        ORC_TRY(arena->alloc(nn, &tent));
         ORC_TRY(arena->alloc((size_t)2, &flags));
         ORC_TRY(arena->alloc((size_t)128, &counts));
     } else {
         ORC_TRY(C.color.alloc(nn));
         ORC_TRY(C.rows.alloc(nn));
         ORC_TRY(tmp_b.alloc(nn));
+        ORC_TRY(tent_b.alloc(nn));
         ORC_TRY(flags_b.alloc(2));
         ORC_TRY(counts_b.alloc(128));
-        C.color_p = C.color.p; C.rows_p = C.rows.p; tmp = tmp_b.p; flags = flags_b.p; counts = counts_b.p;
+        C.color_p = C.color.p; C.rows_p = C.rows.p; tmp = tmp_b.p; tent = tent_b.p; flags = flags_b.p; counts = counts_b.p;
     }
     ORC_HIP(hipMemsetAsync(C.color_p, 0xff, sizeof(int) * (size_t)n, st));
     int *in = C.color_p, *out = tmp;
     const int g = grid_for(n);
+    static const bool speculative = !(getenv("ORC_GS_JONES_PLASSMANN") && atoi(getenv("ORC_GS_JONES_PLASSMANN")) != 0);
     for (int round = 0; round < 10000; ++round) {
         ORC_HIP(hipMemsetAsync(flags, 0, 2 * sizeof(int), st));
-        hipLaunchKernelGGL(jp_round_k, dim3(g), dim3(kBlock), 0, st, P, in, out, flags, flags + 1);
+        if (speculative) {
+            hipLaunchKernelGGL(spec_assign_k, dim3(g), dim3(kBlock), 0, st, P, in, tent, flags + 1);
+            hipLaunchKernelGGL(spec_resolve_k, dim3(g), dim3(kBlock), 0, st, P, in, tent, out, flags);
+        } else {
+            hipLaunchKernelGGL(jp_round_k, dim3(g), dim3(kBlock), 0, st, P, in, out, flags, flags + 1);
+        }
         ORC_HIP(hipGetLastError());
         int h[2];
         ORC_HIP(hipMemcpyAsync(h, flags, sizeof(h), hipMemcpyDeviceToHost, st));
