@@ -559,7 +559,7 @@ int orc_mesh_sync_zones(OrcMesh *m, const OrcMeshData *d) {
 // ---- io.rs:573-620
 int orc_write_data(const char *path, int64_t n_cells, const double *cell_centroid, const double *u, const double *v, const double *w,
                    const double *p, int decimal_precision) {
-    if (!path || !cell_centroid || !u || !v || !w || !p || n_cells < 0) return set_error(ORC_ERR_BAD_ARGUMENT, "null argument");
+    if (!path || n_cells < 0 || (n_cells > 0 && (!cell_centroid || !u || !v || !w || !p))) return set_error(ORC_ERR_BAD_ARGUMENT, "null argument");
     std::string out;
     out.reserve((size_t)n_cells * 96);
     for (int64_t i = 0; i < n_cells; ++i) {
