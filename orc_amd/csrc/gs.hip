@@ -617,6 +617,7 @@ static int spmv_launch(const MatView &A, const double *x, const Epi &epi, double
     if (g >= 8) g = (g / 8) * 8;
     if (g < 1) g = 1;
     *grid_out = (int)g;
+    if (A.halo) ORC_TRY(A.halo->exchange(const_cast<double *>(x)));  // C1: refresh the ghost entries of x
     hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi>), dim3((unsigned)g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip);
     ORC_HIP(hipGetLastError());
     return ORC_OK;
@@ -625,7 +626,10 @@ static int spmv_launch(const MatView &A, const double *x, const Epi &epi, double
 int gs_arm_dev(const MatView &A, const double *b, double *x, uint64_t iteration_count, double relaxation_factor, int method, Arena &arena) {
     const int64_t n = A.P.n;
     if (n == 0) return ORC_OK;
-    if (A.halo) return set_error(ORC_ERR_UNSUPPORTED_SOLVER, "the multicolour Gauss-Seidel extension is single-GPU in this round");
+    // Partitioned operator: every rank colours and sweeps its own rows; the ghost entries of the swept vector are refreshed
+    // once per sweep, so rows along a cut see their remote neighbours as of the previous sweep (processor-block
+    // Gauss-Seidel: Gauss-Seidel inside a rank, Jacobi across the cuts).  Reductions are summed over the ranks.
+    const bool global = A.halo != nullptr && ctx().world > 1;
     hipStream_t st = ctx().stream;
     std::unique_ptr<Coloring> owned;
     const Coloring *C = nullptr;
@@ -649,9 +653,12 @@ int gs_arm_dev(const MatView &A, const double *b, double *x, uint64_t iteration_
     }
     const SortedView *sv = &view;
     if (method == ORC_SOLVER_MULTICOLOR_GS) {
-        for (uint64_t it = 0; it < iteration_count; ++it) ORC_TRY(gs_sweep(A, *C, b, x, relaxation_factor, status, sv));
+        for (uint64_t it = 0; it < iteration_count; ++it) {
+            if (A.halo) ORC_TRY(A.halo->exchange(x));
+            ORC_TRY(gs_sweep(A, *C, b, x, relaxation_factor, status, sv));
+        }
     } else {  // ORC_SOLVER_BICGSTAB_GS_PRECOND: linear_algebra.rs:247-269 with p^ = M^-1 p, s^ = M^-1 s, M^-1 = one GS sweep from 0
-        const size_t nn = (size_t)n;
+        const size_t nn = (size_t)std::max(A.P.ncols, n);  // products gather ghost entries of p^ and s^
         double *r, *p, *nu, *s, *t, *ph, *sh, *partials, *scal;
         ORC_TRY(arena.alloc(nn, &r)); ORC_TRY(arena.alloc(nn, &p)); ORC_TRY(arena.alloc(nn, &nu)); ORC_TRY(arena.alloc(nn, &s));
         ORC_TRY(arena.alloc(nn, &t)); ORC_TRY(arena.alloc(nn, &ph)); ORC_TRY(arena.alloc(nn, &sh));
@@ -664,20 +671,20 @@ int gs_arm_dev(const MatView &A, const double *b, double *x, uint64_t iteration_
         const int vg = grid_for(n);
         int g = 0;
         ORC_TRY(spmv_launch(A, x, EpiRes{b, r, p}, partials, &g));
-        ORC_TRY(reduce_partials(partials, g, 1, scal + RHO0));
+        ORC_TRY(reduce_partials(partials, g, 1, scal + RHO0, global));
         for (uint64_t it = 0; it < iteration_count; ++it) {
             const int cur = (int)(it & 1), nxt = cur ^ 1;
-            ORC_TRY(vec_fill(ph, 0., n));
+            ORC_TRY(vec_fill(ph, 0., (int64_t)nn));  // ghost entries too: the preconditioner is rank-local
             ORC_TRY(gs_sweep(A, *C, p, ph, 1.0, status, sv));
             ORC_TRY(spmv_launch(A, ph, EpiSum{nu}, partials, &g, skip));
-            ORC_TRY(reduce_partials(partials, g, 1, scal + SUM_NU));
+            ORC_TRY(reduce_partials(partials, g, 1, scal + SUM_NU, global));
             hipLaunchKernelGGL(bicg_s_pre_k, dim3(vg), dim3(kBlock), 0, st, scal, RHO0 + cur, SUM_NU, r, nu, s, n, guard);
-            ORC_TRY(vec_fill(sh, 0., n));
+            ORC_TRY(vec_fill(sh, 0., (int64_t)nn));
             ORC_TRY(gs_sweep(A, *C, s, sh, 1.0, status, sv));
             ORC_TRY(spmv_launch(A, sh, EpiTsPre{s, t}, partials, &g, skip));
-            ORC_TRY(reduce_partials(partials, g, 2, scal + TS));
+            ORC_TRY(reduce_partials(partials, g, 2, scal + TS, global));
             hipLaunchKernelGGL(bicg_xr_pre_k, dim3(vg), dim3(kBlock), 0, st, scal, RHO0 + cur, SUM_NU, TS, TT, x, ph, sh, s, t, r, n, partials, guard);
-            ORC_TRY(reduce_partials(partials, vg, 1, scal + RHO0 + nxt));
+            ORC_TRY(reduce_partials(partials, vg, 1, scal + RHO0 + nxt, global));
             hipLaunchKernelGGL(bicg_p_pre_k, dim3(vg), dim3(kBlock), 0, st, scal, RHO0 + cur, RHO0 + nxt, SUM_NU, TS, TT, r, nu, p, n, guard);
             ORC_HIP(hipGetLastError());
         }
