@@ -61,10 +61,22 @@ def cpu_baseline(settings_kw, sample=(100, 40, 40), iters=6):
     dt = time.perf_counter() - t0
     n = nx * ny * nz
     it_per_s_sample = iters / dt
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    import shutil
     return {
         "value": it_per_s_sample * n / REF_CELLS,
         "unit": "SIMPLE iterations/s (10.24M-cell equivalent)",
         "cores": 1,
+        "host_cpu": "%s (%d logical cores on the box; ORC's path is single-threaded)" % (cpu_model, os.cpu_count() or 0),
+        "rust_toolchain": "present" if shutil.which("cargo") else "absent (ORC itself cannot be built: the port is timed)",
         "kind": "port",
         "sample": "%dx%dx%d hex channel (%d cells = 1/%d of the workload), %d SIMPLE iterations in %.2f s, status %d; scaled by cells"
                   % (nx, ny, nz, n, REF_CELLS // n, iters, dt, st),
