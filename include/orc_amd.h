@@ -122,6 +122,14 @@ int orc_iterative_solve(int64_t n, const int64_t *row_ptr, const int64_t *col_id
 /* Process-wide default of OrcSettings.breakdown_guard for orc_iterative_solve (whose signature has no
  * settings argument, like the reference's).  1 (default) = guard on; 0 = NaN like the reference. */
 int orc_set_breakdown_guard(int on);
+/* Number of BiCGSTAB solves (process-wide, since the last call with reset != 0) in which the breakdown guard fired, i.e.
+ * in which the reference (linear_algebra.rs:255-268, no test at all) would have divided 0/0 and returned NaN — a caller
+ * that replaces solver::solve_steady (solver.rs:217-221 "solution diverged") can tell that the guard kept it alive.
+ * orc_solve_steady / orc_solver_iterate also leave "breakdown guard fired in N solve(s)" in orc_last_error() when they
+ * return ORC_OK after such an iteration. */
+int64_t orc_breakdown_guard_events(int reset);
+/* Process-wide default of OrcSettings.reduction_order for orc_iterative_solve (OrcReductionOrder). */
+int orc_set_reduction_order(int order);
 /* sweeps the Jacobi arm executed in the last orc_iterative_solve (linear_algebra.rs:188-217) */
 int64_t orc_last_jacobi_sweeps(void);
 /* y = A x: the `&CsrMatrix * &DVector` product the reference takes from nalgebra-sparse

@@ -112,6 +112,13 @@ enum OrcStatus {
     ORC_ERR_NO_BOUNDARY_CONDITIONS = 17 /* solver.rs:770 "You must set boundary conditions." */
 };
 
+/* Association of the solvers' dot products and norms (linear_algebra.rs:97,202,253,257,261,265).
+ * TREE: per-workgroup wave-shuffle trees folded in a fixed order — deterministic, fast, the product default.
+ * REFERENCE: nalgebra 0.32.4's `dotx` order (eight running accumulators over blocks of 8, then the tail), evaluated by
+ * one wavefront — slow, but every iterate of BiCGSTAB / Jacobi / the Multigrid arm is then bit-identical to the
+ * reference's arithmetic at any iteration count (verification mode; single GPU only). */
+enum OrcReductionOrder { ORC_REDUCTION_TREE = 0, ORC_REDUCTION_REFERENCE = 1 };
+
 /* settings::NumericalSettings + settings::MatrixSolverSettings (lib.rs:14-56), flattened.
  * orc_settings_default() fills in lib.rs:58-86. */
 typedef struct OrcSettings {
@@ -133,7 +140,10 @@ typedef struct OrcSettings {
     int32_t breakdown_guard;         /* new-build extension, default 1: BiCGSTAB stops updating x when a denominator of its
                                         recurrences (rho, r_hat.nu, t.t, omega) is exactly 0 or non-finite — the only cases
                                         in which the reference (no guard, linear_algebra.rs:255-268) yields NaN and panics
-                                        "solution diverged".  0 = reference behaviour (NaN propagates). */
+                                        "solution diverged".  0 = reference behaviour (NaN propagates).  Every solve in
+                                        which the guard fired is counted: orc_breakdown_guard_events(). */
+    int32_t reduction_order;         /* OrcReductionOrder; default TREE */
+    int32_t reserved0;
 } OrcSettings;
 
 #ifdef __cplusplus

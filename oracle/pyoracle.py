@@ -29,6 +29,7 @@ class Settings(C.Structure):
         ("iterations", C.c_uint64), ("momentum_relaxation", C.c_double), ("pressure_relaxation", C.c_double),
         ("relaxation", C.c_double), ("relative_convergence_threshold", C.c_double),
         ("frozen_diagonals", C.c_int32), ("breakdown_guard", C.c_int32),
+        ("reduction_order", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 

@@ -919,13 +919,15 @@ static int multigrid_solve_dev(const MatView &A, const double *r, uint64_t level
         ORC_TRY(varena.alloc((size_t)std::max<int64_t>(nc, 1), &e_prime));
         ORC_TRY(varena.alloc((size_t)kMaxPartials, &partials));
         ORC_TRY(varena.alloc((size_t)4, &scal));
+        double *r_check = nullptr;  // reference-order norm (verification mode): the residual is materialised
+        if (ctx().reduction_order == ORC_REDUCTION_REFERENCE) ORC_TRY(varena.alloc((size_t)std::max<int64_t>(nc, 1), &r_check));
         hipLaunchKernelGGL(restrict_k, dim3(grid_for(nc)), dim3(kBlock), 0, vs, choice, n, nc, r, r_prime);  // :82
         ORC_HIP(hipGetLastError());
         ORC_TRY(vec_fill(e_prime, 0., nc));  // :86
         int stt = iterative_solve_dev(Ac, r_prime, e_prime, mp.iters, mp.smoother, mp.relaxation, threshold, mp.preconditioner, varena, stats);  // :87-96
         if (stt != ORC_OK) return leave(stt);
         // :97-105  |r' - a' e'| is NaN -> "Multigrid diverged"
-        ORC_TRY(residual_norm2_dev(Ac, r_prime, e_prime, partials, scal));
+        ORC_TRY(residual_norm2_dev(Ac, r_prime, e_prime, partials, scal, r_check));
         hipLaunchKernelGGL(nan_to_status_k, dim3(1), dim3(64), 0, vs, scal, dev_status, (int)ORC_ERR_MULTIGRID_DIVERGED);
     }
     if (level < mp.max_levels && nc > 16) {  // :109

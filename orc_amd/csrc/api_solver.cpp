@@ -143,9 +143,27 @@ int orc_solver_get_fields(OrcSolver *s, double *u, double *v, double *w, double 
     return ORC_OK;
 }
 
+namespace {
+// A drop-in for solver::solve_steady must not hide that the breakdown guard (default on) kept a solve alive where the
+// reference divides 0/0 and panics "solution diverged" (solver.rs:217-221): an ORC_OK return then carries a note.
+struct GuardNote {
+    int64_t before;
+    GuardNote() : before(orc_breakdown_guard_events(0)) {}
+    void leave(int status) const {
+        if (status != ORC_OK) return;
+        const int64_t fired = orc_breakdown_guard_events(0) - before;
+        if (fired > 0) set_error(ORC_OK, "breakdown guard fired in %lld solve(s): the reference would have returned NaN (linear_algebra.rs:255-268)", (long long)fired);
+        else ctx().last_error.clear();
+    }
+};
+}  // namespace
+
 int orc_solver_iterate(OrcSolver *s, uint64_t iterations, double *report) {
     if (!s) return set_error(ORC_ERR_BAD_ARGUMENT, "null solver");
-    return solver_iterate(s->st, iterations, report);
+    GuardNote note;
+    const int st = solver_iterate(s->st, iterations, report);
+    note.leave(st);
+    return st;
 }
 
 int orc_solver_assemble_momentum(OrcSolver *s, double *a_u, double *a_v, double *a_w, double *b_u, double *b_v, double *b_w,
@@ -291,7 +309,7 @@ namespace {
 OrcSettings initializer_settings(const OrcSettings *settings) {
     OrcSettings t;
     orc_settings_default(&t);
-    if (settings) { t.q1_compat = settings->q1_compat; t.breakdown_guard = settings->breakdown_guard; }
+    if (settings) { t.q1_compat = settings->q1_compat; t.breakdown_guard = settings->breakdown_guard; t.reduction_order = settings->reduction_order; }
     t.momentum = ORC_MOMENTUM_UD;
     t.velocity_interpolation = ORC_VINTERP_LINEAR_WEIGHTED;
     t.pressure_interpolation = ORC_PINTERP_LINEAR_WEIGHTED;
@@ -352,6 +370,7 @@ int orc_solve_steady(OrcMesh *m, double *u, double *v, double *w, double *p, con
     if (!s) return st;
     std::unique_ptr<OrcSolver> guard(s);
     ORC_TRY(orc_solver_set_fields(s, u, v, w, p));
+    GuardNote note;
     auto start = std::chrono::steady_clock::now();
     for (uint64_t it = 1; it <= iteration_count && st == ORC_OK; ++it) {
         double rep[8];
@@ -365,6 +384,7 @@ int orc_solve_steady(OrcMesh *m, double *u, double *v, double *w, double *p, con
         }
     }
     int st2 = orc_solver_get_fields(s, u, v, w, p);  // fields are mutated in place up to a panic
+    note.leave(st != ORC_OK ? st : st2);
     return st != ORC_OK ? st : st2;
 }
 

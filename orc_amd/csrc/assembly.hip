@@ -772,6 +772,7 @@ static int solve_field_on(SolverState &s, DevBuf<double> &a, DevBuf<double> &b, 
     A.persistent_pattern = true;
     const OrcSettings &t = s.settings;
     ctx().breakdown_guard = t.breakdown_guard != 0;
+    ctx().reduction_order = t.reduction_order;
     stats.cache = &s.amg_cache[eq];
     stats.side = nullptr;
     stats.hierarchy = (eq == 3 && s.p_hierarchy.n_levels > 0) ? &s.p_hierarchy : nullptr;
@@ -913,6 +914,7 @@ static int solve_momentum_partitioned(SolverState &s) {
     }
     ORC_HIP(hipStreamSynchronize(g.stream));  // the assembled systems and the scalings are complete
     g.breakdown_guard = t.breakdown_guard != 0;
+    g.reduction_order = ORC_REDUCTION_TREE;  // partitioned operators always reduce as trees + all-reduce
 
     std::mutex mu;
     std::condition_variable cv;
@@ -1175,6 +1177,7 @@ int initialize_flow_dev(SolverState &s, uint64_t iteration_count) {
     ORC_TRY(k_face_flux(s, true));
     ORC_TRY(k_momentum(s, nullptr));  // :288-309 (b += b_di inside)
     ctx().breakdown_guard = s.settings.breakdown_guard != 0;
+    ctx().reduction_order = s.settings.reduction_order;
     const int64_t len = std::max<int64_t>(s.mesh->pat.padded, 1);
     double diffusion_fraction = 1.;
     while (diffusion_fraction >= 0.) {  // :316-349

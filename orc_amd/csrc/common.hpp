@@ -26,6 +26,8 @@ struct Ctx {
     std::string last_error;
     bool profile = false;
     bool breakdown_guard = true;  // OrcSettings.breakdown_guard of the running solve
+    int reduction_order = 0;      // OrcReductionOrder of the running solve: 0 = wave trees, 1 = the reference's (nalgebra) association
+    int *guard_events = nullptr;  // device counter: BiCGSTAB solves in which the breakdown guard fired (orc_breakdown_guard_events)
     // multi-GPU (comm.cpp)
     int rank = 0, world = 1;
     void *nccl_comm = nullptr;
@@ -131,9 +133,11 @@ __device__ __forceinline__ double wave_sum(double v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     return v;
 }
+// max that keeps a NaN (fmax drops it): the reference's max_by(total_cmp) ranks NaN above every number
+__device__ __forceinline__ double max_nan(double a, double b) { return (a != a || b != b) ? __builtin_nan("") : fmax(a, b); }
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+    for (int off = 32; off > 0; off >>= 1) v = max_nan(v, __shfl_down(v, off, 64));
     return v;
 }
 // Sum over the workgroup (256 threads = 4 waves); result valid in thread 0.
@@ -160,7 +164,7 @@ __device__ __forceinline__ double block_max(double v, double *lds) {
     if (threadIdx.x == 0) {
         const int nw = (blockDim.x + 63) >> 6;
         r = lds[0];
-        for (int i = 1; i < nw; i++) r = fmax(r, lds[i]);
+        for (int i = 1; i < nw; i++) r = max_nan(r, lds[i]);
     }
     return r;
 }

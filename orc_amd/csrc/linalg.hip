@@ -38,6 +38,61 @@ int reduce_partials(const double *partials, int count, int nq, double *out, bool
     return ORC_OK;
 }
 
+// ------------------------------------------------------------------ reference-order reductions (verification mode)
+// OrcSettings.reduction_order = ORC_REDUCTION_REFERENCE: every dot product / norm of the solvers is evaluated in the
+// association of nalgebra 0.32.4's `dotx` (base/blas.rs; restated in oracle/sparse.c or_dot): eight running accumulators
+// over blocks of 8, folded as res += (acc0+acc4); (acc1+acc5); (acc2+acc6); (acc3+acc7), then the tail left to right.
+// Lane k of one wavefront owns accumulator k and walks its elements in order — n/8 dependent additions, so this is a
+// slow path (microseconds per thousand rows); it exists so that a device solve can be compared with the reference's
+// arithmetic BIT FOR BIT at any iteration count, instead of through tolerances that the unguarded r_hat_0 = 1
+// BiCGSTAB (linear_algebra.rs:252) amplifies.  a == nullptr stands for the all-ones r_hat_0 (1.0 * b[i] == b[i]).
+__global__ __launch_bounds__(64) void dot_reference_k(const double *__restrict__ a, const double *__restrict__ b, int64_t n,
+                                                      double *__restrict__ out, const double *__restrict__ skip_flags) {
+    if (skip_flags && (skip_flags[0] != 0. || skip_flags[1] != 0.)) return;
+    const int lane = threadIdx.x;
+    const int64_t blocks = n >> 3;
+    double acc = 0.;
+    if (lane < 8) {
+        int64_t j = 0;
+        for (; j + 8 <= blocks; j += 8) {  // eight blocks' loads in flight, additions in block order
+            double pa[8], pb[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int64_t i = ((j + q) << 3) + lane;
+                pb[q] = b[i];
+                pa[q] = a ? a[i] : 1.;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc += pa[q] * pb[q];
+        }
+        for (; j < blocks; ++j) {
+            const int64_t i = (j << 3) + lane;
+            acc += (a ? a[i] : 1.) * b[i];
+        }
+    }
+    // lane k < 4 forms acc_k + acc_{k+4}; lane 0 adds the four pairs and the tail in order
+    const double hi = __shfl_down(acc, 4, 64);
+    const double pair = acc + hi;
+    const double p1 = __shfl(pair, 1, 64), p2 = __shfl(pair, 2, 64), p3 = __shfl(pair, 3, 64);
+    if (lane == 0) {
+        double res = 0.;
+        res += pair;
+        res += p1;
+        res += p2;
+        res += p3;
+        for (int64_t k = blocks << 3; k < n; ++k) res += (a ? a[k] : 1.) * b[k];
+        out[0] = res;
+    }
+}
+
+int dot_reference(const double *a, const double *b, int64_t n, double *out, const double *skip_flags) {
+    hipLaunchKernelGGL(dot_reference_k, dim3(1), dim3(64), 0, ctx().stream, a, b, n, out, skip_flags);
+    ORC_HIP(hipGetLastError());
+    return ORC_OK;
+}
+
+static inline bool reference_order(const MatView &A) { return ctx().reduction_order == ORC_REDUCTION_REFERENCE && A.halo == nullptr; }
+
 static inline int spmv_grid(int32_t n_slices) {
     int64_t g = ((int64_t)n_slices + 3) / 4;  // 4 waves (slices) per workgroup
     if (g > kMaxGrid) g = kMaxGrid;
@@ -236,9 +291,11 @@ int residual_dev(const MatView &A, const double *b, const double *x, double *r) 
     return launch_spmv(A, x, EpiResidual{b, r, nullptr}, dummy, &g);
 }
 
-int residual_norm2_dev(const MatView &A, const double *b, const double *x, double *partials, double *out) {
+int residual_norm2_dev(const MatView &A, const double *b, const double *x, double *partials, double *out, double *r_scratch) {
     int g = 0;
-    ORC_TRY(launch_spmv(A, x, EpiResidualNorm{b, nullptr}, partials, &g));
+    const bool ref = reference_order(A) && r_scratch != nullptr;
+    ORC_TRY(launch_spmv(A, x, EpiResidualNorm{b, ref ? r_scratch : nullptr}, partials, &g));
+    if (ref) return dot_reference(r_scratch, r_scratch, A.P.n, out, nullptr);
     return reduce_partials(partials, g, 1, out, A.halo != nullptr);
 }
 
@@ -347,6 +404,12 @@ __global__ void bicg_p_k(double *__restrict__ scal, int rho_prev_idx, int rho_id
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) p[n - 1] = r[n - 1] + beta * (p[n - 1] - omega * nu[n - 1]);
 }
 
+// one more solve in which the guard fired (orc_breakdown_guard_events): a drop-in caller must be able to tell that the
+// reference would have produced NaN here
+__global__ void guard_event_k(const double *__restrict__ scal, int *__restrict__ counter) {
+    if (scal[S_FROZEN] != 0. || scal[S_FROZEN2] != 0.) atomicAdd(counter, 1);
+}
+
 struct BicgWork {
     double *r, *p, *nu, *s, *t, *partials, *scal;
 };
@@ -370,13 +433,19 @@ static int bicg_iteration(const MatView &A, double *x, const BicgWork &w, uint64
     const int cur = (int)(it & 1), nxt = cur ^ 1;
     const double *skip = guard ? w.scal + S_FROZEN : nullptr;  // frozen solves skip their SpMVs too
     int g = 0;
+    const bool ref = reference_order(A);  // dot products in nalgebra's association (verification mode)
     ORC_TRY(launch_spmv(A, w.p, EpiStoreSum{w.nu}, w.partials, &g, skip));     // nu = A p, sum(nu)
-    ORC_TRY(reduce_partials(w.partials, g, 1, w.scal + S_SUM_NU, A.halo != nullptr));
+    if (ref) ORC_TRY(dot_reference(nullptr, w.nu, n, w.scal + S_SUM_NU, skip));            // r_hat_0 . nu  (:257)
+    else ORC_TRY(reduce_partials(w.partials, g, 1, w.scal + S_SUM_NU, A.halo != nullptr));
     hipLaunchKernelGGL(bicg_s_k, dim3(vg), dim3(kBlock), 0, ctx().stream, w.scal, S_RHO0 + cur, w.r, w.nu, w.s, n, guard);
     ORC_TRY(launch_spmv(A, w.s, EpiTs{w.s, w.t}, w.partials, &g, skip));       // t = A s, t.s, t.t
-    ORC_TRY(reduce_partials(w.partials, g, 2, w.scal + S_TS, A.halo != nullptr));
+    if (ref) {
+        ORC_TRY(dot_reference(w.t, w.s, n, w.scal + S_TS, skip));                          // t . s, t . t  (:261)
+        ORC_TRY(dot_reference(w.t, w.t, n, w.scal + S_TT, skip));
+    } else ORC_TRY(reduce_partials(w.partials, g, 2, w.scal + S_TS, A.halo != nullptr));
     hipLaunchKernelGGL(bicg_xr_k, dim3(vg), dim3(kBlock), 0, ctx().stream, w.scal, S_RHO0 + cur, x, w.p, w.s, w.t, w.r, n, w.partials, guard);
-    ORC_TRY(reduce_partials(w.partials, vg, 1, w.scal + S_RHO0 + nxt, A.halo != nullptr));  // rho = r_hat_0 . r
+    if (ref) ORC_TRY(dot_reference(nullptr, w.r, n, w.scal + S_RHO0 + nxt, skip));  // rho = r_hat_0 . r  (:265)
+    else ORC_TRY(reduce_partials(w.partials, vg, 1, w.scal + S_RHO0 + nxt, A.halo != nullptr));  // rho = r_hat_0 . r
     hipLaunchKernelGGL(bicg_p_k, dim3(vg), dim3(kBlock), 0, ctx().stream, w.scal, S_RHO0 + cur, S_RHO0 + nxt, w.r, w.nu, w.p, n, guard);
     ORC_HIP(hipGetLastError());
     return ORC_OK;
@@ -391,8 +460,13 @@ static int bicgstab_dev(const MatView &A, const double *b, double *x, uint64_t i
     const int guard = ctx().breakdown_guard ? 1 : 0;
     int g = 0;
     ORC_TRY(launch_spmv(A, x, EpiResidual{b, w.r, w.p}, w.partials, &g));      // r = b - A x ; p = r ; rho = sum(r)
-    ORC_TRY(reduce_partials(w.partials, g, 1, w.scal + S_RHO0, A.halo != nullptr));
+    if (reference_order(A)) ORC_TRY(dot_reference(nullptr, w.r, n, w.scal + S_RHO0, nullptr));  // r . r_hat_0  (:253)
+    else ORC_TRY(reduce_partials(w.partials, g, 1, w.scal + S_RHO0, A.halo != nullptr));
     for (uint64_t it = 0; it < iteration_count; ++it) ORC_TRY(bicg_iteration(A, x, w, it, guard));
+    if (guard && ctx().guard_events) {
+        hipLaunchKernelGGL(guard_event_k, dim3(1), dim3(1), 0, ctx().stream, w.scal, ctx().guard_events);
+        ORC_HIP(hipGetLastError());
+    }
     arena.release(mk);
     return ORC_OK;
 }
@@ -493,7 +567,7 @@ __global__ __launch_bounds__(kBlock) void jacobi_residual_k(MatView A, const dou
         if (live) {
             const double v = b[row] - acc;
             r2 += v * v;
-            mx = fmax(mx, fabs(x[row]));
+            mx = max_nan(mx, fabs(x[row]));
         }
     }
     const double t = block_sum(r2, lds);
@@ -505,18 +579,20 @@ __global__ __launch_bounds__(kBlock) void jacobi_residual_k(MatView A, const dou
 __global__ __launch_bounds__(1024) void reduce_max_k(const double *__restrict__ partials, int count, double *__restrict__ out) {
     __shared__ double lds[16];
     double v = 0.;
-    for (int i = threadIdx.x; i < count; i += blockDim.x) v = fmax(v, partials[i]);
+    for (int i = threadIdx.x; i < count; i += blockDim.x) v = max_nan(v, partials[i]);
     v = wave_max(v);
     if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
     __syncthreads();
     if (threadIdx.x == 0) {
         double r = lds[0];
-        for (int i = 1; i < (int)(blockDim.x >> 6); ++i) r = fmax(r, lds[i]);
+        for (int i = 1; i < (int)(blockDim.x >> 6); ++i) r = max_nan(r, lds[i]);
         out[0] = r;
     }
 }
 
-// one thread: the reference's per-sweep bookkeeping (:208-216); red[0] = sum((b - A x)^2), red[1] = max |x|
+// one thread: the reference's per-sweep bookkeeping (:208-216); red[0] = sum((b - A x)^2), red[1] = max |x| — NaN when x
+// holds one: max_by(total_cmp) (:203-207) ranks NaN above everything, `NaN > 1e10` is false, and the next sweep's
+// NaN check (:192-196) is what panics
 __global__ void jacobi_control_k(const double *__restrict__ red, double threshold, JacobiCtrl *ctrl) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (ctrl->done || ctrl->status) return;
@@ -543,6 +619,12 @@ static int jacobi_dev(const MatView &A, const double *b, double *x, uint64_t ite
     ORC_TRY(arena.alloc((size_t)2, &red));
     ORC_TRY(arena.alloc((size_t)1, &ctrl));
     ORC_HIP(hipMemsetAsync(ctrl, 0, sizeof(JacobiCtrl), ctx().stream));
+    const bool ref = reference_order(A);
+    double *rvec = nullptr, *ref_partials = nullptr;
+    if (ref) {
+        ORC_TRY(arena.alloc((size_t)n, &rvec));
+        ORC_TRY(arena.alloc((size_t)kMaxPartials, &ref_partials));
+    }
     const int g = spmv_grid(A.P.n_slices);
     // Sweeps alternate x -> x2 -> x.  A sweep that is skipped (done/status set) leaves both
     // buffers untouched, so the newest iterate is in x2 iff the executed sweep count is odd.
@@ -553,6 +635,11 @@ static int jacobi_dev(const MatView &A, const double *b, double *x, uint64_t ite
         if (global) ORC_TRY(A.halo->exchange(nxt));
         hipLaunchKernelGGL(jacobi_residual_k, dim3(g), dim3(kBlock), 0, ctx().stream, A, b, nxt, partials, ctrl);
         ORC_TRY(reduce_partials(partials, g, 1, red, global));
+        if (ref) {  // |b - A x|^2 in nalgebra's association (:202); a sweep past the break recomputes a value nobody reads
+            int g2 = 0;
+            ORC_TRY(launch_spmv(A, nxt, EpiResidualNorm{b, rvec}, ref_partials, &g2));
+            ORC_TRY(dot_reference(rvec, rvec, n, red, nullptr));
+        }
         hipLaunchKernelGGL(reduce_max_k, dim3(1), dim3(1024), 0, ctx().stream, partials + g, g, red + 1);
         if (global) ORC_TRY(comm_allreduce_max(red + 1, 1));
         hipLaunchKernelGGL(jacobi_control_k, dim3(1), dim3(1), 0, ctx().stream, red, threshold, ctrl);

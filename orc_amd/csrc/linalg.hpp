@@ -127,7 +127,10 @@ int bench_bicgstab_dev(const MatView &A, const double *b, double *x, int reps, A
 
 // r = b - A x ;  out[0] = sum((b - A x)^2) (NaN iff the reference's .norm() is NaN)
 int residual_dev(const MatView &A, const double *b, const double *x, double *r);
-int residual_norm2_dev(const MatView &A, const double *b, const double *x, double *partials, double *out);
+// r_scratch (n doubles, optional): where the residual is kept when the norm is to be summed in the reference's order
+int residual_norm2_dev(const MatView &A, const double *b, const double *x, double *partials, double *out, double *r_scratch = nullptr);
+// out[0] = a . b in nalgebra's dotx association (a == nullptr: the all-ones vector); one wavefront, verification mode only
+int dot_reference(const double *a, const double *b, int64_t n, double *out, const double *skip_flags);
 
 // plain vector helpers used by the SIMPLE driver
 int vec_fill(double *x, double v, int64_t n);

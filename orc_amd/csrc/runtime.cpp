@@ -89,6 +89,9 @@ int orc_init(int device_ordinal) {
     if (c.stream) { (void)hipStreamDestroy(c.stream); c.stream = nullptr; }
     ORC_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
     c.device = device_ordinal;
+    if (c.guard_events) { (void)hipFree(c.guard_events); c.guard_events = nullptr; }
+    ORC_HIP(hipMalloc((void **)&c.guard_events, sizeof(int)));
+    ORC_HIP(hipMemset(c.guard_events, 0, sizeof(int)));
     c.inited = true;
     return ORC_OK;
 }
@@ -151,11 +154,28 @@ void orc_settings_default(OrcSettings *s) {  // lib.rs:58-86
     s->q1_compat = 1;
     s->breakdown_guard = 1;
     s->frozen_diagonals = 1;  // the device evaluates all Rhie-Chow diagonals from the previous iteration
+    s->reduction_order = ORC_REDUCTION_TREE;
 }
 
 int orc_set_breakdown_guard(int on) {
     orc::ctx().breakdown_guard = on != 0;
     return ORC_OK;
+}
+
+int orc_set_reduction_order(int order) {
+    if (order != ORC_REDUCTION_TREE && order != ORC_REDUCTION_REFERENCE) return orc::set_error(ORC_ERR_BAD_ARGUMENT, "unknown reduction order %d", order);
+    orc::ctx().reduction_order = order;
+    return ORC_OK;
+}
+
+int64_t orc_breakdown_guard_events(int reset) {
+    orc::Ctx &c = orc::ctx();
+    if (!c.inited || !c.guard_events) return 0;
+    int h = 0;
+    if (hipStreamSynchronize(c.stream) != hipSuccess) return -1;
+    if (hipMemcpy(&h, c.guard_events, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (reset && hipMemset(c.guard_events, 0, sizeof(int)) != hipSuccess) return -1;
+    return h;
 }
 
 int orc_profile_enable(int on) {

@@ -41,6 +41,18 @@ def set_breakdown_guard(on):
     check(lib().orc_set_breakdown_guard(C.c_int(1 if on else 0)))
 
 
+def set_reduction_order(order):
+    """process-wide OrcSettings.reduction_order for iterative_solve: 0 = wave trees (default), 1 = the reference's
+    (nalgebra dotx) association, bit-identical iterates (verification mode)"""
+    check(lib().orc_set_reduction_order(C.c_int(int(order))))
+
+
+def breakdown_guard_events(reset=False):
+    """BiCGSTAB solves in which the breakdown guard fired since the last reset (the reference would have returned NaN)"""
+    lib().orc_breakdown_guard_events.restype = C.c_int64
+    return int(lib().orc_breakdown_guard_events(C.c_int(1 if reset else 0)))
+
+
 def last_jacobi_sweeps():
     return lib().orc_last_jacobi_sweeps()
 

@@ -13,6 +13,7 @@ class NumericalSettings(C.Structure):
         ("iterations", C.c_uint64), ("momentum_relaxation", C.c_double), ("pressure_relaxation", C.c_double),
         ("relaxation", C.c_double), ("relative_convergence_threshold", C.c_double),
         ("frozen_diagonals", C.c_int32), ("breakdown_guard", C.c_int32),
+        ("reduction_order", C.c_int32), ("reserved0", C.c_int32),
     ]
 
     @classmethod
@@ -42,6 +43,10 @@ class VelocityInterpolation:  # lib.rs:135-146
 class SolutionMethod:  # lib.rs:171-179 (+ new-build extensions)
     GaussSeidel, Jacobi, Multigrid, BiCGSTAB = range(4)
     MulticolorGS, BiCGSTAB_GS, Multigrid_GS = 16, 17, 18
+
+
+class ReductionOrder:  # include/orc_types.h OrcReductionOrder
+    Tree, Reference = 0, 1
 
 
 class PreconditionMethod:  # lib.rs:181-185
