@@ -5,7 +5,9 @@ One "step" = one full SIMPLE iteration of solver::solve_steady (solver.rs:60-222
 momentum solves, pressure-correction assembly + solve, correction — all device-resident in liborc_amd.so.
 N = 1: 400 x 160 x 160 = 10 240 000 hex cells, UMIST TVD momentum, Rhie-Chow, SecondOrder,
 reference Multigrid arm (pairwise-aggregation AMG with BiCGSTAB smoother) + Jacobi preconditioning.
-N > 1: weak scaling, every rank owns a 400 x 160 x 160 slab of a (400 N) x 160 x 160 channel.
+N > 1: weak scaling, every rank owns a 400 x 160 x 160 slab of a 400 x 160 x (160 N) channel.
+Every warm-up and timed step restores the same device-side snapshot (state after two spin-up iterations) and runs one
+full SIMPLE iteration, so all steps do identical work (the reference algorithm itself diverges on this mesh).
 
 Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (CSR SpMV inside BiCGSTAB, HBM bound,
 measured live with HIP events on the library stream) and `cpu_baseline` (the CPU oracle = restatement of
@@ -98,6 +100,7 @@ def main():
     ap.add_argument("--pressure-relaxation", type=float, default=0.001)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--spmv-reps", type=int, default=50)
+    ap.add_argument("--levels-csv", default=None, help="write the per-level product table (profiles/rNN_levels.csv)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -164,33 +167,40 @@ def main():
             torch.cuda.synchronize()
 
     # The reference algorithm (fixed-count, unguarded inner solves; no implicit momentum under-relaxation) does not
-    # converge on a mesh this fine: the CPU oracle and the device diverge alike.  Its per-iteration work
-    # does not depend on the field values, so the benchmark keeps the fields finite by re-seeding them whenever an
-    # iteration ends in the reference's "solution diverged" panic (or the corrections exceed 1e30); re-seeds are counted
-    # in the JSON line and their upload time stays inside the timed region.
-    seed_fields = solver.get_fields()
-    reseeds = 0
+    # converge on a mesh this fine: the CPU oracle and the device diverge alike, and the work of an
+    # iteration DOES depend on the field state (coarse AMG operators get denser as the fields degrade).  So that every
+    # timed step does identical work, the benchmark times ONE iteration of the trajectory repeatedly: two untimed
+    # spin-up iterations from the seeded fields, a device-side snapshot of the state (u, v, w, p, momentum diagonals),
+    # then every warm-up and timed step = restore the snapshot (device-to-device, 0.57 GB, inside the timed region)
+    # + one full SIMPLE iteration (iteration 3 of the run).  Nothing is skipped or cached between steps: assembly,
+    # the four hierarchy set-ups and all solves run in full each time.
+    SPIN_UP = 2
+    for _ in range(SPIN_UP):
+        st_, _ = solver.iterate(1, report=True, raise_on_error=False)
+        if st_ != 0:
+            raise SystemExit("bench.py: spin-up iteration failed with status %d" % st_)
+    solver.snapshot()
+    step_ms = []
 
-    def run(k):
-        nonlocal reseeds
+    def run(k, record):
         last, status = None, 0
         for _ in range(k):
+            ts = time.perf_counter()
+            solver.restore()
             st_, rep_ = solver.iterate(1, report=True, raise_on_error=False)
             last = rep_[0]
-            if st_ == 1 or not np.isfinite(last).all() or abs(last[6]) > 1e30:
-                solver.set_fields(*seed_fields)
-                reseeds += 1
-            elif st_ != 0:
+            if record:
+                step_ms.append((time.perf_counter() - ts) * 1e3)  # iterate() ends with a host sync
+            if st_ != 0:
                 status = st_
                 break
         return status, last
 
     if args.warmup > 0:
-        run(args.warmup)
-    reseeds = 0
+        run(args.warmup, False)
     barrier_sync()
     t0 = time.perf_counter()
-    st, last_rep = run(args.steps)
+    st, last_rep = run(args.steps, True)
     barrier_sync()
     dt = time.perf_counter() - t0
     rep = np.array([last_rep]) if last_rep is not None else None
@@ -207,6 +217,23 @@ def main():
     spmv_bytes = 12.0 * nnz_local + 20.0 * n_local  # f64 value + i32 column per nnz; row_ptr, x, y per row
     achieved = spmv_bytes / (spmv_ms * 1e-3) / 1e9
     bicg_ms = solver.bench_bicgstab_iteration(10)
+    # per level of the momentum system's Multigrid hierarchy: rows, nnz, padded entries, product time, roofline fraction
+    levels = []
+    if args.solver in ("multigrid", "multigrid_gs") and world == 1:
+        solver.restore()
+        for lvl, (rows_l, nnz_l, padded_l, ms_l) in enumerate(solver.bench_amg_levels(20)):
+            # bytes per product: value + column per stored entry, row length + x + y per row, + the Jacobi scaling vectors
+            # the solver's products read (two on level 0, one on the coarse levels: SURVEY Q4)
+            bytes_l = 12.0 * nnz_l + 20.0 * rows_l + 8.0 * rows_l * (2 if lvl == 0 else 1)
+            levels.append({"level": lvl, "rows": rows_l, "nnz": nnz_l, "padded": padded_l, "us_per_product": ms_l * 1e3,
+                           "algorithmic_bytes": bytes_l, "GBs": bytes_l / (ms_l * 1e-3) / 1e9,
+                           "frac_of_peak": bytes_l / (ms_l * 1e-3) / 1e9 / HBM_PEAK_GBS})
+        if args.levels_csv and rank == 0:
+            with open(args.levels_csv, "w") as fh:
+                fh.write("level,rows,nnz,padded_entries,padding_ratio,us_per_product,algorithmic_bytes,GB_per_s,frac_of_8TBs\n")
+                for L in levels:
+                    fh.write("%d,%d,%d,%d,%.4f,%.2f,%.0f,%.1f,%.4f\n" % (L["level"], L["rows"], L["nnz"], L["padded"], L["padded"] / max(L["nnz"], 1),
+                                                                        L["us_per_product"], L["algorithmic_bytes"], L["GBs"], L["frac_of_peak"]))
     import ctypes
     free_b, total_b = ctypes.c_int64(0), ctypes.c_int64(0)
     orc_amd._lib.check(orc_amd._lib.lib().orc_device_memory(ctypes.byref(free_b), ctypes.byref(total_b)))
@@ -239,11 +266,15 @@ def main():
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
             "scaling": "weak",
+            "scaling_definition": "weak: every rank owns a %dx%dx%d slab of a %dx%dx(%d*N) channel cut along z; value = N x (10.24M-cell SIMPLE "
+                                  "iterations per second), i.e. cells processed per second / 10.24M" % (nx, ny, nz, nx, ny, nz),
+            "step_definition": "restore the device-side snapshot taken after %d spin-up iterations (0.57 GB device-to-device, inside the "
+                               "timed region) + one full SIMPLE iteration; every step does identical work" % SPIN_UP,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "status": int(st),
-            "reseeds": int(reseeds),
+            "step_ms": [round(x, 2) for x in step_ms],
             "config": {
                 "workload": "%s: synthetic hex channel %dx%dx%d per GPU (%d cells total), TVD-%s momentum, "
                             "Rhie-Chow + SecondOrder, solver=%s (%d inner iterations) + Jacobi preconditioner, relaxation u %.3g / p %.3g, "
@@ -268,6 +299,7 @@ def main():
                 "bicgstab_iteration_ms": bicg_ms,
                 "bicgstab_iteration_GBs": bicg_bytes / (bicg_ms * 1e-3) / 1e9,
             },
+            "amg_levels": levels,
             "report_last": [float(x) for x in rep[-1]] if rep is not None and len(rep) else None,
         }
         if not args.no_cpu_baseline:

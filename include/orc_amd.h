@@ -203,6 +203,11 @@ int orc_solver_get_fields(OrcSolver *s, double *u, double *v, double *w, double 
 /* runs `iterations` SIMPLE iterations (solver.rs:60-222); report, if not NULL, receives 8 doubles per
  * iteration: u_avg, v_avg, w_avg, peclet_avg, peclet_min, peclet_max, vel_corr, p_corr */
 int orc_solver_iterate(OrcSolver *s, uint64_t iterations, double *report);
+/* Device-side copy of the state a SIMPLE iteration starts from (u, v, w, p and the momentum diagonals that Rhie-Chow
+ * reads, solver.rs:1068-1081) and its restoration (asynchronous device-to-device copies on the library stream):
+ * bench.py times the same iteration repeatedly, so that every step does identical work. */
+int orc_solver_snapshot(OrcSolver *s);
+int orc_solver_restore(OrcSolver *s);
 /* individual phases, for the parity tests: matrices come back in pattern order */
 int orc_solver_assemble_momentum(OrcSolver *s, double *a_u, double *a_v, double *a_w, double *b_u, double *b_v, double *b_w, double peclet[3]);
 int orc_solver_assemble_pressure(OrcSolver *s, double *a_p, double *b_p);
@@ -212,6 +217,10 @@ int orc_solver_assemble_pressure(OrcSolver *s, double *a_p, double *b_p);
 int orc_bench_spmv(OrcSolver *s, int reps, double *avg_ms, double *checksum);
 /* one BiCGSTAB iteration body (linear_algebra.rs:255-268) repeated `reps` times on a_u */
 int orc_bench_bicgstab_iteration(OrcSolver *s, int reps, double *avg_ms);
+/* The Multigrid hierarchy of the momentum system a_u as the solver builds it (Jacobi-scaled operator, levels 0..3):
+ * per level rows, stored non-zeros, padded SELL-64 entries and the HIP-event average of `reps` products y = A x.
+ * Arrays hold up to 4 entries; *n_levels receives the count (level 0 = the mesh-pattern matrix). */
+int orc_bench_amg_levels(OrcSolver *s, int reps, int64_t *rows, int64_t *nnz, int64_t *padded, double *avg_ms, int *n_levels);
 /* kernel-level timers accumulated inside orc_solver_iterate when enabled: name/ms pairs */
 int orc_profile_enable(int on);
 int orc_profile_report(char *buf, int64_t buf_len);

@@ -19,6 +19,7 @@
 // coarse operator is bit-identical to nalgebra-sparse's.
 #include <algorithm>
 #include <cmath>
+#include <mutex>
 
 #include "linalg_kernels.hpp"
 
@@ -797,11 +798,10 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
     double *s_val;
     ORC_TRY(arena.alloc((size_t)scratch_cap, &s_col));
     ORC_TRY(arena.alloc((size_t)scratch_cap, &s_val));
-    static bool attr_done = false;
-    if (!attr_done) {
+    static std::once_flag attr_once;  // several lane threads reach this concurrently
+    std::call_once(attr_once, [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&galerkin_wave_k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
+    });
     // LDS tiers (32 B per list slot): every row was assigned to the narrowest list that is guaranteed to hold it
     if ((size_t)2 * max_cand > (size_t)(64 << (kGalerkinTiers - 1))) return set_error(ORC_ERR_BAD_ARGUMENT, "Galerkin row too long for LDS (%d candidates)", max_cand);
     for (int t = 0; t < kGalerkinTiers; ++t) {
@@ -860,6 +860,25 @@ static int setup_wait_side(SolveSide *side, hipStream_t setup_stream) {
     return ORC_OK;
 }
 
+// Leaves a level of the Multigrid arm on every exit path: what the side stream still reads (pairing, coarse matrix,
+// vectors) must outlive it, so the set-up stream first waits for the side stream, then both arenas unwind.
+struct SideScope {
+    SolveSide *side;
+    hipStream_t setup_stream;
+    Arena &arena, &varena;
+    Arena::Mark mk, vmk;
+    bool release_varena;
+    SideScope(SolveSide *sd, hipStream_t st, Arena &a, Arena &va, bool rel_v)
+        : side(sd), setup_stream(st), arena(a), varena(va), mk(a.mark()), vmk(va.mark()), release_varena(rel_v) {}
+    ~SideScope() {
+        if (side) (void)setup_wait_side(side, setup_stream);
+        if (release_varena) varena.release(vmk);
+        arena.release(mk);
+    }
+    SideScope(const SideScope &) = delete;
+    SideScope &operator=(const SideScope &) = delete;
+};
+
 // linear_algebra.rs:66-141.  `add_to`: the fine vector the prolonged correction is added to.
 // With a SolveSide the vector work of a level (restriction, smoothing solves, residual check, prolongation) is queued
 // on the side stream in exactly the order below, and the recursion's set-up overlaps this level's smoothing.
@@ -868,15 +887,8 @@ static int multigrid_solve_dev(const MatView &A, const double *r, uint64_t level
     const int64_t n = A.P.n;
     hipStream_t st = ctx().stream;
     Arena &varena = side ? *side->arena : arena;  // vectors and solver work space
-    Arena::Mark mk = arena.mark();
-    Arena::Mark vmk = varena.mark();
-    auto leave = [&](int code) {
-        // what the side stream still reads (choice, chooser, the coarse matrix) must outlive it
-        if (side) (void)setup_wait_side(side, st);
-        if (side) varena.release(vmk);
-        arena.release(mk);
-        return code;
-    };
+    SideScope scope(side, st, arena, varena, side != nullptr);  // runs on every return below
+    auto leave = [](int code) { return code; };
     int *choice, *chooser;
     CoarseLevel L;
     const AmgHierarchy *hier = stats ? stats->hierarchy : nullptr;
@@ -1006,14 +1018,8 @@ int multigrid_arm_dev(const MatView &A, const double *b, double *x, uint64_t ite
     SolveSide *side = (stats && stats->side && stats->side->stream && smoother == ORC_SOLVER_BICGSTAB && !stats->hierarchy) ? stats->side : nullptr;
     SolveSide *side0 = A.halo ? nullptr : side;
     Arena &varena = side0 ? *side0->arena : arena;
-    Arena::Mark mk = arena.mark();
-    Arena::Mark vmk = varena.mark();
-    auto leave = [&](int code) {
-        if (side) (void)setup_wait_side(side, st);
-        if (side0) varena.release(vmk);
-        arena.release(mk);
-        return code;
-    };
+    SideScope scope(side, st, arena, varena, side0 != nullptr);  // runs on every return below
+    auto leave = [](int code) { return code; };
     ORC_TRY(side_wait_setup(side0, st));  // the preconditioned system (scaling vectors, b) was prepared on the set-up stream
     double *r;
     int *dev_status;

@@ -166,6 +166,29 @@ int orc_solver_iterate(OrcSolver *s, uint64_t iterations, double *report) {
     return st;
 }
 
+int orc_solver_snapshot(OrcSolver *s) {
+    if (!s) return set_error(ORC_ERR_BAD_ARGUMENT, "null solver");
+    SolverState &t = s->st;
+    DevBuf<double> *src[7] = {&t.u, &t.v, &t.w, &t.p, &t.du, &t.dv, &t.dw};
+    for (int k = 0; k < 7; ++k) {
+        ORC_TRY(t.snap[k].ensure((size_t)t.n));
+        ORC_TRY(vec_copy(t.snap[k].p, src[k]->p, t.n));
+    }
+    t.snap_iterations = t.iterations_done;
+    t.has_snapshot = true;
+    return ORC_OK;
+}
+
+int orc_solver_restore(OrcSolver *s) {
+    if (!s) return set_error(ORC_ERR_BAD_ARGUMENT, "null solver");
+    SolverState &t = s->st;
+    if (!t.has_snapshot) return set_error(ORC_ERR_BAD_ARGUMENT, "orc_solver_restore without orc_solver_snapshot");
+    DevBuf<double> *dst[7] = {&t.u, &t.v, &t.w, &t.p, &t.du, &t.dv, &t.dw};
+    for (int k = 0; k < 7; ++k) ORC_TRY(vec_copy(dst[k]->p, t.snap[k].p, t.n));  // asynchronous, library stream
+    t.iterations_done = t.snap_iterations;
+    return ORC_OK;
+}
+
 int orc_solver_assemble_momentum(OrcSolver *s, double *a_u, double *a_v, double *a_w, double *b_u, double *b_v, double *b_w,
                                  double peclet[3]) {
     if (!s) return set_error(ORC_ERR_BAD_ARGUMENT, "null solver");
@@ -434,6 +457,70 @@ int orc_bench_bicgstab_iteration(OrcSolver *s, int reps, double *avg_ms) {
     float ms = 0.f;
     ORC_TRY(bench_bicgstab_dev(A, t.b_u.p, x, reps, t.arena, &ms));
     if (avg_ms) *avg_ms = ms;
+    t.arena.release(mk);
+    return ORC_OK;
+}
+
+int orc_bench_amg_levels(OrcSolver *s, int reps, int64_t *rows, int64_t *nnz, int64_t *padded, double *avg_ms, int *n_levels) {
+    if (!s || !rows || !nnz || !padded || !avg_ms || !n_levels) return set_error(ORC_ERR_BAD_ARGUMENT, "null argument");
+    SolverState &t = s->st;
+    if (reps < 1) reps = 1;
+    Arena::Mark mk = t.arena.mark();
+    MatView A;
+    A.P = t.mesh->pat.dev();
+    A.val = t.a_u.p;
+    A.symmetric = t.mesh->pat.symmetric;
+    A.persistent_pattern = true;
+    const int pre = t.settings.preconditioner;
+    AmgHierarchy H;
+    ORC_TRY(multigrid_prepare_dev(A, pre, t.arena, H));
+    hipEvent_t e0, e1;
+    ORC_HIP(hipEventCreate(&e0));
+    ORC_HIP(hipEventCreate(&e1));
+    int count = 0;
+    for (int l = 0; l <= H.n_levels && l < 4; ++l) {
+        MatView V;
+        int64_t n_l, padded_l;
+        if (l == 0) { V = A; n_l = t.mesh->pat.n; padded_l = t.mesh->pat.padded; }
+        else {
+            const AmgHierarchy::Level &h = H.level[l - 1];
+            V.P = h.P; V.val = h.val; V.symmetric = A.symmetric;
+            n_l = h.n; padded_l = h.padded;
+        }
+        // the scalings the solver's products carry: the arm's Jacobi preconditioner on level 0, and the smoother's own
+        // on every level
+        double *d1 = nullptr, *d2 = nullptr, *x, *y;
+        const size_t nn = (size_t)std::max<int64_t>(n_l, 1);
+        ORC_TRY(t.arena.alloc(nn, &x));
+        ORC_TRY(t.arena.alloc(nn, &y));
+        ORC_TRY(vec_fill(x, 1., n_l));
+        if (pre == ORC_PRECOND_JACOBI) {
+            ORC_TRY(t.arena.alloc(nn, &d1));
+            ORC_TRY(diag_inverse_dev(V, d1));
+            V.s1 = d1;
+            if (l == 0) {
+                ORC_TRY(t.arena.alloc(nn, &d2));
+                ORC_TRY(diag_inverse_dev(V, d2));
+                V.s2 = d2;
+            }
+        }
+        ORC_TRY(spmv_dev(V, x, y));
+        ORC_HIP(hipEventRecord(e0, ctx().stream));
+        for (int i = 0; i < reps; ++i) ORC_TRY(spmv_dev(V, x, y));
+        ORC_HIP(hipEventRecord(e1, ctx().stream));
+        ORC_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        ORC_HIP(hipEventElapsedTime(&ms, e0, e1));
+        std::vector<int32_t> len((size_t)n_l);
+        ORC_HIP(hipMemcpy(len.data(), V.P.row_len, sizeof(int32_t) * (size_t)n_l, hipMemcpyDeviceToHost));
+        int64_t nz = 0;
+        for (int32_t q : len) nz += q;
+        rows[count] = n_l; nnz[count] = nz; padded[count] = padded_l; avg_ms[count] = (double)ms / reps;
+        ++count;
+    }
+    *n_levels = count;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
     t.arena.release(mk);
     return ORC_OK;
 }

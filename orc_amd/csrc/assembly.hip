@@ -613,6 +613,11 @@ static int validate_settings(const OrcSettings &s) {
     if (!(s.velocity_interpolation == ORC_VINTERP_LINEAR || s.velocity_interpolation == ORC_VINTERP_LINEAR_WEIGHTED ||
           s.velocity_interpolation == ORC_VINTERP_RHIE_CHOW))
         return set_error(ORC_ERR_UNSUPPORTED_SCHEME, "unsupported velocity interpolation");  // solver.rs:994,1097
+    if (s.frozen_diagonals == 0)  // the device does not evaluate the reference's order-dependent in-place reads
+        return set_error(ORC_ERR_UNSUPPORTED_SCHEME, "frozen_diagonals = 0 (in-place Rhie-Chow diagonal reads, discretization.rs:182-197) is "
+                                                     "not available on the device: set frozen_diagonals = 1");
+    if (s.reduction_order != ORC_REDUCTION_TREE && s.reduction_order != ORC_REDUCTION_REFERENCE)
+        return set_error(ORC_ERR_BAD_ARGUMENT, "unknown reduction order %d", s.reduction_order);
     return ORC_OK;
 }
 
@@ -877,7 +882,7 @@ static int solve_momentum_partitioned(SolverState &s) {
     OrcMesh &m = *s.mesh;
     const int64_t n = m.n_own;
     DevBuf<double> *mats[3] = {&s.a_u, &s.a_v, &s.a_w}, *rhs[3] = {&s.b_u, &s.b_v, &s.b_w}, *sol[3] = {&s.u, &s.v, &s.w};
-    Arena::Mark mk = s.arena.mark();
+    ArenaScope arena_scope(s.arena);  // unwound on every exit (ORC_TRY / ORC_HIP return early)
     MatView plain[3], view[3];
     const double *b_used[3];
     double *r[3];
@@ -983,20 +988,22 @@ static int solve_momentum_partitioned(SolverState &s) {
     for (int k = 0; k < 3; ++k)
         if (th[k].joinable()) th[k].join();
     // (4) the verdicts, agreed between the ranks in u, v, w order (a rank whose lane failed locally still takes part)
+    // iterative_solve_dev has already agreed st_main between the ranks (its own status agreement), so either every rank
+    // is here with st_main == ORC_OK or none is; a local HIP failure below still enters the three agreements.
     int result = st_main;
     if (st_main == ORC_OK) {
         int h[4] = {0, 0, 0, 0};
-        ORC_HIP(hipMemcpyAsync(h, dev_status, sizeof(h), hipMemcpyDeviceToHost, g.stream));
-        ORC_HIP(hipStreamSynchronize(g.stream));
+        int copy_st = ORC_OK;
+        if (hipMemcpyAsync(h, dev_status, sizeof(h), hipMemcpyDeviceToHost, g.stream) != hipSuccess || hipStreamSynchronize(g.stream) != hipSuccess)
+            copy_st = set_error(ORC_ERR_HIP, "fetching the Multigrid status words failed");
         for (int k = 0; k < 3; ++k) {
-            int stk = st_lane[k] != ORC_OK ? st_lane[k] : h[k];
+            int stk = st_lane[k] != ORC_OK ? st_lane[k] : (copy_st != ORC_OK ? copy_st : h[k]);
             if (st_lane[k] != ORC_OK) g.last_error = local[k].last_error;
             stk = comm_global_status(stk);
             if (result == ORC_OK && stk != ORC_OK) result = stk;
         }
     }
     s.stats = s.lanes[0].stats;
-    s.arena.release(mk);
     return result;
 }
 

@@ -91,6 +91,11 @@ struct SolverState {
     bool concurrent_momentum = true;
     ~SolverState();
     uint64_t iterations_done = 0;
+    // orc_solver_snapshot / orc_solver_restore: the state one SIMPLE iteration starts from (u, v, w, p and the momentum
+    // diagonals Rhie-Chow reads), kept device-side so that a benchmark can time the SAME iteration repeatedly
+    DevBuf<double> snap[7];
+    uint64_t snap_iterations = 0;
+    bool has_snapshot = false;
 };
 
 int mesh_upload(OrcMesh &m, int64_t n_own, int64_t n_cells, int64_t n_faces, int32_t n_zones, const int64_t *face_c0, const int64_t *face_c1,

@@ -119,6 +119,16 @@ class Arena {
     size_t cur_ = 0, off_ = 0;
 };
 
+// Unwinds an arena to where it stood when the scope was entered, on EVERY exit path (ORC_TRY / ORC_HIP return early).
+struct ArenaScope {
+    Arena &arena;
+    Arena::Mark mark;
+    explicit ArenaScope(Arena &a) : arena(a), mark(a.mark()) {}
+    ~ArenaScope() { arena.release(mark); }
+    ArenaScope(const ArenaScope &) = delete;
+    ArenaScope &operator=(const ArenaScope &) = delete;
+};
+
 inline int grid_for(int64_t work_items, int per_block = kBlock) {
     int64_t g = (work_items + per_block - 1) / per_block;
     if (g < 1) g = 1;

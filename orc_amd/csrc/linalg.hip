@@ -454,7 +454,7 @@ static int bicg_iteration(const MatView &A, double *x, const BicgWork &w, uint64
 static int bicgstab_dev(const MatView &A, const double *b, double *x, uint64_t iteration_count, Arena &arena) {
     const int64_t n = A.P.n;
     if (n == 0) return ORC_OK;
-    Arena::Mark mk = arena.mark();
+    ArenaScope scope(arena);
     BicgWork w;
     ORC_TRY(bicg_alloc(arena, std::max(A.P.ncols, n), w));
     const int guard = ctx().breakdown_guard ? 1 : 0;
@@ -467,7 +467,6 @@ static int bicgstab_dev(const MatView &A, const double *b, double *x, uint64_t i
         hipLaunchKernelGGL(guard_event_k, dim3(1), dim3(1), 0, ctx().stream, w.scal, ctx().guard_events);
         ORC_HIP(hipGetLastError());
     }
-    arena.release(mk);
     return ORC_OK;
 }
 
@@ -610,7 +609,7 @@ static int jacobi_dev(const MatView &A, const double *b, double *x, uint64_t ite
     const int64_t n = A.P.n;
     *status_out = ORC_OK;
     if (n == 0 || iteration_count == 0) return ORC_OK;
-    Arena::Mark mk = arena.mark();
+    ArenaScope scope(arena);
     double *x2, *partials, *red;
     JacobiCtrl *ctrl;
     const bool global = A.halo != nullptr;
@@ -658,7 +657,6 @@ static int jacobi_dev(const MatView &A, const double *b, double *x, uint64_t ite
     const bool newest_in_x2 = (h.sweeps & 1) != 0;
     if (newest_in_x2) ORC_TRY(vec_copy(x, x2, n));
     *status_out = h.status;
-    arena.release(mk);
     return ORC_OK;
 }
 
@@ -668,12 +666,11 @@ int multigrid_arm_dev(const MatView &A, const double *b, double *x, uint64_t ite
 int gs_arm_dev(const MatView &A, const double *b, double *x, uint64_t iteration_count, double relaxation_factor, int method,
                Arena &arena);  // gs.hip (extension)
 
-int iterative_solve_dev(const MatView &A_in, const double *b_in, double *x, uint64_t iteration_count, int method,
-                        double relaxation_factor, double convergence_threshold, int preconditioner, Arena &arena,
-                        SolveStats *stats) {
-    ORC_TRY(ensure_init());
+static int iterative_solve_body(const MatView &A_in, const double *b_in, double *x, uint64_t iteration_count, int method,
+                                double relaxation_factor, double convergence_threshold, int preconditioner, Arena &arena,
+                                SolveStats *stats) {
     const int64_t n = A_in.P.n;
-    Arena::Mark mk = arena.mark();
+    ArenaScope scope(arena);
     MatView A = A_in;
     const double *b = b_in;
     if (preconditioner == ORC_PRECOND_JACOBI) {  // :159-167
@@ -722,8 +719,18 @@ int iterative_solve_dev(const MatView &A_in, const double *b_in, double *x, uint
     default:
         st = ORC_ERR_UNSUPPORTED_SOLVER;  // :297
     }
-    arena.release(mk);
-    if (A_in.halo) st = comm_global_status(st);  // partitioned operator: every rank leaves with the same verdict
+    return st;
+}
+
+int iterative_solve_dev(const MatView &A_in, const double *b_in, double *x, uint64_t iteration_count, int method,
+                        double relaxation_factor, double convergence_threshold, int preconditioner, Arena &arena,
+                        SolveStats *stats) {
+    int st = ensure_init();
+    if (st == ORC_OK)
+        st = iterative_solve_body(A_in, b_in, x, iteration_count, method, relaxation_factor, convergence_threshold, preconditioner, arena, stats);
+    // partitioned operator: whatever happened locally (an early error return included), every rank takes part in the
+    // status agreement and leaves with the same verdict — a rank that skipped it would strand its peers in RCCL
+    if (A_in.halo) st = comm_global_status(st);
     return st;
 }
 

@@ -92,6 +92,22 @@ class Solver:
         check(lib().orc_solver_assemble_pressure(self.ptr, _p(a), _p(b)))
         return a, b
 
+    def snapshot(self):
+        """device-side copy of the state the next SIMPLE iteration starts from"""
+        check(lib().orc_solver_snapshot(self.ptr))
+
+    def restore(self):
+        check(lib().orc_solver_restore(self.ptr))
+
+    def bench_amg_levels(self, reps=20):
+        """per level of a_u's Multigrid hierarchy: (rows, nnz, padded SELL entries, ms per product)"""
+        rows, nnz, padded = (np.zeros(4, dtype=np.int64) for _ in range(3))
+        ms = np.zeros(4)
+        nl = C.c_int(0)
+        i64 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64))
+        check(lib().orc_bench_amg_levels(self.ptr, C.c_int(reps), i64(rows), i64(nnz), i64(padded), _p(ms), C.byref(nl)))
+        return [(int(rows[k]), int(nnz[k]), int(padded[k]), float(ms[k])) for k in range(nl.value)]
+
     def bench_spmv(self, reps=50):
         ms, cs = C.c_double(0.0), C.c_double(0.0)
         check(lib().orc_bench_spmv(self.ptr, C.c_int(reps), C.byref(ms), C.byref(cs)))

@@ -108,18 +108,23 @@ def _fixture_mesh(oracle, mesh_path, name):
     return om, Mesh(a), a
 
 
-@pytest.mark.parametrize("name", ["channel_flow", "3x3_cube", "couette_flow_8x8x1"])
+@pytest.mark.parametrize("name,inner", [("channel_flow", 50), ("3x3_cube", 50), ("3x3_cube", 20), ("couette_flow_8x8x1", 50),
+                                        ("couette_flow_8x8x1", 20)])
 @pytest.mark.parametrize("solver,momentum", [(MULTIGRID, 1), (MULTIGRID, 5), (BICGSTAB, 5)])
-def test_solve_steady_default_stack_bit_exact(gpu, oracle, mesh_path, name, solver, momentum):
+def test_solve_steady_default_stack_bit_exact(gpu, oracle, mesh_path, name, inner, solver, momentum):
     """Six SIMPLE iterations of NumericalSettings::default() (Multigrid + Jacobi preconditioner, 50 inner iterations,
     Rhie-Chow, SecondOrder; CD1 and TVD-UMIST momentum) and of the BiCGSTAB solver: u, v, w, p identical to the oracle
-    (frozen-diagonal mode on both sides) after every one of them."""
+    (frozen-diagonal mode on both sides) after every one of them.  On the 27- and 64-cell meshes the reference's
+    unguarded BiCGSTAB reaches an exactly zero residual within 50 iterations and panics ("Multigrid diverged" /
+    "solution diverged"): the device must report the same status in the same iteration (fields are not observable
+    after a panic); 20 inner iterations keep those meshes finite."""
     from orc_amd.settings import NumericalSettings
     from orc_amd.solver import Solver
     om, dm, a = _fixture_mesh(oracle, mesh_path, name)
-    kw = dict(momentum=momentum, solver_type=solver, frozen_diagonals=1, breakdown_guard=0)
+    kw = dict(momentum=momentum, solver_type=solver, iterations=inner, frozen_diagonals=1, breakdown_guard=0)
     u, v, w, p = H.seeded_fields(a, seed=5, scale_u=4e-4)
     fo = [x.copy() for x in (u, v, w, p)]
+    compared = 0
     s = Solver(dm, NumericalSettings.default(reduction_order=REFERENCE, **kw), 1000.0, 1e-3)
     s.set_fields(u, v, w, p)
     for it in range(6):
@@ -127,11 +132,14 @@ def test_solve_steady_default_stack_bit_exact(gpu, oracle, mesh_path, name, solv
         # the oracle keeps its matrices inside one call: it + 1 iterations from the start for the comparison
         ref = [x.copy() for x in fo]
         sto, _ = oracle.solve_steady(om, *ref, oracle.default_settings(**kw), 1000.0, 1e-3, it + 1)
-        assert std == sto
-        for x, y in zip(s.get_fields(), ref):
-            assert same_bits(x, y), "iteration %d" % (it + 1)
+        assert std == sto, "iteration %d" % (it + 1)
         if std != 0:
             break
+        for x, y in zip(s.get_fields(), ref):
+            assert same_bits(x, y), "iteration %d" % (it + 1)
+        compared += 1
+    if name == "channel_flow" or inner == 20:
+        assert compared == 6
 
 
 def test_solve_steady_mixed_prism_hex_bit_exact(gpu, oracle, tmp_path):
@@ -151,7 +159,7 @@ def test_solve_steady_mixed_prism_hex_bit_exact(gpu, oracle, tmp_path):
     uo, vo, wo, po = (x.copy() for x in (u, v, w, p))
     sto, _ = oracle.solve_steady(om, uo, vo, wo, po, oracle.default_settings(**kw), 1000.0, 1e-3, 5)
     std = solve_steady(dm, u, v, w, p, NumericalSettings.default(reduction_order=REFERENCE, **kw), 1000.0, 1e-3, 5, raise_on_error=False)
-    assert std == sto
+    assert std == sto == 0
     for x, y in ((u, uo), (v, vo), (w, wo), (p, po)):
         assert same_bits(x, y)
 
