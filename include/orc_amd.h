@@ -221,6 +221,10 @@ int orc_bench_bicgstab_iteration(OrcSolver *s, int reps, double *avg_ms);
  * per level rows, stored non-zeros, padded SELL-64 entries and the HIP-event average of `reps` products y = A x.
  * Arrays hold up to 4 entries; *n_levels receives the count (level 0 = the mesh-pattern matrix). */
 int orc_bench_amg_levels(OrcSolver *s, int reps, int64_t *rows, int64_t *nnz, int64_t *padded, double *avg_ms, int *n_levels);
+/* Measurement only: force a product kernel variant for the next launches (0 = production choice, 1 = padded SELL-64,
+ * 2 = padded with predicated padding, 3 = packed where a mirror exists, 4/5 = packed/padded WITHOUT the x gathers —
+ * wrong results, times the matrix stream alone). */
+int orc_debug_set_spmv_variant(int variant);
 /* kernel-level timers accumulated inside orc_solver_iterate when enabled: name/ms pairs */
 int orc_profile_enable(int on);
 int orc_profile_report(char *buf, int64_t buf_len);

@@ -651,6 +651,158 @@ __global__ __launch_bounds__(1024) void slice_ptr_k(const int *__restrict__ row_
     }
 }
 
+// ---- packed mirror of the coarse operator (PackedDev, linalg.hpp): what the level's ~200 products stream
+// slice sizes (sum of the row lengths, rounded up to 16 elements = 128 bytes) -> pk_ptr (single workgroup scan)
+__global__ __launch_bounds__(1024) void pk_ptr_k(const int *__restrict__ row_len, int64_t n, int n_slices, int64_t *__restrict__ pk_ptr) {
+    __shared__ long long carry;
+    __shared__ long long buf[1024];
+    if (threadIdx.x == 0) { carry = 0; pk_ptr[0] = 0; }
+    __syncthreads();
+    for (int base = 0; base < n_slices; base += 1024) {
+        const int s = base + threadIdx.x;
+        long long w = 0;
+        if (s < n_slices) {
+            const int64_t lo = (int64_t)s * 64, hi = lo + 64 < n ? lo + 64 : n;
+            long long sum = 0;
+            for (int64_t r = lo; r < hi; ++r) sum += row_len[r];
+            w = (sum + 15) & ~15ll;
+        }
+        buf[threadIdx.x] = w;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+            long long v = threadIdx.x >= off ? buf[threadIdx.x - off] : 0;
+            __syncthreads();
+            buf[threadIdx.x] += v;
+            __syncthreads();
+        }
+        if (s < n_slices) pk_ptr[s + 1] = carry + buf[threadIdx.x];
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += buf[1023];
+        __syncthreads();
+    }
+}
+
+// scratch rows -> packed image: one wavefront per slice, depth by depth; the entries of the active lanes land back to back
+__global__ __launch_bounds__(kBlock) void galerkin_pack_packed_k(SellDev Pc, const int64_t *__restrict__ pk_ptr, const long long *__restrict__ slice_base,
+                                                                 const int *__restrict__ intra_off, const int *__restrict__ s_col,
+                                                                 const double *__restrict__ s_val, int *__restrict__ pk_col, double *__restrict__ pk_val) {
+    const int lane = threadIdx.x & 63;
+    const int waves = blockDim.x >> 6;
+    for (int64_t slice = (int64_t)blockIdx.x * waves + (threadIdx.x >> 6); slice < Pc.n_slices; slice += (int64_t)gridDim.x * waves) {
+        const int64_t I = slice * 64 + lane;
+        const bool live = I < Pc.n;
+        const int len = live ? Pc.row_len[I] : 0;
+        const long long src = live ? slice_base[slice] + intra_off[I] : 0;
+        const int width = (int)((Pc.slice_ptr[slice + 1] - Pc.slice_ptr[slice]) >> 6);
+        int64_t off = pk_ptr[slice];
+        for (int q = 0; q < width; ++q) {
+            const bool in = q < len;
+            const unsigned long long m = __ballot(in);
+            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            if (in) {
+                pk_col[off + rank] = s_col[src + q];
+                pk_val[off + rank] = s_val[src + q];
+            }
+            off += __popcll(m);
+        }
+    }
+}
+
+// ---- LDS x windows of the packed mirror (XWinDev, linalg.hpp): per block of 256 rows the ascending list of distinct
+// columns and, per packed entry, the 16-bit position of its column in that list.  One workgroup per block: the columns
+// set bits in an LDS bitmap over the block's column span, a prefix of the word population counts turns a bit into its
+// rank.  A block whose span exceeds the bitmap or whose window exceeds kXWinCap gets wsize = -1 (global gathers).
+constexpr int kXBitWords = 8192;  // 262144 columns of span
+__global__ __launch_bounds__(kBlock) void xwin_build_k(SellDev P, PackedDev pk, int *__restrict__ wcol, int *__restrict__ wsize,
+                                                       unsigned short *__restrict__ lidx, int64_t n_blocks) {
+    __shared__ unsigned bits[kXBitWords];
+    __shared__ unsigned short wpre[kXBitWords];  // exclusive prefix of the word population counts (windows hold <= 4096)
+    __shared__ int s_min, s_max, s_part[kBlock];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int64_t b = blockIdx.x; b < n_blocks; b += gridDim.x) {
+        const int64_t row = b * kXWinRows + tid;
+        const bool live = row < P.n;
+        const int len = live ? P.row_len[row] : 0;
+        const int64_t rbase = live ? P.slice_ptr[row >> 6] + (row & 63) : 0;
+        if (tid == 0) { s_min = 0x7fffffff; s_max = -1; }
+        __syncthreads();
+        if (len > 0) {  // columns ascend within a row
+            atomicMin(&s_min, P.col[rbase]);
+            atomicMax(&s_max, P.col[rbase + (int64_t)(len - 1) * 64]);
+        }
+        __syncthreads();
+        const int cmin = s_min, span = s_max - s_min + 1;
+        const int words = (span + 31) >> 5;
+        if (s_max < 0) {  // empty block
+            if (tid == 0) wsize[b] = 0;
+            __syncthreads();
+            continue;
+        }
+        if (words > kXBitWords) {
+            if (tid == 0) wsize[b] = -1;
+            __syncthreads();
+            continue;
+        }
+        for (int w = tid; w < words; w += kBlock) bits[w] = 0u;
+        __syncthreads();
+        for (int k = 0; k < len; ++k) {
+            const int c = P.col[rbase + (int64_t)k * 64] - cmin;
+            atomicOr(&bits[c >> 5], 1u << (c & 31));
+        }
+        __syncthreads();
+        // prefix over the words: thread t owns words [t * per, (t + 1) * per)
+        const int per = (words + kBlock - 1) / kBlock;
+        int local = 0;
+        for (int w = tid * per; w < words && w < (tid + 1) * per; ++w) local += __popc(bits[w]);
+        s_part[tid] = local;
+        __syncthreads();
+        for (int off = 1; off < kBlock; off <<= 1) {  // Hillis-Steele inclusive scan of the 256 partial sums
+            const int t = tid >= off ? s_part[tid - off] : 0;
+            __syncthreads();
+            s_part[tid] += t;
+            __syncthreads();
+        }
+        const int total = s_part[kBlock - 1];
+        if (total > kXWinCap) {
+            __syncthreads();
+            if (tid == 0) wsize[b] = -1;
+            __syncthreads();
+            continue;
+        }
+        int run = s_part[tid] - local;  // exclusive
+        int *wc = wcol + b * kXWinCap;
+        for (int w = tid * per; w < words && w < (tid + 1) * per; ++w) {
+            wpre[w] = (unsigned short)run;
+            unsigned m = bits[w];
+            while (m) {
+                const int bit = __ffs(m) - 1;
+                wc[run++] = cmin + (w << 5) + bit;
+                m &= m - 1;
+            }
+        }
+        if (tid == 0) wsize[b] = total;
+        __syncthreads();
+        // window positions of the packed entries: wave per slice, depth by depth (the packed order of galerkin_pack_packed_k)
+        const int64_t slice = b * 4 + wave;
+        if (slice < P.n_slices) {
+            const int64_t sbase = P.slice_ptr[slice];
+            const int width = (int)((P.slice_ptr[slice + 1] - sbase) >> 6);
+            int64_t off = pk.ptr[slice];
+            for (int q = 0; q < width; ++q) {
+                const bool in = q < len;
+                const unsigned long long m = __ballot(in);
+                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                if (in) {
+                    const int c = P.col[sbase + (int64_t)q * 64 + lane] - cmin;
+                    lidx[off + rank] = (unsigned short)(wpre[c >> 5] + __popc(bits[c >> 5] & ((1u << (c & 31)) - 1u)));
+                }
+                off += __popcll(m);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 __global__ void nan_to_status_k(const double *__restrict__ value, int *status, int code) {
     if (threadIdx.x == 0 && blockIdx.x == 0 && isnan(value[0])) atomicCAS(status, 0, code);
 }
@@ -659,6 +811,8 @@ __global__ void nan_to_status_k(const double *__restrict__ value, int *status, i
 struct CoarseLevel {
     SellDev P;
     double *val = nullptr;
+    PackedDev pk;
+    XWinDev xw;
     int64_t n = 0, padded = 0;
     int *choice = nullptr, *chooser = nullptr;  // of the FINE level this was built from
     int rounds = 0;
@@ -814,8 +968,12 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
                            flags + 1, (const int *)(tier_list + (int64_t)t * nc), (const int *)(tier_count + t), (int *)nullptr, (int *)nullptr);
     }
     hipLaunchKernelGGL(slice_ptr_k, dim3(1), dim3(1024), 0, st, row_len, nc, n_slices, slice_ptr);
+    int64_t *pk_ptr;
+    ORC_TRY(arena.alloc((size_t)n_slices + 1, &pk_ptr));
+    hipLaunchKernelGGL(pk_ptr_k, dim3(1), dim3(1024), 0, st, row_len, nc, n_slices, pk_ptr);
     ORC_HIP(hipGetLastError());
-    int64_t padded = 0;
+    int64_t padded = 0, packed_total = 0;
+    ORC_HIP(hipMemcpyAsync(&packed_total, pk_ptr + n_slices, sizeof(int64_t), hipMemcpyDeviceToHost, st));
     ORC_HIP(hipMemcpyAsync(&padded, slice_ptr + n_slices, sizeof(int64_t), hipMemcpyDeviceToHost, st));
     ORC_HIP(hipMemcpyAsync(hflags, flags, sizeof(hflags), hipMemcpyDeviceToHost, st));
     ORC_HIP(hipStreamSynchronize(st));
@@ -830,6 +988,31 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
     hipLaunchKernelGGL(galerkin_pack_k, dim3(grid_for(nc)), dim3(kBlock), 0, st, Pc, slice_base, intra_off, s_col, s_val, col, val, diag);
     ORC_HIP(hipGetLastError());
     L.P = Pc; L.val = val; L.n = nc; L.padded = padded;
+    L.pk = PackedDev();
+    L.xw = XWinDev();
+    // Packed mirror + LDS x windows for the levels whose rows are long enough for a window to be re-used (measured at
+    // 10.24 M fine rows: 33 entries per row +2 %, 70 entries per row +17 % against the padded product; 15 entries per row
+    // -10 %, so that level keeps the padded image).  ORC_SPMV_XWIN_MIN_NNZ < 0 switches the mirror off.
+    static const int xwin_min = getenv("ORC_SPMV_XWIN_MIN_NNZ") ? atoi(getenv("ORC_SPMV_XWIN_MIN_NNZ")) : 24;
+    if (xwin_min >= 0 && packed_total > 0 && packed_total >= (int64_t)xwin_min * nc) {
+        int *pk_col;
+        double *pk_val;
+        ORC_TRY(arena.alloc((size_t)packed_total, &pk_col));
+        ORC_TRY(arena.alloc((size_t)packed_total, &pk_val));
+        const int gp = (int)std::min<int64_t>(((int64_t)n_slices + 3) / 4, kMaxGrid);
+        hipLaunchKernelGGL(galerkin_pack_packed_k, dim3(std::max(gp, 1)), dim3(kBlock), 0, st, Pc, pk_ptr, slice_base, intra_off, s_col, s_val, pk_col, pk_val);
+        ORC_HIP(hipGetLastError());
+        L.pk.ptr = pk_ptr; L.pk.col = pk_col; L.pk.val = pk_val;
+        const int64_t n_blocks = ((int64_t)n_slices + 3) / 4;
+        int *wcol, *wsize;
+        unsigned short *lidx;
+        ORC_TRY(arena.alloc((size_t)n_blocks * kXWinCap, &wcol));
+        ORC_TRY(arena.alloc((size_t)n_blocks, &wsize));
+        ORC_TRY(arena.alloc((size_t)packed_total, &lidx));
+        hipLaunchKernelGGL(xwin_build_k, dim3((unsigned)std::min<int64_t>(n_blocks, 2048)), dim3(kBlock), 0, st, Pc, L.pk, wcol, wsize, lidx, n_blocks);
+        ORC_HIP(hipGetLastError());
+        L.xw.wcol = wcol; L.xw.wsize = wsize; L.xw.lidx = lidx;
+    }
     return ORC_OK;
 }
 
@@ -896,7 +1079,7 @@ static int multigrid_solve_dev(const MatView &A, const double *r, uint64_t level
         // :80, :84 were done ahead of time (multigrid_prepare_dev) for exactly this matrix
         const AmgHierarchy::Level &h = hier->level[level - 1];
         choice = h.choice; chooser = h.chooser;
-        L.P = h.P; L.val = h.val; L.n = h.n; L.padded = h.padded; L.rounds = h.rounds;
+        L.P = h.P; L.val = h.val; L.pk = h.pk; L.xw = h.xw; L.n = h.n; L.padded = h.padded; L.rounds = h.rounds;
     } else {
         ORC_TRY(arena.alloc((size_t)std::max<int64_t>(n, 1), &choice));
         ORC_TRY(arena.alloc((size_t)std::max<int64_t>(n, 1), &chooser));
@@ -922,6 +1105,8 @@ static int multigrid_solve_dev(const MatView &A, const double *r, uint64_t level
     MatView Ac;
     Ac.P = L.P;
     Ac.val = L.val;
+    Ac.pk = L.pk;
+    Ac.xw = L.xw;
     Ac.symmetric = A.symmetric;  // halo stays null: coarse levels are solved per rank
     double *r_prime, *e_prime, *partials, *scal;
     {
@@ -985,12 +1170,14 @@ int multigrid_prepare_dev(const MatView &A_in, int preconditioner, Arena &arena,
         CoarseLevel L;
         ORC_TRY(aggregate(A, arena, h.choice, h.chooser, &L.rounds));
         ORC_TRY(galerkin(A, h.choice, h.chooser, arena, L));
-        h.P = L.P; h.val = L.val; h.n = L.n; h.padded = L.padded; h.rounds = L.rounds;
+        h.P = L.P; h.val = L.val; h.pk = L.pk; h.xw = L.xw; h.n = L.n; h.padded = L.padded; h.rounds = L.rounds;
         H.n_levels = (int)level;
         if (!(level < max_levels && L.n > 16)) break;  // :109
         MatView Ac;
         Ac.P = L.P;
         Ac.val = L.val;
+        Ac.pk = L.pk;
+        Ac.xw = L.xw;
         Ac.symmetric = A.symmetric;
         views[level] = Ac;
     }

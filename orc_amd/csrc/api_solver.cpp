@@ -484,8 +484,19 @@ int orc_bench_amg_levels(OrcSolver *s, int reps, int64_t *rows, int64_t *nnz, in
         if (l == 0) { V = A; n_l = t.mesh->pat.n; padded_l = t.mesh->pat.padded; }
         else {
             const AmgHierarchy::Level &h = H.level[l - 1];
-            V.P = h.P; V.val = h.val; V.symmetric = A.symmetric;
+            V.P = h.P; V.val = h.val; V.pk = h.pk; V.xw = h.xw; V.symmetric = A.symmetric;
             n_l = h.n; padded_l = h.padded;
+            if (getenv("ORC_DEBUG_XWIN") && h.xw.wsize) {  // window statistics of the level (measurement runs only)
+                const int64_t nb = ((int64_t)h.P.n_slices + 3) / 4;
+                std::vector<int32_t> ws((size_t)nb);
+                ORC_HIP(hipStreamSynchronize(ctx().stream));
+                ORC_HIP(hipMemcpy(ws.data(), h.xw.wsize, sizeof(int32_t) * (size_t)nb, hipMemcpyDeviceToHost));
+                int64_t neg = 0, mx = 0;
+                double sum = 0.;
+                for (int32_t w : ws) { if (w < 0) ++neg; else { sum += w; mx = std::max<int64_t>(mx, w); } }
+                fprintf(stderr, "[orc xwin] level %d: %lld blocks, %lld without a window, mean window %.0f, max %lld\n", l, (long long)nb, (long long)neg,
+                        nb > neg ? sum / (double)(nb - neg) : 0., (long long)mx);
+            }
         }
         // the scalings the solver's products carry: the arm's Jacobi preconditioner on level 0, and the smoother's own
         // on every level

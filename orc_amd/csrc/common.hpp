@@ -27,6 +27,7 @@ struct Ctx {
     bool profile = false;
     bool breakdown_guard = true;  // OrcSettings.breakdown_guard of the running solve
     int reduction_order = 0;      // OrcReductionOrder of the running solve: 0 = wave trees, 1 = the reference's (nalgebra) association
+    int spmv_variant = 0;         // orc_debug_set_spmv_variant (measurement only)
     int *guard_events = nullptr;  // device counter: BiCGSTAB solves in which the breakdown guard fired (orc_breakdown_guard_events)
     // multi-GPU (comm.cpp)
     int rank = 0, world = 1;

@@ -263,15 +263,43 @@ struct EpiTs {  // t = A s ; partials t.s, t.t            (linear_algebra.rs:260
 
 template <class Epi>
 static int launch_spmv(const MatView &A, const double *x, const Epi &epi, double *partials, int *grid_out, const double *skip_flags = nullptr) {
-    const int g = spmv_grid(A.P.n_slices);
+    int g = spmv_grid(A.P.n_slices);
+    const int variant = ctx().spmv_variant;  // measurement hook (orc_debug_set_spmv_variant); 0 in production
+    const bool xwin = A.xw.lidx != nullptr && A.pk.ptr != nullptr && (variant == 0 || (variant >= 20 && variant <= 22));
+    if (xwin) {  // one workgroup per 256-row block, at most 5 resident per CU (32 KB of LDS each)
+        int64_t gb = ((int64_t)A.P.n_slices + 3) / 4;
+        if (gb > 256 * 5) gb = 256 * 5;
+        if (gb >= 8) gb = (gb / 8) * 8;
+        g = (int)std::max<int64_t>(gb, 1);
+    }
     if (grid_out) *grid_out = g;
     if (A.P.n == 0) return ORC_OK;
     if (A.halo) ORC_TRY(A.halo->exchange(const_cast<double *>(x)));  // C1: refresh the ghost entries of x
+    if (xwin) {
+        if (variant == 21) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_xwin_k<Epi, 1>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
+        else if (variant == 22) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_xwin_k<Epi, 2>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_xwin_k<Epi>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
+        ORC_HIP(hipGetLastError());
+        return ORC_OK;
+    }
     static const bool ragged_enabled = !(getenv("ORC_SPMV_RAGGED") && atoi(getenv("ORC_SPMV_RAGGED")) == 0);
-    if (ragged_enabled && A.P.ragged)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
+    if (variant >= 10) {  // pipelined kernels: 10 = production layout choice, 11 = padded, 12 = padded-predicated
+        if (variant == 10 && A.pk.ptr) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_pipe_k<Epi, kSpmvPacked>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
+        else if (variant == 12) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_pipe_k<Epi, kSpmvRagged>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_pipe_k<Epi, kSpmvPlain>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
+    } else if (variant != 0) {
+        if (variant == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi, kSpmvPlain>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
+        else if (variant == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi, kSpmvRagged>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
+        else if (variant == 4 && A.pk.ptr) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi, kSpmvPacked, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
+        else if (variant == 5 || variant == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi, kSpmvPlain, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
+        else if (A.pk.ptr) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi, kSpmvPacked>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi, kSpmvPlain>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
+    } else if (A.pk.ptr)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi, kSpmvPacked>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
+    else if (ragged_enabled && A.P.ragged)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi, kSpmvRagged>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
     else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi, false>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi, kSpmvPlain>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
     ORC_HIP(hipGetLastError());
     return ORC_OK;
 }

@@ -21,6 +21,36 @@ struct SellDev {
     const int32_t *diag_pos = nullptr;   // [n] element offset of the stored diagonal, -1 if absent
 };
 
+// Zero-padding mirror of a SELL-64 matrix for the wave-cooperative product (coarse AMG levels, whose rows are ragged:
+// 6-47 % of a padded SELL image is padding).  Row r keeps lane r & 63 of slice r >> 6; at depth k only the lanes whose
+// row is longer than k own an entry, and those entries are stored back to back in lane order:
+//     pos(r, k) = ptr[r >> 6] + sum_{k' < k} count(k') + |{lanes l < (r & 63) : len(l) > k}|
+// which the wavefront evaluates with a ballot, a population count and v_mbcnt per depth.  Loads stay contiguous over the
+// active lanes, every row is still summed in ascending-column order (bit-identical to the padded product), and the
+// 64 rows of a wavefront remain neighbours (no length sorting: the x gathers keep their locality).  A lone thread
+// cannot address an entry, so the padded image stays beside it for the set-up kernels that walk single rows.
+struct PackedDev {
+    const int64_t *ptr = nullptr;  // [n_slices+1] element offsets, multiples of 16 (128-byte aligned values)
+    const int32_t *col = nullptr;
+    const double *val = nullptr;
+};
+
+// LDS-staged x tiles for the packed mirror (BASELINE north star: "LDS-staged x-vector tiles").  Rows are taken in
+// blocks of kXWinRows (one workgroup); the distinct columns a block references — its window — are listed once, ascending,
+// in wcol, and every entry carries the 16-bit position of its column inside that window.  A product loads the window
+// from x into LDS with (mostly contiguous) coalesced reads, then every gather is an LDS read: the per-lane divergent
+// global gathers of a coarse level (13 cache lines per wave-instruction, each re-fetched ~100x per product) leave the
+// vector-memory pipe, which is what bounds those levels once their loads are branch-free.  Entries cost 8 + 2 bytes
+// instead of 8 + 4.  Same values, same order, same sums.  A block whose window does not fit (wsize < 0) keeps the
+// global gathers.
+constexpr int kXWinRows = 256;   // rows per block = 4 slices = one workgroup
+constexpr int kXWinCap = 4080;   // window entries per block (just under 32 KB of LDS: five workgroups per CU)
+struct XWinDev {
+    const int32_t *wcol = nullptr;   // [n_blocks * kXWinCap]
+    const int32_t *wsize = nullptr;  // [n_blocks], -1 = no window for this block
+    const uint16_t *lidx = nullptr;  // [packed entries] window position of the entry's column
+};
+
 // A matrix seen through up to two explicit left (row) scalings: value(i,j) = s2[i]*(s1[i]*val).
 // This is how the reference's Jacobi preconditioner `p_inv * a` (linear_algebra.rs:159-166) and
 // its nested re-application are evaluated without materialising a_tmp.
@@ -29,6 +59,8 @@ struct MatView {
     const double *val = nullptr;
     const double *s1 = nullptr;
     const double *s2 = nullptr;
+    PackedDev pk;           // optional packed mirror (same pattern, same values): what the product streams when present
+    XWinDev xw;             // optional LDS x-window description of the packed mirror
     bool symmetric = true;  // structural symmetry of the pattern (aggregation fast path)
     bool persistent_pattern = false;  // the pattern outlives the solve (mesh pattern): derived data such as a colouring may be cached
     HaloPlan *halo = nullptr;  // partitioned level-0 operator: x's ghost entries are refreshed before every product,
@@ -82,6 +114,8 @@ struct AmgHierarchy {
         int *choice = nullptr, *chooser = nullptr;  // partner of / chosen-by, per row of the finer level
         SellDev P;                                  // coarse operator
         double *val = nullptr;
+        PackedDev pk;
+        XWinDev xw;
         int64_t n = 0, padded = 0;
         int rounds = 0;
     } level[4];

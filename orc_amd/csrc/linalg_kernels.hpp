@@ -40,7 +40,12 @@ struct SliceWalk {
 // Generic thread-per-row SELL-64 SpMV.  Epi::apply(row, acc, r0, r1) consumes the row result and
 // may accumulate up to two per-thread reduction terms; partial sums per workgroup go to
 // partials[q * gridDim.x + blockIdx.x] and are folded by reduce_partials_k.
-template <class Epi, bool kRagged = false>
+// kLayout: 0 = padded SELL-64, wave-uniform loads (mesh-pattern matrices, < 8 % padding);
+//          1 = padded SELL-64, padding slots not fetched (ragged matrices without a packed mirror);
+//          2 = packed mirror (PackedDev): no padding in memory at all.
+enum { kSpmvPlain = 0, kSpmvRagged = 1, kSpmvPacked = 2 };
+// kNoGather (diagnostic, orc_debug_set_spmv_variant): x[row] instead of x[col] — the matrix stream without the gathers
+template <class Epi, int kLayout = kSpmvPlain, bool kNoGather = false>
 __global__ __launch_bounds__(kBlock) void spmv_k(MatView A, const double *__restrict__ x, Epi epi, double *__restrict__ partials,
                                                  const double *__restrict__ skip_flags /* 2 doubles or null: non-zero = no-op */) {
     __shared__ double lds[8];
@@ -60,31 +65,299 @@ __global__ __launch_bounds__(kBlock) void spmv_k(MatView A, const double *__rest
         // chunks of 8 entries: all column and value loads are issued first, then the dependent x gathers, then the
         // products are added in ascending k — the association of the CPU product, just with the loads in flight together.
         // Padding slots hold a valid column (the row itself) and are masked out of the sum.
+        // Every load below is UNCONDITIONAL and branch-free: a lane past its row's end re-reads an entry that is being
+        // read anyway (same cache line or its own previous entry) and its product is dropped by a select.  Per-lane
+        // predicated loads compile into one exec-masked branch each with an s_waitcnt behind every column load, i.e.
+        // eight serialised round trips per chunk — that, not padding or the x gathers, is what held the ragged coarse
+        // levels at 36-48 % of peak.
+        int64_t pk_off = kLayout == kSpmvPacked ? A.pk.ptr[slice] : 0;  // wave-uniform running offset of depth k0
+        const int last = (kLayout == kSpmvRagged ? (len > 0 ? len : 1) : width) - 1;  // deepest slot this lane may touch
+        // lanes past the last row of the matrix (last slice only) re-read the last row's slots: their own were never
+        // written by the device-side pack kernels, and an unconditional gather through a garbage column would fault
+        const int lane_c = live ? lane : (int)((A.P.n - 1) & 63);
         for (int k0 = 0; k0 < width; k0 += 8) {
             int c[8];
             double v[8], xv[8];
-            const int64_t p0 = base + (int64_t)k0 * 64 + lane;
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                // kRagged (coarse AMG levels, 11-49 % padding): padding slots are not fetched, so a cache line whose lanes
-                // are all past their rows' ends stays in HBM; otherwise the loads stay wave-uniform (cheaper to issue)
-                const bool in = k0 + u < (kRagged ? len : width);
-                c[u] = in ? A.P.col[p0 + (int64_t)u * 64] : 0;
-                v[u] = in ? A.val[p0 + (int64_t)u * 64] : 0.;
+                if (kLayout == kSpmvPacked) {
+                    // entries of depth k0 + u: one per lane whose row is long enough, back to back in lane order
+                    const bool in = k0 + u < len;
+                    const unsigned long long m = __ballot(in);
+                    const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                    const int64_t p = in ? pk_off + rank : (m != 0ull ? pk_off : pk_off - 1);  // idle lanes: a stored neighbour
+                    c[u] = A.pk.col[p];
+                    v[u] = A.pk.val[p];
+                    pk_off += __popcll(m);
+                } else {
+                    const int kk = k0 + u < last ? k0 + u : last;
+                    const int64_t p = base + (int64_t)kk * 64 + lane_c;
+                    c[u] = A.P.col[p];
+                    v[u] = A.val[p];
+                }
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) xv[u] = (k0 + u < len) ? x[c[u]] : 0.;
+            for (int u = 0; u < 8; ++u) xv[u] = x[kNoGather ? (int)(live ? row : 0) + (c[u] & 0) : c[u]];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                if (k0 + u < len) {
-                    double t = v[u];
-                    if (A.s1) t = s1 * t;
-                    if (A.s2) t = s2 * t;
-                    acc += t * xv[u];
-                }
+                double t = v[u];
+                if (A.s1) t = s1 * t;
+                if (A.s2) t = s2 * t;
+                const double next = acc + t * xv[u];
+                acc = (k0 + u < len) ? next : acc;
             }
         }
         if (live) epi.apply(row, acc, r0, r1);
+    }
+    if (Epi::kReductions > 0) {
+        double t = block_sum(r0, lds);
+        if (threadIdx.x == 0) partials[blockIdx.x] = t;
+    }
+    if (Epi::kReductions > 1) {
+        double t = block_sum(r1, lds);
+        if (threadIdx.x == 0) partials[gridDim.x + blockIdx.x] = t;
+    }
+}
+
+// The same product software-pipelined across chunks AND slices: the column/value loads of the next chunk (of the same
+// slice or of the wave's next slice) are issued right behind the current chunk's x gathers, so a wave's HBM round trip
+// overlaps its gather round trip instead of following it (vmcnt counts in order: gathers first, then the younger
+// prefetches, so the wait for the gathers leaves the prefetches in flight).  Same rows, same order, same sums.
+template <int kLayout>
+struct SpmvSliceMeta {
+    int64_t base, row, pk_off;
+    int width, len, last;
+    bool live;
+    double s1, s2;
+    int lane_c;
+    __device__ __forceinline__ void load(const MatView &A, int64_t slice, int lane) {
+        row = slice * 64 + lane;
+        lane_c = row < A.P.n ? lane : (int)((A.P.n - 1) & 63);
+        base = A.P.slice_ptr[slice];
+        width = (int)((A.P.slice_ptr[slice + 1] - base) >> 6);
+        live = row < A.P.n;
+        len = live ? A.P.row_len[row] : 0;
+        s1 = (A.s1 && live) ? A.s1[row] : 1.;
+        s2 = (A.s2 && live) ? A.s2[row] : 1.;
+        pk_off = kLayout == kSpmvPacked ? A.pk.ptr[slice] : 0;
+        last = (kLayout == kSpmvRagged ? (len > 0 ? len : 1) : width) - 1;
+    }
+    // issues the 16 loads of chunk k0 (branch-free, see spmv_k); advances the packed offset
+    __device__ __forceinline__ void issue(const MatView &A, int k0, int lane, int (&c)[8], double (&v)[8]) {
+        if (width <= 0) {  // wave-uniform: an all-empty slice owns no storage
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { c[u] = 0; v[u] = 0.; }
+            return;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (kLayout == kSpmvPacked) {
+                const bool in = k0 + u < len;
+                const unsigned long long m = __ballot(in);
+                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                const int64_t p = in ? pk_off + rank : (m != 0ull ? pk_off : pk_off - 1);
+                c[u] = A.pk.col[p];
+                v[u] = A.pk.val[p];
+                pk_off += __popcll(m);
+            } else {
+                const int kk = k0 + u < last ? k0 + u : last;
+                const int64_t p = base + (int64_t)kk * 64 + lane_c;
+                c[u] = A.P.col[p];
+                v[u] = A.val[p];
+            }
+        }
+    }
+};
+
+template <class Epi, int kLayout = kSpmvPlain>
+__global__ __launch_bounds__(kBlock) void spmv_pipe_k(MatView A, const double *__restrict__ x, Epi epi, double *__restrict__ partials,
+                                                      const double *__restrict__ skip_flags) {
+    __shared__ double lds[8];
+    if (skip_flags && (skip_flags[0] != 0. || skip_flags[1] != 0.)) return;
+    const int lane = threadIdx.x & 63;
+    double r0 = 0., r1 = 0.;
+    SliceWalk w(A.P.n_slices);
+    int64_t slice = w.begin;
+    if (slice < w.end) {
+        SpmvSliceMeta<kLayout> cur;
+        cur.load(A, slice, lane);
+        int k0 = 0;
+        int c[8];
+        double v[8];
+        cur.issue(A, k0, lane, c, v);
+        double acc = 0.;
+        while (true) {
+            const bool same = k0 + 8 < cur.width;
+            const int64_t nslice = same ? slice : slice + w.step;
+            const bool has_next = same || nslice < w.end;
+            const int nk0 = same ? k0 + 8 : 0;
+            SpmvSliceMeta<kLayout> nxt = cur;
+            if (!same && has_next) nxt.load(A, nslice, lane);
+            double xv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xv[u] = x[c[u]];      // gathers of the current chunk
+            int cn[8];
+            double vn[8];
+            if (has_next) nxt.issue(A, nk0, lane, cn, vn);      // prefetch: stays in flight across the gather wait
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                double t = v[u];
+                if (A.s1) t = cur.s1 * t;
+                if (A.s2) t = cur.s2 * t;
+                const double next = acc + t * xv[u];
+                acc = (k0 + u < cur.len) ? next : acc;
+            }
+            if (!same) {
+                if (cur.live) epi.apply(cur.row, acc, r0, r1);
+                acc = 0.;
+            }
+            if (!has_next) break;
+            cur = nxt;
+            slice = nslice;
+            k0 = nk0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { c[u] = cn[u]; v[u] = vn[u]; }
+        }
+    }
+    if (Epi::kReductions > 0) {
+        double t = block_sum(r0, lds);
+        if (threadIdx.x == 0) partials[blockIdx.x] = t;
+    }
+    if (Epi::kReductions > 1) {
+        double t = block_sum(r1, lds);
+        if (threadIdx.x == 0) partials[gridDim.x + blockIdx.x] = t;
+    }
+}
+
+// Product on the packed mirror with LDS-staged x windows (XWinDev): one workgroup per block of 256 rows, its 4 waves on
+// the block's 4 slices.  Workgroups b and b + 8 share an XCD, so XCD g walks a contiguous eighth of the blocks.
+// kDebug (measurement only): 1 = window loads skipped, 2 = stream phase skipped
+template <class Epi, int kDebug = 0>
+__global__ __launch_bounds__(kBlock) void spmv_xwin_k(MatView A, const double *__restrict__ x, Epi epi, double *__restrict__ partials,
+                                                      const double *__restrict__ skip_flags) {
+    __shared__ double lds[8];
+    __shared__ double xs[kXWinCap];
+    if (skip_flags && (skip_flags[0] != 0. || skip_flags[1] != 0.)) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double r0 = 0., r1 = 0.;
+    const int64_t n_blocks = ((int64_t)A.P.n_slices + 3) >> 2;
+    int64_t b_begin, b_end, b_step;
+    if ((gridDim.x & 7) == 0 && gridDim.x >= 8) {
+        const int xcd = blockIdx.x & 7, bl = blockIdx.x >> 3, nb = gridDim.x >> 3;
+        const int64_t per = (n_blocks + 7) / 8;
+        b_begin = (int64_t)xcd * per + bl;
+        b_end = (int64_t)(xcd + 1) * per < n_blocks ? (int64_t)(xcd + 1) * per : n_blocks;
+        b_step = nb;
+    } else {
+        b_begin = blockIdx.x; b_end = n_blocks; b_step = gridDim.x;
+    }
+    for (int64_t b = b_begin; b < b_end; b += b_step) {
+        const int ws = A.xw.wsize[b];  // workgroup-uniform
+        if (ws > 0 && kDebug != 1) {
+            // window -> LDS: all column loads of a pass are issued before the x gathers, those before the LDS writes
+            // (a rolled loop would cost two dependent round trips per element)
+            const int32_t *wc = A.xw.wcol + b * kXWinCap;
+            for (int j0 = 0; j0 < ws; j0 += 8 * kBlock) {
+                int wj[8];
+                double xw[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int j = j0 + q * kBlock + (int)threadIdx.x;
+                    wj[q] = wc[j < ws ? j : 0];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) xw[q] = x[wj[q]];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int j = j0 + q * kBlock + (int)threadIdx.x;
+                    if (j < ws) xs[j] = xw[q];
+                }
+            }
+        }
+        __syncthreads();
+        const int64_t slice = b * 4 + wave;
+        if (slice < A.P.n_slices && kDebug != 2) {
+            const int64_t row = slice * 64 + lane;
+            const int64_t base = A.P.slice_ptr[slice];
+            const int width = (int)((A.P.slice_ptr[slice + 1] - base) >> 6);
+            const bool live = row < A.P.n;
+            const int len = live ? A.P.row_len[row] : 0;
+            const double s1 = (A.s1 && live) ? A.s1[row] : 1.;
+            const double s2 = (A.s2 && live) ? A.s2[row] : 1.;
+            double acc = 0.;
+            int64_t pk_off = A.pk.ptr[slice];
+            if (ws >= 0) {
+                // two chunks in flight: the loads of chunk k0 + 8 are issued before chunk k0 is consumed (with 32 KB of LDS
+                // per workgroup only 20 waves fit a CU, so each has to keep more bytes in flight).  Addresses are a
+                // wave-uniform slice base (scalar registers) plus a 32-bit in-slice offset: no 64-bit vector arithmetic
+                // per entry.
+                const int64_t sb = __builtin_amdgcn_readfirstlane((int)(pk_off & 0xffffffff)) | ((int64_t)__builtin_amdgcn_readfirstlane((int)(pk_off >> 32)) << 32);
+                const unsigned short *s_lidx = A.xw.lidx + sb;
+                const double *s_val = A.pk.val + sb;
+                int off32 = 0;  // wave-uniform running offset of the chunk inside the slice
+                int c[8], cn[8];
+                double v[8], vn[8];
+                auto issue = [&](int k0, int (&cc)[8], double (&vv)[8]) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {  // branch-free loads, see spmv_k
+                        const bool in = k0 + u < len;
+                        const unsigned long long m = __ballot(in);
+                        const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                        const int p = in ? off32 + rank : (m != 0ull ? off32 : off32 - 1);
+                        cc[u] = (int)s_lidx[p];
+                        vv[u] = s_val[p];
+                        off32 += __popcll(m);
+                    }
+                };
+                if (width > 0) issue(0, c, v);
+                for (int k0 = 0; k0 < width; k0 += 8) {
+                    const bool more = k0 + 8 < width;
+                    if (more) issue(k0 + 8, cn, vn);
+                    double xv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) xv[u] = xs[c[u]];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        double t = v[u];
+                        if (A.s1) t = s1 * t;
+                        if (A.s2) t = s2 * t;
+                        const double next = acc + t * xv[u];
+                        acc = (k0 + u < len) ? next : acc;
+                    }
+                    if (more) {
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) { c[u] = cn[u]; v[u] = vn[u]; }
+                    }
+                }
+            } else {
+                for (int k0 = 0; k0 < width; k0 += 8) {
+                    int c[8];
+                    double v[8], xv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const bool in = k0 + u < len;
+                        const unsigned long long m = __ballot(in);
+                        const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                        const int64_t p = in ? pk_off + rank : (m != 0ull ? pk_off : pk_off - 1);
+                        c[u] = A.pk.col[p];
+                        v[u] = A.pk.val[p];
+                        pk_off += __popcll(m);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) xv[u] = x[c[u]];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        double t = v[u];
+                        if (A.s1) t = s1 * t;
+                        if (A.s2) t = s2 * t;
+                        const double next = acc + t * xv[u];
+                        acc = (k0 + u < len) ? next : acc;
+                    }
+                }
+            }
+            if (live) epi.apply(row, acc, r0, r1);
+        }
+        __syncthreads();  // the next block overwrites the window
     }
     if (Epi::kReductions > 0) {
         double t = block_sum(r0, lds);

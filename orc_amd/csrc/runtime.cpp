@@ -178,6 +178,11 @@ int64_t orc_breakdown_guard_events(int reset) {
     return h;
 }
 
+int orc_debug_set_spmv_variant(int variant) {
+    orc::ctx().spmv_variant = variant;
+    return ORC_OK;
+}
+
 int orc_profile_enable(int on) {
     orc::ctx().profile = on != 0;
     return ORC_OK;
