@@ -128,10 +128,28 @@ __global__ void agg_rotate_k(AggCounters *C, int *snapshot) {
 // commit, recompute taken_by for the two columns every change touches, activate later rows.
 struct TailCounters {
     int cur, changed, next, rounds;
+    int parity;    // which of the two work lists is the current one (the other collects the next round's rows)
+    int first;     // first round: every row is evaluated, no list
+    int finished;  // a round without a change has been seen: the fixed point is certified
 };
 
 __global__ void tail_seed_k(TailCounters *T, int n) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) { T->cur = n; T->changed = 0; T->next = 0; T->rounds = 0; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { T->cur = n; T->changed = 0; T->next = 0; T->rounds = 0; T->parity = 1; T->first = 1; T->finished = 0; }
+}
+
+// One atomicAdd per wavefront instead of one per lane: the lanes that want a slot are counted with a ballot, the
+// lowest of them reserves the block of slots and every lane takes its rank inside it.  The work lists of a round hold
+// tens of thousands of rows; their appends all hit ONE counter, and same-address atomics retire at ~12 ns each on
+// this chip — that serialisation, not the row work, was most of a round's 50-60 us.
+__device__ __forceinline__ int wave_append_slot(int *counter, bool want) {
+    const unsigned long long m = __ballot(want);
+    if (!want) return -1;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)m) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(counter, __popcll(m));
+    base = __shfl(base, leader, 64);
+    return base + __popcll(m & ((1ull << lane) - 1ull));
 }
 
 // Row-level kernels use one 16-lane group per row: coarse-level rows hold 40-100 entries and a single thread
@@ -139,17 +157,34 @@ __global__ void tail_seed_k(TailCounters *T, int n) {
 // reduces (value, k) lexicographically, which is exactly the sequential "strict <, first wins" scan.
 constexpr int kG = 16;
 
+// entry k of row i: column and value through the view, from the row-contiguous mirror where the matrix has one
+struct RowWalk {
+    const int32_t *col;
+    const double *val;
+    int64_t base, stride;
+    __device__ __forceinline__ RowWalk(const MatView &A, int64_t i) {
+        if (A.rows.col) { col = A.rows.col; val = A.rows.val; base = A.rows.slice_base[i >> 6] + A.rows.intra_off[i]; stride = 1; }
+        else { col = A.P.col; val = A.val; base = A.P.slice_ptr[i >> 6] + (i & 63); stride = 64; }
+    }
+    __device__ __forceinline__ int column(int k) const { return col[base + (int64_t)k * stride]; }
+    __device__ __forceinline__ double value(const MatView &A, int64_t i, int k) const {
+        double v = val[base + (int64_t)k * stride];
+        if (A.s1) v = A.s1[i] * v;
+        if (A.s2) v = A.s2[i] * v;
+        return v;
+    }
+};
+
 __device__ __forceinline__ int group_eval_row(const MatView &A, const int *__restrict__ taken_by, int64_t i, int gl) {
     const int len = A.P.row_len[i];
-    const int64_t base = A.P.slice_ptr[i >> 6] + (i & 63);
+    const RowWalk W(A, i);
     double best = 1.7976931348623157e308;  // Float::MAX
     int bk = 0x7fffffff, bj = -1;
     for (int k = gl; k < len; k += kG) {
-        const int64_t pos = base + (int64_t)k * 64;
-        const int j = A.P.col[pos];
+        const int j = W.column(k);
         if (j == i || j >= A.P.n) continue;
         if (taken_by[j] < i) continue;
-        const double a = view_value(A, i, pos);
+        const double a = W.value(A, i, k);
         if (a < best) { best = a; bk = k; bj = j; }
     }
 #pragma unroll
@@ -162,21 +197,25 @@ __device__ __forceinline__ int group_eval_row(const MatView &A, const int *__res
     return bj;
 }
 
-__global__ void tail_eval_k(MatView A, const int *__restrict__ choice, const int *__restrict__ taken_by, const int *__restrict__ list,
-                            TailCounters *T, int *__restrict__ flag, int *__restrict__ ch_row, int *__restrict__ ch_new) {
+__global__ void tail_eval_k(MatView A, const int *__restrict__ choice, const int *__restrict__ taken_by, const int *__restrict__ list_a,
+                            const int *__restrict__ list_b, TailCounters *T, int *__restrict__ flag, int *__restrict__ ch_row, int *__restrict__ ch_new) {
+    if (T->finished) return;
     const int count = T->cur;
+    const int *__restrict__ list = T->first ? nullptr : (T->parity ? list_b : list_a);
     const int gl = threadIdx.x & (kG - 1);
     const int64_t groups = ((int64_t)gridDim.x * blockDim.x) / kG;
     for (int64_t idx = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kG; idx < count; idx += groups) {
         const int i = list ? list[idx] : (int)idx;
         const int nv = group_eval_row(A, taken_by, i, gl);
+        bool changed = false;
         if (gl == 0) {
             flag[i] = 0;
-            if (nv != choice[i]) {
-                const int slot = atomicAdd(&T->changed, 1);
-                ch_row[slot] = i;
-                ch_new[slot] = nv;
-            }
+            changed = nv != choice[i];
+        }
+        const int slot = wave_append_slot(&T->changed, changed);
+        if (changed) {
+            ch_row[slot] = i;
+            ch_new[slot] = nv;
         }
     }
 }
@@ -184,6 +223,7 @@ __global__ void tail_eval_k(MatView A, const int *__restrict__ choice, const int
 // commit the changes; remember who held the two touched columns before (for the exact activation interval)
 __global__ void tail_commit_k(int *__restrict__ choice, const int *__restrict__ taken_by, const TailCounters *T, const int *__restrict__ ch_row,
                               const int *__restrict__ ch_new, int *__restrict__ ch_old, int *__restrict__ ch_t_old, int *__restrict__ ch_t_new) {
+    if (T->finished) return;
     const int count = T->changed;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < count; idx += gridDim.x * blockDim.x) {
         const int i = ch_row[idx];
@@ -202,10 +242,10 @@ __global__ void tail_commit_k(int *__restrict__ choice, const int *__restrict__ 
 __device__ __forceinline__ void tail_touch_column(const MatView &A, const int *choice, int *taken_by, int j, int t_before, int gl, int *flag,
                                                   int *next_list, int *next_count) {
     const int lj = A.P.row_len[j];
-    const int64_t bj = A.P.slice_ptr[j >> 6] + (j & 63);
+    const RowWalk W(A, j);
     int mn = 0x7fffffff;
     for (int kk = gl; kk < lj; kk += kG) {  // rows holding column j = (symmetric pattern) the columns of row j
-        const int m = A.P.col[bj + (int64_t)kk * 64];
+        const int m = W.column(kk);
         if (m >= A.P.n || m == j) continue;
         if (choice[m] == j && m < mn) mn = m;
     }
@@ -215,10 +255,11 @@ __device__ __forceinline__ void tail_touch_column(const MatView &A, const int *c
         const int lo = min(mn, t_before), hi = max(mn, t_before);
         const bool taken_earlier = mn < t_before;
         for (int kk = gl; kk < lj; kk += kG) {
-            const int m = A.P.col[bj + (int64_t)kk * 64];
+            const int m = W.column(kk);
             if (m >= A.P.n || m <= lo || m > hi) continue;
-            if (taken_earlier && choice[m] != j) continue;
-            if (atomicExch(&flag[m], 1) == 0) next_list[atomicAdd(next_count, 1)] = m;
+            const bool push = !(taken_earlier && choice[m] != j) && atomicExch(&flag[m], 1) == 0;
+            const int slot = wave_append_slot(next_count, push);
+            if (push) next_list[slot] = m;
         }
     }
     if (gl == 0) taken_by[j] = mn;  // several changes touching j compute the same value
@@ -227,8 +268,10 @@ __device__ __forceinline__ void tail_touch_column(const MatView &A, const int *c
 __global__ void tail_update_k(MatView A, const int *__restrict__ choice, int *__restrict__ taken_by, TailCounters *T,
                               const int *__restrict__ ch_row, const int *__restrict__ ch_new, const int *__restrict__ ch_old,
                               const int *__restrict__ ch_t_old, const int *__restrict__ ch_t_new, int *__restrict__ flag,
-                              int *__restrict__ next_list) {
+                              int *__restrict__ list_a, int *__restrict__ list_b) {
+    if (T->finished) return;
     const int count = T->changed;
+    int *__restrict__ next_list = T->parity ? list_a : list_b;
     const int gl = threadIdx.x & (kG - 1);
     const int64_t groups = ((int64_t)gridDim.x * blockDim.x) / kG;
     for (int64_t idx = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kG; idx < count; idx += groups) {
@@ -238,13 +281,88 @@ __global__ void tail_update_k(MatView A, const int *__restrict__ choice, int *__
     }
 }
 
-__global__ void tail_rotate_k(TailCounters *T, int *snapshot) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        *snapshot = T->changed;
+__global__ void tail_rotate_k(TailCounters *T) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && !T->finished) {
+        if (T->changed == 0) T->finished = 1;  // an evaluation round without a change: fixed point
         T->cur = T->next;
         T->next = 0;
         T->changed = 0;
         T->rounds += 1;
+        T->parity ^= 1;
+        T->first = 0;
+    }
+}
+
+// The same rounds inside ONE workgroup while the work list is short: the cascades that remain after the first rounds
+// touch tens to hundreds of rows for hundreds of dependent rounds (one row of an x-line hands its partner on to the
+// next), and four kernel boundaries per round cost more than the round's work.  __syncthreads() separates the phases —
+// evaluate against the committed state, commit, repair taken_by and activate — exactly as the kernel boundaries do, so
+// the same fixed point is reached.  Returns when a round changes nothing (finished), when the list outgrows
+// kTailSmallMax rows (the four-kernel rounds take over), or after max_rounds.
+__global__ __launch_bounds__(1024) void tail_small_k(MatView A, int *choice, int *taken_by, TailCounters *T, int *list_a, int *list_b, int *flag,
+                                                     int *ch_row, int *ch_new, int *ch_old, int *ch_t_old, int *ch_t_new, int max_rounds, int kTailSmallMax) {
+    // (no __restrict__: every array is written in one phase and read by other waves in the next)
+    __shared__ int s_changed, s_next, s_cur, s_parity;
+    const int tid = threadIdx.x, gl = tid & (kG - 1);
+    const int groups = blockDim.x / kG;
+    if (T->finished || T->first || T->cur > kTailSmallMax) return;
+    if (tid == 0) { s_cur = T->cur; s_parity = T->parity; }
+    __syncthreads();
+    int rounds = 0;
+    bool finished = false;
+    while (rounds < max_rounds) {
+        if (tid == 0) { s_changed = 0; s_next = 0; }
+        __syncthreads();
+        const int count = s_cur;
+        const int *cur = s_parity ? list_b : list_a;
+        int *next = s_parity ? list_a : list_b;
+        // ---- evaluate the listed rows against the committed state
+        for (int idx = tid / kG; idx < count; idx += groups) {
+            const int i = cur[idx];
+            const int nv = group_eval_row(A, taken_by, i, gl);
+            bool changed = false;
+            if (gl == 0) {
+                flag[i] = 0;
+                changed = nv != choice[i];
+            }
+            const int slot = wave_append_slot(&s_changed, changed);
+            if (changed) {
+                ch_row[slot] = i;
+                ch_new[slot] = nv;
+            }
+        }
+        __syncthreads();
+        const int nchg = s_changed;
+        ++rounds;
+        if (nchg == 0) { finished = true; break; }
+        // ---- commit
+        for (int idx = tid; idx < nchg; idx += blockDim.x) {
+            const int i = ch_row[idx];
+            const int old = choice[i], nv = ch_new[idx];
+            ch_old[idx] = old;
+            ch_t_old[idx] = old >= 0 ? taken_by[old] : 0x7fffffff;
+            ch_t_new[idx] = nv >= 0 ? taken_by[nv] : 0x7fffffff;
+            choice[i] = nv;
+        }
+        __syncthreads();
+        // ---- exact taken_by of the touched columns + activation
+        for (int idx = tid / kG; idx < nchg; idx += groups) {
+            const int old = ch_old[idx], nv = ch_new[idx];
+            if (old >= 0) tail_touch_column(A, choice, taken_by, old, ch_t_old[idx], gl, flag, next, &s_next);
+            if (nv >= 0) tail_touch_column(A, choice, taken_by, nv, ch_t_new[idx], gl, flag, next, &s_next);
+        }
+        __syncthreads();
+        if (tid == 0) { s_cur = s_next; s_parity ^= 1; }
+        __syncthreads();
+        if (s_cur > kTailSmallMax) break;
+    }
+    if (tid == 0) {
+        T->cur = finished ? 0 : s_cur;
+        T->next = 0;
+        T->changed = 0;
+        T->rounds += rounds;
+        T->parity = s_parity;
+        if (finished) T->finished = 1;
     }
 }
 
@@ -813,6 +931,7 @@ struct CoarseLevel {
     double *val = nullptr;
     PackedDev pk;
     XWinDev xw;
+    RowsDev rows;
     int64_t n = 0, padded = 0;
     int *choice = nullptr, *chooser = nullptr;  // of the FINE level this was built from
     int rounds = 0;
@@ -880,31 +999,34 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
         hipLaunchKernelGGL(agg_scatter_k, dim3(g), dim3(kBlock), 0, st, choice, taken_by, n);
         ORC_HIP(hipMemsetAsync(flag, 0, sizeof(int) * (size_t)n, st));
         hipLaunchKernelGGL(tail_seed_k, dim3(1), dim3(1), 0, st, T, (int)n);
-        const int *cur_list = nullptr;  // first round: every row
-        int *next_list = listA;
-        const int kBatch = 16;  // rounds per host round trip; a round past the fixed point is a no-op
+        // The first rounds see every row / long lists: four kernels per round on the whole chip.  As soon as the list is
+        // short the rounds continue inside one workgroup (tail_small_k) until the fixed point or until the list grows again.
+        static const int small_enabled = getenv("ORC_AMG_TAIL_SMALL") ? atoi(getenv("ORC_AMG_TAIL_SMALL")) : 0;  // measured: exact, fewer launches, but +2-3 % wall at 10.24 M cells
+        static const int small_max = getenv("ORC_AMG_TAIL_SMALL_MAX") ? atoi(getenv("ORC_AMG_TAIL_SMALL_MAX")) : 512;
+        static const int big_batch = getenv("ORC_AMG_TAIL_BATCH") ? atoi(getenv("ORC_AMG_TAIL_BATCH")) : 2;
+        const int kBatch = small_enabled ? big_batch : 16;  // four-kernel rounds per host round trip; a round past the fixed point is a no-op
         bool first = true, fin = false;
+        TailCounters h;
         while (!fin) {
             for (int b = 0; b < kBatch; ++b) {
-                const int ge = first ? g : 1024;
-                hipLaunchKernelGGL(tail_eval_k, dim3(ge), dim3(kBlock), 0, st, A, choice, taken_by, cur_list, T, flag, ch_row, ch_new);
+                static const int tail_grid = getenv("ORC_AMG_TAIL_GRID") ? atoi(getenv("ORC_AMG_TAIL_GRID")) : 1024;
+                const int ge = first ? g : tail_grid;
+                hipLaunchKernelGGL(tail_eval_k, dim3(ge), dim3(kBlock), 0, st, A, choice, taken_by, (const int *)listA, (const int *)listB, T, flag, ch_row, ch_new);
                 hipLaunchKernelGGL(tail_commit_k, dim3(ge), dim3(kBlock), 0, st, choice, taken_by, T, ch_row, ch_new, ch_old, ch_t_old, ch_t_new);
-                hipLaunchKernelGGL(tail_update_k, dim3(ge), dim3(kBlock), 0, st, A, choice, taken_by, T, ch_row, ch_new, ch_old, ch_t_old, ch_t_new, flag, next_list);
-                hipLaunchKernelGGL(tail_rotate_k, dim3(1), dim3(1), 0, st, T, snap + b);
-                cur_list = next_list;
-                next_list = (next_list == listA) ? listB : listA;
+                hipLaunchKernelGGL(tail_update_k, dim3(ge), dim3(kBlock), 0, st, A, choice, taken_by, T, ch_row, ch_new, ch_old, ch_t_old, ch_t_new, flag, listA, listB);
+                hipLaunchKernelGGL(tail_rotate_k, dim3(1), dim3(1), 0, st, T);
                 first = false;
             }
+            if (small_enabled)
+                hipLaunchKernelGGL(tail_small_k, dim3(1), dim3(1024), 0, st, A, choice, taken_by, T, listA, listB, flag, ch_row, ch_new, ch_old, ch_t_old, ch_t_new,
+                                   1 << 20, small_max);
             ORC_HIP(hipGetLastError());
-            int h[kBatch];
-            ORC_HIP(hipMemcpyAsync(h, snap, sizeof(h), hipMemcpyDeviceToHost, st));
+            ORC_HIP(hipMemcpyAsync(&h, T, sizeof(h), hipMemcpyDeviceToHost, st));
             ORC_HIP(hipStreamSynchronize(st));
-            for (int b = 0; b < kBatch; ++b) {
-                ++rounds;
-                if (h[b] == 0) { fin = true; break; }  // an evaluation round without a change: fixed point
-            }
-            if (rounds > 8 * 1000 * 1000) return set_error(ORC_ERR_BAD_ARGUMENT, "aggregation did not reach its fixed point");
+            fin = h.finished != 0;
+            if (h.rounds > 8 * 1000 * 1000) return set_error(ORC_ERR_BAD_ARGUMENT, "aggregation did not reach its fixed point");
         }
+        rounds += h.rounds;
     }
     ORC_HIP(hipMemsetAsync(chooser, 0xff, sizeof(int) * (size_t)n, st));
     hipLaunchKernelGGL(chooser_k, dim3(g), dim3(kBlock), 0, st, choice, chooser, n);
@@ -990,6 +1112,9 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
     L.P = Pc; L.val = val; L.n = nc; L.padded = padded;
     L.pk = PackedDev();
     L.xw = XWinDev();
+    L.rows = RowsDev();
+    static const bool rows_enabled = !(getenv("ORC_AMG_ROWS_MIRROR") && atoi(getenv("ORC_AMG_ROWS_MIRROR")) == 0);
+    if (rows_enabled) { L.rows.slice_base = slice_base; L.rows.intra_off = intra_off; L.rows.col = s_col; L.rows.val = s_val; }
     // Packed mirror + LDS x windows for the levels whose rows are long enough for a window to be re-used (measured at
     // 10.24 M fine rows: 33 entries per row +2 %, 70 entries per row +17 % against the padded product; 15 entries per row
     // -10 %, so that level keeps the padded image).  ORC_SPMV_XWIN_MIN_NNZ < 0 switches the mirror off.
@@ -1079,7 +1204,7 @@ static int multigrid_solve_dev(const MatView &A, const double *r, uint64_t level
         // :80, :84 were done ahead of time (multigrid_prepare_dev) for exactly this matrix
         const AmgHierarchy::Level &h = hier->level[level - 1];
         choice = h.choice; chooser = h.chooser;
-        L.P = h.P; L.val = h.val; L.pk = h.pk; L.xw = h.xw; L.n = h.n; L.padded = h.padded; L.rounds = h.rounds;
+        L.P = h.P; L.val = h.val; L.pk = h.pk; L.xw = h.xw; L.rows = h.rows; L.n = h.n; L.padded = h.padded; L.rounds = h.rounds;
     } else {
         ORC_TRY(arena.alloc((size_t)std::max<int64_t>(n, 1), &choice));
         ORC_TRY(arena.alloc((size_t)std::max<int64_t>(n, 1), &chooser));
@@ -1107,6 +1232,7 @@ static int multigrid_solve_dev(const MatView &A, const double *r, uint64_t level
     Ac.val = L.val;
     Ac.pk = L.pk;
     Ac.xw = L.xw;
+    Ac.rows = L.rows;
     Ac.symmetric = A.symmetric;  // halo stays null: coarse levels are solved per rank
     double *r_prime, *e_prime, *partials, *scal;
     {
@@ -1170,7 +1296,7 @@ int multigrid_prepare_dev(const MatView &A_in, int preconditioner, Arena &arena,
         CoarseLevel L;
         ORC_TRY(aggregate(A, arena, h.choice, h.chooser, &L.rounds));
         ORC_TRY(galerkin(A, h.choice, h.chooser, arena, L));
-        h.P = L.P; h.val = L.val; h.pk = L.pk; h.xw = L.xw; h.n = L.n; h.padded = L.padded; h.rounds = L.rounds;
+        h.P = L.P; h.val = L.val; h.pk = L.pk; h.xw = L.xw; h.rows = L.rows; h.n = L.n; h.padded = L.padded; h.rounds = L.rounds;
         H.n_levels = (int)level;
         if (!(level < max_levels && L.n > 16)) break;  // :109
         MatView Ac;
@@ -1178,6 +1304,7 @@ int multigrid_prepare_dev(const MatView &A_in, int preconditioner, Arena &arena,
         Ac.val = L.val;
         Ac.pk = L.pk;
         Ac.xw = L.xw;
+        Ac.rows = L.rows;
         Ac.symmetric = A.symmetric;
         views[level] = Ac;
     }

@@ -51,6 +51,16 @@ struct XWinDev {
     const uint16_t *lidx = nullptr;  // [packed entries] window position of the entry's column
 };
 
+// Row-contiguous mirror (the Galerkin product's scratch rows, kept alive with their level): entry k of row r sits at
+// slice_base[r >> 6] + intra_off[r] + k.  The set-up kernels that walk single, scattered rows (aggregation rounds) read
+// a row's columns and values from two or three cache lines here instead of one line per entry in the SELL image.
+struct RowsDev {
+    const long long *slice_base = nullptr;  // [n_slices]
+    const int32_t *intra_off = nullptr;     // [n]
+    const int32_t *col = nullptr;
+    const double *val = nullptr;
+};
+
 // A matrix seen through up to two explicit left (row) scalings: value(i,j) = s2[i]*(s1[i]*val).
 // This is how the reference's Jacobi preconditioner `p_inv * a` (linear_algebra.rs:159-166) and
 // its nested re-application are evaluated without materialising a_tmp.
@@ -61,6 +71,7 @@ struct MatView {
     const double *s2 = nullptr;
     PackedDev pk;           // optional packed mirror (same pattern, same values): what the product streams when present
     XWinDev xw;             // optional LDS x-window description of the packed mirror
+    RowsDev rows;           // optional row-contiguous mirror for single-row walks
     bool symmetric = true;  // structural symmetry of the pattern (aggregation fast path)
     bool persistent_pattern = false;  // the pattern outlives the solve (mesh pattern): derived data such as a colouring may be cached
     HaloPlan *halo = nullptr;  // partitioned level-0 operator: x's ghost entries are refreshed before every product,
@@ -116,6 +127,7 @@ struct AmgHierarchy {
         double *val = nullptr;
         PackedDev pk;
         XWinDev xw;
+        RowsDev rows;
         int64_t n = 0, padded = 0;
         int rounds = 0;
     } level[4];
