@@ -169,8 +169,9 @@ int orc_build_pressure_correction_matrices(const OrcMesh *m, const double *u, co
                                            double *a_values /*[nnz]*/, double *b /*[n]*/);
 
 /* ---------- solver::* ---------- */
-/* calculate_pressure_gradient / calculate_velocity_gradient, Green-Gauss arms (solver.rs:774-802, 874-902),
- * evaluated for every cell: grad_p[3n], grad_u[9n] (row = velocity component) */
+/* calculate_pressure_gradient / calculate_velocity_gradient (solver.rs:774-950) evaluated for every cell with
+ * settings->gradient_reconstruction — GreenGauss(CellBased) or LeastSquares: grad_p[3n], grad_u[9n] (row = velocity
+ * component).  ORC_ERR_SINGULAR_MATRIX where the reference's try_inverse().unwrap() panics. */
 int orc_calculate_gradients(const OrcMesh *m, const double *u, const double *v, const double *w, const double *p,
                             const OrcSettings *settings, double *grad_p, double *grad_u);
 /* check_boundary_conditions (solver.rs:710-772): constraint_type 0 PressureOnly, 1 VelocityOnly, 2 Hybrid;
@@ -183,7 +184,13 @@ int orc_initialize_pressure_field(const OrcMesh *m, double *p /*[n]*/);
  * settings may be NULL; only q1_compat and breakdown_guard are read from it.  Outputs u, v, w, p [n]. */
 int orc_initialize_flow(const OrcMesh *m, double mu, double rho, uint64_t iteration_count, const OrcSettings *settings,
                         double *u, double *v, double *w, double *p);
-/* initialize_flow_new (solver.rs:354-410), PressureOnly / Hybrid arms */
+/* initialize_velocity_field (solver.rs:511-696): potential-flow system for psi (velocity inlets as sources, a pressure
+ * outlet as psi = 0), ten Jacobi-preconditioned BiCGSTAB iterations, then u, v, w = least-squares gradient of psi over
+ * the interior neighbours with all-zero columns dropped.  settings may be NULL (q1_compat, breakdown_guard and
+ * reduction_order are read).  psi [n] is optional: the field the reference writes to ./examples/psi.csv. */
+int orc_initialize_velocity_field(const OrcMesh *m, const OrcSettings *settings, double *u, double *v, double *w, double *psi);
+/* initialize_flow_new (solver.rs:354-410): PressureOnly | Hybrid -> initialize_pressure_field, VelocityOnly ->
+ * initialize_velocity_field */
 int orc_initialize_flow_new(const OrcMesh *m, double mu, double rho, uint64_t iteration_count,
                             double *u, double *v, double *w, double *p);
 /* solve_steady (solver.rs:26-37). report_cb is called every reporting_interval iterations with

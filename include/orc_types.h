@@ -51,7 +51,7 @@ enum OrcVelocityInterpolation {
 enum OrcGradientReconstruction {
     ORC_GRAD_GREEN_GAUSS_CELL = 0,
     ORC_GRAD_GREEN_GAUSS_NODE = 1, /* reference panics (solver.rs:901) */
-    ORC_GRAD_LEAST_SQUARES = 2,    /* out of scope; returns ORC_ERR_UNSUPPORTED_SCHEME */
+    ORC_GRAD_LEAST_SQUARES = 2,    /* solver.rs:803-869, 903-947: normal equations per cell, 3x3 inverse */
     ORC_GRAD_NONE = 3
 };
 
@@ -109,7 +109,8 @@ enum OrcStatus {
     ORC_ERR_COMM = 14,
     ORC_ERR_MESH_FORMAT = 15,          /* io.rs:32-515: any of read_mesh's expect()/panic! sites; orc_last_error() names file:line and the reference's message */
     ORC_ERR_ZONE_NOT_FOUND = 16,       /* mesh.rs:189-195 "face zone '{zone_name}' should exist in mesh" */
-    ORC_ERR_NO_BOUNDARY_CONDITIONS = 17 /* solver.rs:770 "You must set boundary conditions." */
+    ORC_ERR_NO_BOUNDARY_CONDITIONS = 17, /* solver.rs:770 "You must set boundary conditions." */
+    ORC_ERR_SINGULAR_MATRIX = 18       /* solver.rs:850,943: `a.try_inverse().unwrap()` on a singular least-squares normal matrix */
 };
 
 /* Association of the solvers' dot products and norms (linear_algebra.rs:97,202,253,257,261,265).

@@ -129,6 +129,7 @@ int or_solve_steady(const OrMesh *m, double *u, double *v, double *w, double *p,
                     double mu, uint64_t iteration_count, double *report); /* solver.rs:26-244 */
 int or_initialize_flow(const OrMesh *m, double mu, double rho, uint64_t iteration_count, int q1_compat,
                        double *u, double *v, double *w, double *p); /* solver.rs:246-352 */
+int or_initialize_velocity_field(const OrMesh *m, double *u, double *v, double *w, double *psi_out);
 int or_initialize_pressure_field(const OrMesh *m, double *p); /* solver.rs:414-509 */
 
 void or_settings_default(OrcSettings *s); /* lib.rs:58-86 */

@@ -402,6 +402,14 @@ def initialize_flow(mesh, mu, rho, iteration_count, q1_compat=1):
     return st, u, v, w, p
 
 
+def initialize_velocity_field(mesh):
+    """solver::initialize_velocity_field (solver.rs:511-696) -> (status, u, v, w, psi)"""
+    n = mesh.n_cells
+    u, v, w, psi = np.zeros(n), np.zeros(n), np.zeros(n), np.zeros(n)
+    st = lib().or_initialize_velocity_field(mesh.ptr, _dp(u), _dp(v), _dp(w), _dp(psi))
+    return st, u, v, w, psi
+
+
 def initialize_pressure_field(mesh):
     p = np.zeros(mesh.n_cells)
     st = lib().or_initialize_pressure_field(mesh.ptr, _dp(p))

@@ -74,7 +74,113 @@ int or_get_face_velocity(const OrMesh *m, const double *u, const double *v, cons
 }
 
 /* solver.rs:874-902 (Green-Gauss cell-based arm) */
+/* nalgebra 0.32.4 dense arithmetic of the least-squares arms (crate not vendored, Cargo.lock:326-327; restated from its
+ * published source):
+ *   - `&a.transpose() * &b`, `&a.transpose() * &a`, `a_inv * b` (base/blas.rs gemm): an operand dimension <= 5 keeps
+ *     matrixmultiply out and the product is one gemv per output column — y = (1 * col_0) * x_0, then
+ *     y += (1 * col_j) * x_j — i.e. every output entry is a left-to-right sum over the inner index, no fma.
+ *   - DMatrix::try_inverse (linalg/inverse.rs): closed forms for dimensions 1, 2 and 3 (minors / determinant), a zero
+ *     determinant yields None.
+ * Returns 1 when the matrix was inverted. */
+static int nalgebra_try_inverse(int dim, double a[3][3]) {
+    if (dim == 0) return 1;
+    if (dim == 1) {
+        if (a[0][0] == 0.) return 0;
+        a[0][0] = 1. / a[0][0];
+        return 1;
+    }
+    if (dim == 2) {
+        double m11 = a[0][0], m12 = a[0][1], m21 = a[1][0], m22 = a[1][1];
+        double determinant = m11 * m22 - m21 * m12;
+        if (determinant == 0.) return 0;
+        a[0][0] = m22 / determinant; a[0][1] = -m12 / determinant;
+        a[1][0] = -m21 / determinant; a[1][1] = m11 / determinant;
+        return 1;
+    }
+    double m11 = a[0][0], m12 = a[0][1], m13 = a[0][2], m21 = a[1][0], m22 = a[1][1], m23 = a[1][2], m31 = a[2][0], m32 = a[2][1], m33 = a[2][2];
+    double minor_m12_m23 = m22 * m33 - m32 * m23;
+    double minor_m11_m23 = m21 * m33 - m31 * m23;
+    double minor_m11_m22 = m21 * m32 - m31 * m22;
+    double determinant = m11 * minor_m12_m23 - m12 * minor_m11_m23 + m13 * minor_m11_m22;
+    if (determinant == 0.) return 0;
+    a[0][0] = minor_m12_m23 / determinant;
+    a[0][1] = (m13 * m32 - m33 * m12) / determinant;
+    a[0][2] = (m12 * m23 - m22 * m13) / determinant;
+    a[1][0] = -minor_m11_m23 / determinant;
+    a[1][1] = (m11 * m33 - m31 * m13) / determinant;
+    a[1][2] = (m13 * m21 - m23 * m11) / determinant;
+    a[2][0] = minor_m11_m22 / determinant;
+    a[2][1] = (m12 * m31 - m32 * m11) / determinant;
+    a[2][2] = (m11 * m22 - m21 * m12) / determinant;
+    return 1;
+}
+/* A^T A and A^T b_q for the n x dim matrix whose rows are x[f][cols[.]], q < nb right-hand sides */
+static void normal_equations(int64_t n, const double (*x)[3], int dim, const int *cols, int nb, const double (*b)[3], double ata[3][3], double atb[3][3]) {
+    for (int i = 0; i < dim; i++) {
+        for (int j = 0; j < dim; j++) {
+            double y = 0.;
+            for (int64_t f = 0; f < n; f++) {
+                double t = (1. * x[f][cols[i]]) * x[f][cols[j]];
+                y = (f == 0) ? t : t + 1. * y;
+            }
+            ata[i][j] = y;
+        }
+        for (int q = 0; q < nb; q++) {
+            double y = 0.;
+            for (int64_t f = 0; f < n; f++) {
+                double t = (1. * x[f][cols[i]]) * b[f][q];
+                y = (f == 0) ? t : t + 1. * y;
+            }
+            atb[q][i] = y;
+        }
+    }
+}
+/* a_inv * b (gemv over the columns of a_inv) */
+static void inv_times(int dim, double ainv[3][3], const double b[3], double out[3]) {
+    for (int i = 0; i < dim; i++) {
+        double y = 0.;
+        for (int j = 0; j < dim; j++) {
+            double t = (1. * ainv[i][j]) * b[j];
+            y = (j == 0) ? t : t + 1. * y;
+        }
+        out[i] = y;
+    }
+}
+
+/* solver.rs:874-950 */
 int or_calculate_pressure_gradient(const OrMesh *m, const double *p, int64_t cell, int scheme, int q1, Vec3 *out) {
+    if (scheme == ORC_GRAD_LEAST_SQUARES) { /* :903-947 */
+        int64_t n = m->cell_face_ptr[cell + 1] - m->cell_face_ptr[cell];
+        double (*x)[3] = malloc(sizeof(double[3]) * (size_t)(n > 0 ? n : 1));
+        double (*b)[3] = malloc(sizeof(double[3]) * (size_t)(n > 0 ? n : 1));
+        Vec3 cc = m->cell_centroid[cell];
+        int st = ORC_OK;
+        for (int64_t k = 0; k < n && st == ORC_OK; k++) {
+            int64_t f = m->cell_faces[m->cell_face_ptr[cell] + k];
+            const OrZone *z = zone_of(m, f);
+            Vec3 d;
+            double val;
+            if (z->zone_type == ORC_BC_INTERIOR) {
+                int64_t nb = m->face_c0[f] == cell ? m->face_c1[f] : m->face_c0[f];
+                d = v_sub(m->cell_centroid[nb], cc);
+                val = p[nb] - p[cell];
+            } else { /* :925-934 the face VALUE, not a difference */
+                d = v_sub(m->face_centroid[f], cc);
+                st = or_get_face_pressure(m, p, f, ORC_PINTERP_NONE, ORC_GRAD_NONE, q1, &val);
+            }
+            x[k][0] = d.x; x[k][1] = d.y; x[k][2] = d.z;
+            b[k][0] = val;
+        }
+        if (st == ORC_OK) {
+            const int cols[3] = {0, 1, 2};
+            double ata[3][3], atb[3][3], g[3];
+            normal_equations(n, x, 3, cols, 1, b, ata, atb);
+            if (!nalgebra_try_inverse(3, ata)) st = ORC_ERR_SINGULAR_MATRIX; /* :943 unwrap() */
+            else { inv_times(3, ata, atb[0], g); *out = v3(g[0], g[1], g[2]); }
+        }
+        free(x); free(b);
+        return st;
+    }
     if (scheme != ORC_GRAD_GREEN_GAUSS_CELL) return ORC_ERR_UNSUPPORTED_SCHEME;
     Vec3 acc = v_zero();
     for (int64_t q = m->cell_face_ptr[cell]; q < m->cell_face_ptr[cell + 1]; q++) {
@@ -91,6 +197,41 @@ int or_calculate_pressure_gradient(const OrMesh *m, const double *p, int64_t cel
 
 /* solver.rs:774-802 (Green-Gauss arm) */
 int or_calculate_velocity_gradient(const OrMesh *m, const double *u, const double *v, const double *w, int64_t cell, int scheme, Tensor3 *out) {
+    if (scheme == ORC_GRAD_LEAST_SQUARES) { /* :803-869 */
+        int64_t n = m->cell_face_ptr[cell + 1] - m->cell_face_ptr[cell];
+        double (*x)[3] = malloc(sizeof(double[3]) * (size_t)(n > 0 ? n : 1));
+        double (*b)[3] = malloc(sizeof(double[3]) * (size_t)(n > 0 ? n : 1));
+        Vec3 cc = m->cell_centroid[cell];
+        int st = ORC_OK;
+        for (int64_t k = 0; k < n && st == ORC_OK; k++) {
+            int64_t f = m->cell_faces[m->cell_face_ptr[cell] + k];
+            const OrZone *z = zone_of(m, f);
+            Vec3 d;
+            if (z->zone_type == ORC_BC_INTERIOR) {
+                int64_t nb = m->face_c0[f] == cell ? m->face_c1[f] : m->face_c0[f];
+                d = v_sub(m->cell_centroid[nb], cc);
+                b[k][0] = u[nb] - u[cell]; b[k][1] = v[nb] - v[cell]; b[k][2] = w[nb] - w[cell];
+            } else { /* :830-838 the face VELOCITY, not a difference */
+                Vec3 fv;
+                st = or_get_face_velocity(m, u, v, w, f, ORC_VINTERP_NONE, &fv);
+                d = v_sub(m->face_centroid[f], cc);
+                b[k][0] = fv.x; b[k][1] = fv.y; b[k][2] = fv.z;
+            }
+            x[k][0] = d.x; x[k][1] = d.y; x[k][2] = d.z;
+        }
+        if (st == ORC_OK) {
+            const int cols[3] = {0, 1, 2};
+            double ata[3][3], atb[3][3], g[3][3];
+            normal_equations(n, x, 3, cols, 3, b, ata, atb);
+            if (!nalgebra_try_inverse(3, ata)) st = ORC_ERR_SINGULAR_MATRIX; /* :850 unwrap() */
+            else {
+                for (int q = 0; q < 3; q++) inv_times(3, ata, atb[q], g[q]);
+                out->x = v3(g[0][0], g[0][1], g[0][2]); out->y = v3(g[1][0], g[1][1], g[1][2]); out->z = v3(g[2][0], g[2][1], g[2][2]);
+            }
+        }
+        free(x); free(b);
+        return st;
+    }
     if (scheme != ORC_GRAD_GREEN_GAUSS_CELL && scheme != ORC_GRAD_GREEN_GAUSS_NODE) return ORC_ERR_UNSUPPORTED_SCHEME; /* GreenGauss(_) */
     Tensor3 acc = t_zero();
     for (int64_t q = m->cell_face_ptr[cell]; q < m->cell_face_ptr[cell + 1]; q++) {
@@ -270,7 +411,14 @@ int or_solve_steady(const OrMesh *m, double *u, double *v, double *w, double *p,
         }
         if (isnan(u_avg) || isnan(v_avg) || isnan(w_avg)) st = ORC_ERR_SOLUTION_DIVERGED; /* :217-221 */
     }
-    /* :227-242 computes unused mean gradients: no observable effect */
+    /* :227-242: one gradient evaluation per cell after the loop; the accumulated |gradients| are never printed, but the
+     * pass still panics on an unsupported scheme (:870,:901,:948) or a singular least-squares matrix (:850,:943) */
+    for (int64_t i = 0; i < n && st == ORC_OK; i++) {
+        Vec3 gp;
+        Tensor3 gu;
+        st = or_calculate_pressure_gradient(m, p, i, s->gradient_reconstruction, s->q1_compat, &gp);
+        if (st == ORC_OK) st = or_calculate_velocity_gradient(m, u, v, w, i, s->gradient_reconstruction, &gu);
+    }
     or_csr_free(a_di); or_csr_free(a_u); or_csr_free(a_v); or_csr_free(a_w);
     free(b_u_di); free(b_v_di); free(b_w_di); free(b_u); free(b_v); free(b_w); free(p_prime); free(b_p);
     free(du); free(dv); free(dw);
@@ -308,6 +456,74 @@ int or_initialize_pressure_field(const OrMesh *m, double *p) {
     OrCsr *a = or_csr_from_coo(n, n, cnt, ri, ci, vv);
     int st = or_iterative_solve(a, b, p, 10, ORC_SOLVER_JACOBI, 0.1, 1e-6, ORC_PRECOND_JACOBI); /* :498-507 */
     or_csr_free(a); free(ri); free(ci); free(vv); free(b);
+    return st;
+}
+
+/* solver.rs:511-696.  psi_out (optional, n doubles): the potential the reference writes to ./examples/psi.csv */
+int or_initialize_velocity_field(const OrMesh *m, double *u, double *v, double *w, double *psi_out) {
+    int64_t n = m->n_cells;
+    int64_t cap = m->cell_face_ptr[n] + n + 1, cnt = 0;
+    int64_t *ri = (int64_t *)malloc(8 * (size_t)cap), *ci = (int64_t *)malloc(8 * (size_t)cap);
+    double *vv = (double *)malloc(8 * (size_t)cap);
+    double *b = (double *)calloc((size_t)(n > 0 ? n : 1), 8), *psi = (double *)calloc((size_t)(n > 0 ? n : 1), 8);
+    for (int64_t c = 0; c < n; c++) {
+        double a_p = 0.;
+        for (int64_t q = m->cell_face_ptr[c]; q < m->cell_face_ptr[c + 1]; q++) {
+            int64_t f = m->cell_faces[q];
+            Vec3 nrm = outward_normal(m, f, c);
+            const OrZone *z = zone_of(m, f);
+            double a_nb = 0., source = 0.;
+            int64_t nb = -1;
+            if (z->zone_type == ORC_BC_INTERIOR) { /* :536-552 */
+                nb = m->face_c0[f] == c ? m->face_c1[f] : m->face_c0[f];
+                a_nb = v_dot(v_reciprocal(v_sub(m->cell_centroid[c], m->cell_centroid[nb])), nrm) * (m->face_area[f] / m->cell_volume[c]);
+            } else if (z->zone_type == ORC_BC_VELOCITY_INLET) { /* :553-560 */
+                source = -v_dot(z->vector_value, nrm);
+            } else if (z->zone_type == ORC_BC_PRESSURE_OUTLET) { /* :565-575: no area/volume factor */
+                a_nb = v_dot(v_reciprocal(v_sub(m->cell_centroid[c], m->face_centroid[f])), nrm);
+            }
+            if (nb >= 0) { ri[cnt] = c; ci[cnt] = nb; vv[cnt] = -a_nb; cnt++; }
+            b[c] += source;
+            a_p += a_nb;
+        }
+        ri[cnt] = c; ci[cnt] = c; vv[cnt] = a_p; cnt++;
+    }
+    OrCsr *a = or_csr_from_coo(n, n, cnt, ri, ci, vv);
+    int st = or_iterative_solve(a, b, psi, 10, ORC_SOLVER_BICGSTAB, 0.1, 1e-6, ORC_PRECOND_JACOBI); /* :595-604 */
+    or_csr_free(a); free(ri); free(ci); free(vv); free(b);
+    if (psi_out) memcpy(psi_out, psi, 8 * (size_t)n);
+    /* :606-618 write_data / write_gradients of psi into ./examples: files, not part of the returned fields */
+    for (int64_t c = 0; c < n && st == ORC_OK; c++) { /* :622-692 least-squares gradient of psi over the interior neighbours */
+        int64_t nf = m->cell_face_ptr[c + 1] - m->cell_face_ptr[c];
+        double (*x)[3] = malloc(sizeof(double[3]) * (size_t)(nf > 0 ? nf : 1));
+        double (*rhs)[3] = malloc(sizeof(double[3]) * (size_t)(nf > 0 ? nf : 1));
+        int64_t k = 0;
+        for (int64_t q = m->cell_face_ptr[c]; q < m->cell_face_ptr[c + 1]; q++) {
+            int64_t f = m->cell_faces[q];
+            if (m->face_c1[f] < 0) continue; /* cell_indices.len() == 2 */
+            int64_t nb = m->face_c0[f] != c ? m->face_c0[f] : m->face_c1[f];
+            Vec3 d = v_sub(m->cell_centroid[nb], m->cell_centroid[c]);
+            x[k][0] = d.x; x[k][1] = d.y; x[k][2] = d.z;
+            rhs[k][0] = psi[nb] - psi[c];
+            k++;
+        }
+        int cols[3], dim = 0;
+        for (int j = 0; j < 3; j++) { /* :648-654 columns with a non-zero minimum or maximum */
+            double mn = 0., mx = 0.;
+            for (int64_t r = 0; r < k; r++) { if (r == 0 || x[r][j] < mn) mn = x[r][j]; if (r == 0 || x[r][j] > mx) mx = x[r][j]; }
+            if (mn != 0. || mx != 0.) cols[dim++] = j;
+        }
+        double ata[3][3], atb[3][3], cv[3] = {0., 0., 0.};
+        normal_equations(k, x, dim, cols, 1, rhs, ata, atb);
+        if (nalgebra_try_inverse(dim, ata)) inv_times(dim, ata, atb[0], cv); /* None: "Could not invert. Skipping." */
+        double comp[3] = {0., 0., 0.};
+        for (int j = 0; j < dim; j++) comp[cols[j]] = cv[j];
+        u[c] = isnan(comp[0]) ? 0. : comp[0];
+        v[c] = isnan(comp[1]) ? 0. : comp[1];
+        w[c] = isnan(comp[2]) ? 0. : comp[2];
+        free(x); free(rhs);
+    }
+    free(psi);
     return st;
 }
 

@@ -370,17 +370,32 @@ int orc_initialize_flow(const OrcMesh *m, double mu, double rho, uint64_t iterat
     return st != ORC_OK ? st : st2;
 }
 
-// initialize_flow_new (solver.rs:354-410): PressureOnly | Hybrid -> initialize_pressure_field, velocities stay zero.
-// The VelocityOnly arm (initialize_velocity_field: potential-flow solve, dense least squares per cell, two files
-// written into ./examples) is outside SURVEY section 8 and reports ORC_ERR_UNSUPPORTED_SCHEME.
+// initialize_velocity_field (solver.rs:511-696): u, v, w from the potential psi; psi (optional) is what the reference
+// writes to ./examples/psi.csv — the files themselves are left to the caller (orc_write_data / orc_write_gradients).
+int orc_initialize_velocity_field(const OrcMesh *m, const OrcSettings *settings, double *u, double *v, double *w, double *psi) {
+    if (!m || !u || !v || !w) return set_error(ORC_ERR_BAD_ARGUMENT, "null argument");
+    const OrcSettings t = initializer_settings(settings);
+    auto s = std::make_unique<OrcSolver>();
+    ORC_TRY(solver_init(s->st, const_cast<OrcMesh *>(m), &t, 1.0, 1.0));
+    int st = initialize_velocity_field_dev(s->st);
+    const size_t n = (size_t)s->st.n;
+    int st2 = s->st.u.download(u, n);
+    if (st2 == ORC_OK) st2 = s->st.v.download(v, n);
+    if (st2 == ORC_OK) st2 = s->st.w.download(w, n);
+    if (st2 == ORC_OK && psi) st2 = s->st.p_prime.download(psi, n);
+    return st != ORC_OK ? st : st2;
+}
+
+// initialize_flow_new (solver.rs:354-410): the match has overlapping arms, so Hybrid takes the first one — PressureOnly |
+// Hybrid -> initialize_pressure_field (velocities stay zero), VelocityOnly -> initialize_velocity_field (pressure stays zero).
 int orc_initialize_flow_new(const OrcMesh *m, double mu, double rho, uint64_t iteration_count, double *u, double *v, double *w, double *p) {
     (void)mu; (void)rho; (void)iteration_count;
     if (!m || !u || !v || !w || !p) return set_error(ORC_ERR_BAD_ARGUMENT, "null argument");
     int kind = 0;
     ORC_TRY(orc_check_boundary_conditions(m, &kind));
-    if (kind == 1) return set_error(ORC_ERR_UNSUPPORTED_SCHEME, "initialize_velocity_field (VelocityOnly boundary conditions) is not provided");
     const size_t n = (size_t)m->n_cells;
     std::fill(u, u + n, 0.); std::fill(v, v + n, 0.); std::fill(w, w + n, 0.); std::fill(p, p + n, 0.);
+    if (kind == 1) return orc_initialize_velocity_field(m, nullptr, u, v, w, nullptr);
     return orc_initialize_pressure_field(m, p);
 }
 
@@ -406,6 +421,7 @@ int orc_solve_steady(OrcMesh *m, double *u, double *v, double *w, double *p, con
             report_cb(it, rep, rep + 3, rep[6], rep[7], ms, user);
         }
     }
+    if (st == ORC_OK) st = post_loop_gradients_dev(s->st);  // solver.rs:227-242
     int st2 = orc_solver_get_fields(s, u, v, w, p);  // fields are mutated in place up to a panic
     note.leave(st != ORC_OK ? st : st2);
     return st != ORC_OK ? st : st2;

@@ -207,6 +207,235 @@ __global__ void grad_u_k(MeshDev M, const double *__restrict__ u, const double *
     }
 }
 
+// ------------------------------------------------------------------ least-squares gradients (solver.rs:803-869, 903-947)
+// One thread per cell: the rows of the n x 3 system are the cell's faces in Cell.face_indices order — neighbour centroid
+// minus cell centroid with the value DIFFERENCE on interior faces, face centroid minus cell centroid with the face VALUE
+// itself on boundary faces (the reference's own formulation, solver.rs:830-838, 925-934) — and the normal equations are
+// accumulated face by face in nalgebra's small-matrix product order (one gemv per output column: left-to-right sums,
+// the first term assigned, (1 * a) * b per term), inverted with its closed 3 x 3 form (linalg/inverse.rs) and applied
+// by one more gemv.  A zero determinant is the reference's `try_inverse().unwrap()` panic.
+struct Lsq3 {
+    double ata[3][3], atb[3][3];
+    bool first = true;
+    __device__ __forceinline__ void add_row(const double x[3], const double *b, int nb) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const double t = (1. * x[i]) * x[j];
+                ata[i][j] = first ? t : t + 1. * ata[i][j];
+            }
+            for (int q = 0; q < nb; ++q) {
+                const double t = (1. * x[i]) * b[q];
+                atb[q][i] = first ? t : t + 1. * atb[q][i];
+            }
+        }
+        first = false;
+    }
+};
+// nalgebra try_inverse, dimension 3, in place; false = singular
+__device__ __forceinline__ bool inverse3(double a[3][3]) {
+    const double m11 = a[0][0], m12 = a[0][1], m13 = a[0][2], m21 = a[1][0], m22 = a[1][1], m23 = a[1][2], m31 = a[2][0], m32 = a[2][1], m33 = a[2][2];
+    const double minor_m12_m23 = m22 * m33 - m32 * m23;
+    const double minor_m11_m23 = m21 * m33 - m31 * m23;
+    const double minor_m11_m22 = m21 * m32 - m31 * m22;
+    const double determinant = m11 * minor_m12_m23 - m12 * minor_m11_m23 + m13 * minor_m11_m22;
+    if (determinant == 0.) return false;
+    a[0][0] = minor_m12_m23 / determinant;
+    a[0][1] = (m13 * m32 - m33 * m12) / determinant;
+    a[0][2] = (m12 * m23 - m22 * m13) / determinant;
+    a[1][0] = -minor_m11_m23 / determinant;
+    a[1][1] = (m11 * m33 - m31 * m13) / determinant;
+    a[1][2] = (m13 * m21 - m23 * m11) / determinant;
+    a[2][0] = minor_m11_m22 / determinant;
+    a[2][1] = (m12 * m31 - m32 * m11) / determinant;
+    a[2][2] = (m11 * m22 - m21 * m12) / determinant;
+    return true;
+}
+__device__ __forceinline__ void inv_times3(const double ainv[3][3], const double b[3], double out[3]) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        double y = (1. * ainv[i][0]) * b[0];
+        y = (1. * ainv[i][1]) * b[1] + 1. * y;
+        y = (1. * ainv[i][2]) * b[2] + 1. * y;
+        out[i] = y;
+    }
+}
+
+__global__ void grad_p_lsq_k(MeshDev M, const double *__restrict__ p, double *__restrict__ gp, int *status) {
+    const int64_t n = M.n_cells;
+    GRID_STRIDE(c, M.n_own) {
+        const V3 cc = cell_centroid(M, (int)c);
+        Lsq3 L;
+        for (int q = M.cfp[c]; q < M.cfp[c + 1]; ++q) {
+            const int f = M.cf[q];
+            const int z = M.fzone[f];
+            const int zt = M.ztype[z];
+            if (!bc_supported(zt)) { raise(status, ORC_ERR_UNSUPPORTED_BC); continue; }
+            V3 d;
+            double val;
+            if (zt == ORC_BC_INTERIOR) {
+                const int nb = (M.c0[f] == c) ? M.c1[f] : M.c0[f];
+                d = vsub(cell_centroid(M, nb), cc);
+                val = p[nb] - p[c];
+            } else {  // get_face_pressure(…, None, None): zone scalar on pressure zones, cell-0 value elsewhere
+                d = vsub(face_centroid(M, f), cc);
+                val = (zt == ORC_BC_PRESSURE_INLET || zt == ORC_BC_PRESSURE_OUTLET) ? M.zscal[z] : p[M.c0[f]];
+            }
+            const double x[3] = {d.x, d.y, d.z};
+            L.add_row(x, &val, 1);
+        }
+        double g[3] = {0., 0., 0.};
+        if (L.first || !inverse3(L.ata)) raise(status, ORC_ERR_SINGULAR_MATRIX);  // a cell without faces: 0 x 0 ... the reference cannot get there either
+        else inv_times3(L.ata, L.atb[0], g);
+        gp[c] = g[0]; gp[n + c] = g[1]; gp[2 * n + c] = g[2];
+    }
+}
+
+__global__ void grad_u_lsq_k(MeshDev M, const double *__restrict__ u, const double *__restrict__ v, const double *__restrict__ w,
+                             double *__restrict__ gu, int *status) {
+    const int64_t n = M.n_cells;
+    GRID_STRIDE(c, M.n_own) {
+        const V3 cc = cell_centroid(M, (int)c);
+        Lsq3 L;
+        for (int q = M.cfp[c]; q < M.cfp[c + 1]; ++q) {
+            const int f = M.cf[q];
+            const int z = M.fzone[f];
+            const int zt = M.ztype[z];
+            if (!bc_supported(zt)) { raise(status, ORC_ERR_UNSUPPORTED_BC); continue; }
+            V3 d;
+            double b[3];
+            if (zt == ORC_BC_INTERIOR) {
+                const int nb = (M.c0[f] == c) ? M.c1[f] : M.c0[f];
+                d = vsub(cell_centroid(M, nb), cc);
+                b[0] = u[nb] - u[c]; b[1] = v[nb] - v[c]; b[2] = w[nb] - w[c];
+            } else {  // get_face_velocity(…, None): zone vector on walls / velocity inlets, cell-0 velocity elsewhere
+                d = vsub(face_centroid(M, f), cc);
+                const int a0 = M.c0[f];
+                const V3 fv = (zt == ORC_BC_WALL || zt == ORC_BC_VELOCITY_INLET) ? zone_vec(M, z) : mk(u[a0], v[a0], w[a0]);
+                b[0] = fv.x; b[1] = fv.y; b[2] = fv.z;
+            }
+            const double x[3] = {d.x, d.y, d.z};
+            L.add_row(x, b, 3);
+        }
+        double g[3][3] = {{0., 0., 0.}, {0., 0., 0.}, {0., 0., 0.}};
+        if (L.first || !inverse3(L.ata)) raise(status, ORC_ERR_SINGULAR_MATRIX);
+        else {
+            inv_times3(L.ata, L.atb[0], g[0]);
+            inv_times3(L.ata, L.atb[1], g[1]);
+            inv_times3(L.ata, L.atb[2], g[2]);
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) gu[(3 * r + k) * n + c] = g[r][k];
+    }
+}
+
+// ------------------------------------------------------------------ initialize_velocity_field (solver.rs:511-696)
+// Potential-flow system for psi on the mesh pattern: interior coupling (cc - cc_nb).reciprocal() . n * A / V, velocity inlets
+// put -U . n on the right-hand side, a pressure outlet adds (cc - fc).reciprocal() . n to the diagonal (no A / V: :565-575).
+__global__ void psi_system_k(MeshDev M, SellDev P, double *__restrict__ a, double *__restrict__ b, int *status) {
+    GRID_STRIDE(c, M.n_own) {
+        const V3 cc = cell_centroid(M, (int)c);
+        const double vol = M.vol[c];
+        double a_p = 0., src = 0.;
+        for (int q = M.cfp[c]; q < M.cfp[c + 1]; ++q) {
+            const int f = M.cf[q];
+            const int z = M.fzone[f];
+            const int zt = M.ztype[z];
+            V3 nrm = mk(M.nx[f], M.ny[f], M.nz[f]);
+            if (M.c0[f] != c) nrm = vneg(nrm);
+            double a_nb = 0., source = 0.;
+            if (zt == ORC_BC_INTERIOR) {
+                if (M.cfpos[q] < 0) { raise(status, ORC_ERR_BAD_ARGUMENT); continue; }
+                const int nb = (M.c0[f] == c) ? M.c1[f] : M.c0[f];
+                a_nb = vdot(vreciprocal(vsub(cc, cell_centroid(M, nb))), nrm) * (M.area[f] / vol);
+                a[M.cfpos[q]] = -a_nb;
+            } else if (zt == ORC_BC_VELOCITY_INLET) {
+                source = -vdot(zone_vec(M, z), nrm);
+            } else if (zt == ORC_BC_PRESSURE_OUTLET) {
+                a_nb = vdot(vreciprocal(vsub(cc, face_centroid(M, f))), nrm);
+            }
+            src += source;
+            a_p += a_nb;
+        }
+        a[P.diag_pos[c]] = a_p;
+        b[c] = src;
+    }
+}
+
+// velocity = least-squares gradient of psi over the interior neighbours, all-zero columns dropped (:622-692)
+__global__ void psi_velocity_k(MeshDev M, const double *__restrict__ psi, double *__restrict__ u, double *__restrict__ v, double *__restrict__ w) {
+    GRID_STRIDE(c, M.n_own) {
+        const V3 cc = cell_centroid(M, (int)c);
+        // pass 1: which columns have a non-zero minimum or maximum
+        double mn[3] = {0., 0., 0.}, mx[3] = {0., 0., 0.};
+        int rows = 0;
+        for (int q = M.cfp[c]; q < M.cfp[c + 1]; ++q) {
+            const int f = M.cf[q];
+            if (M.c1[f] < 0) continue;
+            const int nb = (M.c0[f] != c) ? M.c0[f] : M.c1[f];
+            const V3 d = vsub(cell_centroid(M, nb), cc);
+            const double x[3] = {d.x, d.y, d.z};
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                if (rows == 0 || x[j] < mn[j]) mn[j] = x[j];
+                if (rows == 0 || x[j] > mx[j]) mx[j] = x[j];
+            }
+            ++rows;
+        }
+        int cols[3], dim = 0;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (mn[j] != 0. || mx[j] != 0.) cols[dim++] = j;
+        // pass 2: normal equations of the selected columns, face by face
+        double ata[3][3] = {{0., 0., 0.}, {0., 0., 0.}, {0., 0., 0.}}, atb[3] = {0., 0., 0.};
+        bool first = true;
+        for (int q = M.cfp[c]; q < M.cfp[c + 1]; ++q) {
+            const int f = M.cf[q];
+            if (M.c1[f] < 0) continue;
+            const int nb = (M.c0[f] != c) ? M.c0[f] : M.c1[f];
+            const V3 d = vsub(cell_centroid(M, nb), cc);
+            const double x[3] = {d.x, d.y, d.z};
+            const double dpsi = psi[nb] - psi[c];
+            for (int i = 0; i < dim; ++i) {
+                for (int j = 0; j < dim; ++j) {
+                    const double t = (1. * x[cols[i]]) * x[cols[j]];
+                    ata[i][j] = first ? t : t + 1. * ata[i][j];
+                }
+                const double t = (1. * x[cols[i]]) * dpsi;
+                atb[i] = first ? t : t + 1. * atb[i];
+            }
+            first = false;
+        }
+        double cv[3] = {0., 0., 0.};
+        bool ok = true;
+        if (dim == 1) {
+            if (ata[0][0] == 0.) ok = false;
+            else cv[0] = (1. * (1. / ata[0][0])) * atb[0];
+        } else if (dim == 2) {
+            const double m11 = ata[0][0], m12 = ata[0][1], m21 = ata[1][0], m22 = ata[1][1];
+            const double determinant = m11 * m22 - m21 * m12;
+            if (determinant == 0.) ok = false;
+            else {
+                const double i00 = m22 / determinant, i01 = -m12 / determinant, i10 = -m21 / determinant, i11 = m11 / determinant;
+                cv[0] = (1. * i01) * atb[1] + 1. * ((1. * i00) * atb[0]);
+                cv[1] = (1. * i11) * atb[1] + 1. * ((1. * i10) * atb[0]);
+            }
+        } else if (dim == 3) {
+            if (!inverse3(ata)) ok = false;
+            else inv_times3(ata, atb, cv);
+        }
+        double comp[3] = {0., 0., 0.};
+        if (ok)
+            for (int j = 0; j < dim; ++j) comp[cols[j]] = cv[j];
+        u[c] = comp[0] != comp[0] ? 0. : comp[0];
+        v[c] = comp[1] != comp[1] ? 0. : comp[1];
+        w[c] = comp[2] != comp[2] ? 0. : comp[2];
+    }
+}
+
 // ------------------------------------------------------------------ K10: face flux / face pressure
 struct FaceArgs {
     const double *u, *v, *w, *p, *gp, *du, *dv, *dw;
@@ -605,8 +834,8 @@ static int validate_settings(const OrcSettings &s) {
     if (!(s.momentum == ORC_MOMENTUM_UD || s.momentum == ORC_MOMENTUM_CD1 || is_tvd(s.momentum)))
         return set_error(ORC_ERR_UNSUPPORTED_SCHEME, "unsupported momentum scheme");  // discretization.rs:287
     if (s.diffusion != ORC_DIFFUSION_CD) return set_error(ORC_ERR_UNSUPPORTED_SCHEME, "unsupported diffusion scheme");  // :50
-    if (s.gradient_reconstruction != ORC_GRAD_GREEN_GAUSS_CELL)
-        return set_error(ORC_ERR_UNSUPPORTED_SCHEME, "unsupported gradient scheme (Green-Gauss cell-based only)");  // solver.rs:870,901,948
+    if (s.gradient_reconstruction != ORC_GRAD_GREEN_GAUSS_CELL && s.gradient_reconstruction != ORC_GRAD_LEAST_SQUARES)
+        return set_error(ORC_ERR_UNSUPPORTED_SCHEME, "unsupported gradient scheme");  // solver.rs:870,901,948
     if (!(s.pressure_interpolation == ORC_PINTERP_LINEAR || s.pressure_interpolation == ORC_PINTERP_LINEAR_WEIGHTED ||
           s.pressure_interpolation == ORC_PINTERP_SECOND_ORDER))
         return set_error(ORC_ERR_UNSUPPORTED_SCHEME, "unsupported pressure interpolation");  // solver.rs:1136,1145
@@ -683,6 +912,13 @@ int solver_init(SolverState &s, OrcMesh *m, const OrcSettings *settings, double 
 
 int k_gradients(SolverState &s, bool need_gu) {
     OrcMesh &m = *s.mesh;
+    if (s.settings.gradient_reconstruction == ORC_GRAD_LEAST_SQUARES) {
+        hipLaunchKernelGGL(grad_p_lsq_k, dim3(grid_for(s.n)), dim3(kBlock), 0, ctx().stream, m.dev(), s.p.p, s.gp.p, s.dev_status.p);
+        if (need_gu)
+            hipLaunchKernelGGL(grad_u_lsq_k, dim3(grid_for(s.n)), dim3(kBlock), 0, ctx().stream, m.dev(), s.u.p, s.v.p, s.w.p, s.gu.p, s.dev_status.p);
+        ORC_HIP(hipGetLastError());
+        return ORC_OK;
+    }
     hipLaunchKernelGGL(grad_p_k, dim3(grid_for(s.n)), dim3(kBlock), 0, ctx().stream, m.dev(), s.p.p, s.gp.p, s.settings.q1_compat, s.dev_status.p);
     if (need_gu)
         hipLaunchKernelGGL(grad_u_k, dim3(grid_for(s.n)), dim3(kBlock), 0, ctx().stream, m.dev(), s.u.p, s.v.p, s.w.p, s.gu.p, s.dev_status.p);
@@ -1168,6 +1404,35 @@ int initialize_pressure_field_dev(SolverState &s) {
     s.stats.cache = nullptr;
     ORC_TRY(iterative_solve_dev(mesh_view(s, s.a_p.p), s.b_p.p, s.p.p, 10, ORC_SOLVER_JACOBI, 0.1, 1e-6, ORC_PRECOND_JACOBI, s.arena, &s.stats));
     return fetch_status(s);
+}
+
+// initialize_velocity_field (solver.rs:511-696): potential psi from ten Jacobi-preconditioned BiCGSTAB iterations on the
+// psi system (assembled in s.a_p / s.b_p, solved into s.p_prime), then u, v, w = least-squares gradient of psi.
+int initialize_velocity_field_dev(SolverState &s) {
+    OrcMesh &m = *s.mesh;
+    ORC_TRY(s.a_p.zero());
+    hipLaunchKernelGGL(psi_system_k, dim3(grid_for(s.n)), dim3(kBlock), 0, ctx().stream, m.dev(), m.pat.dev(), s.a_p.p, s.b_p.p, s.dev_status.p);
+    ORC_HIP(hipGetLastError());
+    ORC_TRY(vec_fill(s.p_prime.p, 0., s.n));
+    ctx().breakdown_guard = s.settings.breakdown_guard != 0;
+    ctx().reduction_order = s.settings.reduction_order;
+    s.stats.cache = nullptr;
+    ORC_TRY(iterative_solve_dev(mesh_view(s, s.a_p.p), s.b_p.p, s.p_prime.p, 10, ORC_SOLVER_BICGSTAB, 0.1, 1e-6, ORC_PRECOND_JACOBI, s.arena, &s.stats));  // :595-604
+    if (m.halo.active()) ORC_TRY(m.halo.exchange(s.p_prime.p));
+    hipLaunchKernelGGL(psi_velocity_k, dim3(grid_for(s.n)), dim3(kBlock), 0, ctx().stream, m.dev(), s.p_prime.p, s.u.p, s.v.p, s.w.p);
+    ORC_HIP(hipGetLastError());
+    return fetch_status(s);
+}
+
+// the gradient pass solve_steady runs after its loop (solver.rs:227-242): the accumulated values are never used, but an
+// unsupported scheme or a singular least-squares matrix still panics there
+int post_loop_gradients_dev(SolverState &s) {
+    HaloPlan &H = s.mesh->halo;
+    if (H.active()) { double *f[4] = {s.u.p, s.v.p, s.w.p, s.p.p}; ORC_TRY(H.exchange(f, 4)); }
+    ORC_TRY(k_gradients(s, true));
+    int st = fetch_status(s);
+    if (H.active()) st = comm_global_status(st);
+    return st;
 }
 
 // initialize_flow (solver.rs:246-352).  `s` must have been set up with UD / LinearWeighted / LinearWeighted

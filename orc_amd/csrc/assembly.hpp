@@ -117,6 +117,8 @@ int fetch_status(SolverState &s);
 int check_boundary_conditions(const OrcMesh &m);       // solver.rs:710-772: 0 PressureOnly, 1 VelocityOnly, 2 Hybrid, < 0 = -status
 int initialize_pressure_field_dev(SolverState &s);     // solver.rs:414-509
 int initialize_flow_dev(SolverState &s, uint64_t iteration_count);  // solver.rs:246-352
+int initialize_velocity_field_dev(SolverState &s);     // solver.rs:511-696 (psi in s.p_prime, velocities in s.u/v/w)
+int post_loop_gradients_dev(SolverState &s);           // solver.rs:227-242
 
 }  // namespace orc
 

@@ -40,7 +40,7 @@ int reduce_partials(const double *partials, int count, int nq, double *out, bool
 
 // ------------------------------------------------------------------ reference-order reductions (verification mode)
 // OrcSettings.reduction_order = ORC_REDUCTION_REFERENCE: every dot product / norm of the solvers is evaluated in the
-// association of nalgebra 0.32.4's `dotx` (base/blas.rs; restated in oracle/sparse.c or_dot): eight running accumulators
+// association of nalgebra 0.32.4's `dotx` (base/blas.rs): eight running accumulators
 // over blocks of 8, folded as res += (acc0+acc4); (acc1+acc5); (acc2+acc6); (acc3+acc7), then the tail left to right.
 // Lane k of one wavefront owns accumulator k and walks its elements in order — n/8 dependent additions, so this is a
 // slow path (microseconds per thousand rows); it exists so that a device solve can be compared with the reference's

@@ -133,6 +133,7 @@ const char *orc_status_string(int st) {
     case ORC_ERR_MESH_FORMAT: return "malformed mesh or data file";                // io.rs:32-571
     case ORC_ERR_NO_BOUNDARY_CONDITIONS: return "You must set boundary conditions."; // solver.rs:770
     case ORC_ERR_ZONE_NOT_FOUND: return "face zone should exist in mesh";          // mesh.rs:194
+    case ORC_ERR_SINGULAR_MATRIX: return "called `Option::unwrap()` on a `None` value";  // solver.rs:850,943 (try_inverse)
     default: return "unknown status";
     }
 }

@@ -146,8 +146,15 @@ def initialize_flow(mesh, mu, rho, iteration_count, settings=None):
     return u, v, w, p
 
 
+def initialize_velocity_field(mesh, settings=None):
+    """solver::initialize_velocity_field (solver.rs:511-696) -> (u, v, w, psi)."""
+    u, v, w, psi = (np.zeros(mesh.n_cells) for _ in range(4))
+    check(lib().orc_initialize_velocity_field(mesh.ptr, C.byref(settings) if settings is not None else None, _p(u), _p(v), _p(w), _p(psi)))
+    return u, v, w, psi
+
+
 def initialize_flow_new(mesh, mu, rho, iteration_count):
-    """solver::initialize_flow_new (solver.rs:354-410), pressure-constrained arms -> (u, v, w, p)."""
+    """solver::initialize_flow_new (solver.rs:354-410) -> (u, v, w, p)."""
     u, v, w, p = (np.zeros(mesh.n_cells) for _ in range(4))
     check(lib().orc_initialize_flow_new(mesh.ptr, C.c_double(mu), C.c_double(rho), C.c_uint64(iteration_count),
                                         _p(u), _p(v), _p(w), _p(p)))

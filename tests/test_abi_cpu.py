@@ -40,9 +40,9 @@ def test_settings_default_layout_matches_reference_defaults(lib, oracle):
     assert (s.momentum, s.diffusion, s.pressure_interpolation, s.velocity_interpolation, s.gradient_reconstruction) == (1, 0, 3, 2, 0)
     assert (s.solver_type, s.preconditioner, s.iterations) == (2, 1, 50)
     assert (s.momentum_relaxation, s.pressure_relaxation, s.relaxation, s.relative_convergence_threshold) == (0.5, 0.01, 0.5, 1e-3)
-    assert s.q1_compat == 1 and s.frozen_diagonals == 1 and s.breakdown_guard == 1
+    assert s.q1_compat == 1 and s.frozen_diagonals == 1 and s.breakdown_guard == 1 and s.reduction_order == 0
     o = oracle.default_settings()
-    assert C.sizeof(s) == C.sizeof(o) == 80
+    assert C.sizeof(s) == C.sizeof(o) == 88
     assert o.frozen_diagonals == 0 and o.breakdown_guard == 0  # the oracle defaults to the reference's own behaviour
     for f, _ in s._fields_[:13]:
         assert getattr(s, f) == getattr(o, f), f
@@ -51,7 +51,7 @@ def test_settings_default_layout_matches_reference_defaults(lib, oracle):
     exe = os.path.join(ROOT, "tests", ".sizeof_tmp")
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), "-x", "c", "-", "-o", exe], input=src.encode(), check=True)
     try:
-        assert int(subprocess.check_output([exe])) == 80
+        assert int(subprocess.check_output([exe])) == 88
     finally:
         os.remove(exe)
 

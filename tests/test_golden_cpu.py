@@ -105,3 +105,18 @@ def test_initialize_pressure_field_is_bounded_by_bcs(oracle, mesh_path):
     H.channel_bcs(om)
     st, p = oracle.initialize_pressure_field(om)
     assert st == 0 and p.min() >= -0.01 - 1e-6 and p.max() <= 1e-6  # between the inlet (-dp_dx * DX) and outlet (0) values
+
+
+def test_couette_multigrid_golden_is_a_fixed_point_of_the_oracle(oracle, mesh_path):
+    """tests/golden/couette_multigrid_converged.npz holds the converged state it claims to: restarted from it, the oracle
+    (reference mode, default stack) is kicked by its first iteration — Rhie-Chow reads the initial unit diagonals there
+    (SURVEY Q3), 1.4e-4 in u — and is back on the stored fields after 100 iterations (1e-8 in u, 1e-7 in p)."""
+    import helpers as H
+    g = np.load(os.path.join(GOLDEN, "couette_multigrid_converged.npz"))
+    om = oracle.Mesh.read(mesh_path("couette_flow_128x64x1"))
+    H.channel_bcs(om, top_wall_velocity=5e-4, dp_dx=10.0)
+    f = [np.ascontiguousarray(g[k]).copy() for k in ("u", "v", "w", "p")]
+    st, rep = oracle.solve_steady(om, *f, oracle.default_settings(momentum=oracle.CD1, solver_type=oracle.MULTIGRID, iterations=50,
+                                                                  frozen_diagonals=0), 1000.0, 1e-3, 100, report=True)
+    assert st == 0 and rep[-1][4] < 2e-9
+    assert H.rel_l2(f[0], g["u"]) < 3e-8 and H.rel_l2(f[3], g["p"]) < 3e-7

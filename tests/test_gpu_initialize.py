@@ -59,9 +59,8 @@ def test_check_boundary_conditions(gpu, oracle, mesh_path):
     a.set_zone("INLET", H.BC_VINLET, 0.0, (1e-3, 0.0, 0.0))
     dm.update_zones()
     assert check_boundary_conditions(dm) == VELOCITY_ONLY  # one pressure zone left
-    with pytest.raises(OrcError) as e:  # initialize_velocity_field is outside the scope table
-        initialize_flow_new(dm, 1e-3, 1000.0, 10)
-    assert e.value.status == 8
+    u, v, w, p = initialize_flow_new(dm, 1e-3, 1000.0, 10)  # VelocityOnly -> initialize_velocity_field, pressure stays zero
+    assert not p.any() and np.isfinite(u).all() and np.abs(u).max() > 0
     for z in ("INLET", "OUTLET", "WALL"):
         a.set_zone(z, H.BC_WALL)
     dm.update_zones()

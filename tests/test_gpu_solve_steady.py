@@ -162,3 +162,60 @@ def test_nan_field_reports_solution_diverged(gpu, oracle, mesh_path):
     # product default (breakdown_guard=1): the zero-RHS solves freeze instead of dividing 0/0
     st_g = solve_steady(dm, *z, NumericalSettings.default(**kw), 1000.0, 1e-3, 2, raise_on_error=False)
     assert st_g == 0 and all(np.isfinite(x).all() for x in z) and np.abs(z[0]).max() > 0
+
+
+@pytest.mark.parametrize("momentum", [1])
+def test_channel_flow_converged_fields_multigrid_reference_mode(gpu, oracle, mesh_path, momentum):
+    """The same north-star criterion with the reference's DEFAULT solver — solver_type = Multigrid, 50 smoother
+    iterations, Jacobi preconditioner (lib.rs:76-85), the configuration the benchmark runs: device (tree reductions,
+    frozen diagonals) against the oracle in the reference's in-place mode, converged u/v/w/p within 1e-6 rel-L2."""
+    from orc_amd.settings import NumericalSettings
+    from orc_amd.solver import Solver
+    from conftest import splitmix64_uniform
+    om, dm, a = setup(oracle, mesh_path, "channel_flow")
+    n = dm.n_cells
+    cc = np.asarray(a["cell_centroid"])
+    u0 = H.analytical_poiseuille(cc[:, 1]) * (1 + 0.02 * splitmix64_uniform(n, 1))
+    v0 = 1e-7 * splitmix64_uniform(n, 2)
+    w0 = 1e-12 * splitmix64_uniform(n, 3)
+    p0 = -0.01 * (1 - cc[:, 0] / 0.002) * (1 + 0.01 * splitmix64_uniform(n, 4))
+    kw = dict(momentum=momentum, solver_type=MULTIGRID, iterations=50)
+    uo, vo, wo, po_ = (x.copy() for x in (u0, v0, w0, p0))
+    st, rep = oracle.solve_steady(om, uo, vo, wo, po_, oracle.default_settings(frozen_diagonals=0, **kw), 1000.0, 1e-3, 1500, report=True)
+    assert st == 0 and rep[-1][4] < 1e-8  # velocity correction norm: converged
+    s = Solver(dm, NumericalSettings.default(frozen_diagonals=1, **kw), 1000.0, 1e-3)
+    s.set_fields(u0, v0, w0, p0)
+    s.iterate(1500)
+    u, v, w, p = s.get_fields()
+    assert H.rel_l2(u, uo) < 1e-6 and H.rel_l2(p, po_) < 1e-6
+    assert np.linalg.norm(v - vo) < 1e-6 * np.linalg.norm(uo) and np.linalg.norm(w - wo) < 1e-6 * np.linalg.norm(uo)
+    y = cc[:, 1]
+    assert H.rel_l2(u, H.analytical_poiseuille(y)) < 0.01
+
+
+def test_couette_converged_fields_multigrid_golden(gpu, oracle, mesh_path):
+    """couette_flow_128x64x1.msh (8001 cells, moving top wall) with the reference's default stack: the device's converged
+    fields against tests/golden/couette_multigrid_converged.npz — the oracle's converged fields in the reference's
+    in-place mode (1500 iterations, about three minutes of CPU, hence stored; tests/test_golden_cpu.py checks that the
+    stored fields are a fixed point of the oracle)."""
+    import os
+    from conftest import GOLDEN
+    from orc_amd.settings import NumericalSettings
+    from orc_amd.solver import Solver
+    sys_path = os.path.join(GOLDEN, "make_golden_couette_multigrid.py")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_couette_multigrid", sys_path)
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    om, dm, a = setup(oracle, mesh_path, "couette_flow_128x64x1", top_wall_velocity=5e-4, dp_dx=10.0)
+    g = np.load(os.path.join(GOLDEN, "couette_multigrid_converged.npz"))
+    u0, v0, w0, p0 = gen.start_fields(np.asarray(a["cell_centroid"]))
+    s = Solver(dm, NumericalSettings.default(momentum=1, solver_type=MULTIGRID, iterations=50, frozen_diagonals=1), 1000.0, 1e-3)
+    s.set_fields(u0, v0, w0, p0)
+    st, rep = s.iterate(int(g["iterations"]), report=True, raise_on_error=False)
+    assert st == 0 and rep[-1][6] < 1e-8
+    u, v, w, p = s.get_fields()
+    assert H.rel_l2(u, g["u"]) < 1e-6 and H.rel_l2(p, g["p"]) < 1e-6
+    assert np.linalg.norm(v - g["v"]) < 1e-6 * np.linalg.norm(g["u"]) and np.linalg.norm(w - g["w"]) < 1e-6 * np.linalg.norm(g["u"])
+    y = np.asarray(a["cell_centroid"])[:, 1]
+    assert H.rel_l2(u, H.analytical_poiseuille(y, dp_dx=10.0, u_top=5e-4)) < 0.01
