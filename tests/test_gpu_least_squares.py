@@ -130,5 +130,6 @@ def test_initialize_velocity_field_bit_exact(gpu, oracle, mesh_path, name):
         assert same_bits(x, y)
     assert np.abs(u).max() > 0
     if check_boundary_conditions(dm) == VELOCITY_ONLY:
-        un, vn, wn, pn = initialize_flow_new(dm, 1e-3, 1000.0, 10)
-        assert not pn.any() and H.rel_l2(un, uo) < 1e-9
+        un, vn, wn, pn = initialize_flow_new(dm, 1e-3, 1000.0, 10)  # the same arm through initialize_flow_new (product defaults)
+        ud = initialize_velocity_field(dm)[0]
+        assert not pn.any() and same_bits(un, ud) and np.isfinite(un).all()
