@@ -62,6 +62,28 @@ OrcMesh *orc_mesh_create_partitioned(int64_t n_owned, int64_t n_cells, int64_t n
                                      const int32_t *peers, const int64_t *send_ptr, const int64_t *send_idx, const int64_t *recv_ptr,
                                      int *status);
 int64_t orc_mesh_n_owned(const OrcMesh *m);
+/* Cell partitioning of any mesh (host only, no device needed): the cells are put in `ordering` (OrcCellOrdering) and cut
+ * into n_ranks contiguous blocks; the result holds rank `rank`'s arrays exactly as orc_mesh_create_partitioned takes them
+ * (owned cells in block order, ghost blocks per peer sorted by position in the order, faces touching an owned cell in
+ * ascending global id).  Every rank calls it on the same global arrays (those of orc_mesh_create / orc_mesh_data_arrays);
+ * my send list to a peer and that peer's ghost block of my cells coincide by construction.  global_ids[n_local] maps a
+ * local cell to its ORC index: fields are scattered / gathered through it, so the permutation stays internal.
+ * n_ranks = 1 gives the whole mesh renumbered (e.g. RCM row ordering on one GPU). */
+typedef struct OrcPartition OrcPartition;
+OrcPartition *orc_mesh_partition(int64_t n_cells, int64_t n_faces, const int64_t *face_c0, const int64_t *face_c1, const int32_t *face_zone,
+                                 const double *face_area, const double *face_normal, const double *face_centroid,
+                                 const double *cell_centroid, const double *cell_volume, const int64_t *cell_face_ptr,
+                                 const int64_t *cell_faces, int32_t n_ranks, int32_t rank, int32_t ordering, int *status);
+void orc_partition_destroy(OrcPartition *p);
+int orc_partition_sizes(const OrcPartition *p, int64_t *n_owned, int64_t *n_local, int64_t *n_global, int64_t *n_faces, int64_t *n_cell_faces,
+                        int32_t *n_peers, int64_t *n_send);
+/* any pointer may be NULL; sizes from orc_partition_sizes (send_ptr / recv_ptr: n_peers + 1) */
+int orc_partition_arrays(const OrcPartition *p, int64_t *face_c0, int64_t *face_c1, int32_t *face_zone, double *face_area, double *face_normal,
+                         double *face_centroid, double *cell_centroid, double *cell_volume, int64_t *cell_face_ptr, int64_t *cell_faces,
+                         int64_t *global_ids, int64_t *global_face_ids, int32_t *peers, int64_t *send_ptr, int64_t *send_idx, int64_t *recv_ptr);
+/* = orc_mesh_create_partitioned on the partition's arrays and the (global) zone tables */
+OrcMesh *orc_partition_upload(const OrcPartition *p, int32_t n_zones, const int32_t *zone_type, const double *zone_scalar,
+                              const double *zone_vector, int *status);
 /* mesh.get_face_zone(name).zone_type / scalar_value / vector_value = ... (tests.rs:60-76) */
 int orc_mesh_update_zones(OrcMesh *m, const int32_t *zone_type, const double *zone_scalar, const double *zone_vector);
 void orc_mesh_destroy(OrcMesh *m);

@@ -120,6 +120,10 @@ enum OrcStatus {
  * reference's arithmetic at any iteration count (verification mode; single GPU only). */
 enum OrcReductionOrder { ORC_REDUCTION_TREE = 0, ORC_REDUCTION_REFERENCE = 1 };
 
+/* Cell orders for orc_mesh_partition: ORC's own numbering (io.rs:404-438), reverse Cuthill-McKee over the face-neighbour
+ * graph, or sorted along the longest extent of the domain. */
+enum OrcCellOrdering { ORC_ORDER_ORC = 0, ORC_ORDER_RCM = 1, ORC_ORDER_GEOMETRIC = 2 };
+
 /* settings::NumericalSettings + settings::MatrixSolverSettings (lib.rs:14-56), flattened.
  * orc_settings_default() fills in lib.rs:58-86. */
 typedef struct OrcSettings {

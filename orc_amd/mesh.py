@@ -98,6 +98,26 @@ def write_hex_channel_msh(path, nx, ny, nz, lx=0.002, ly=0.001, lz=None):
                                           C.c_double(ly), C.c_double(lz)))
 
 
+def renumber_cells(a, new_of_old):
+    """The same mesh with cell `c` renamed new_of_old[c] (faces keep their ids, orientation and per-cell ascending order):
+    what a mesh generator with another cell numbering would have written.  Used to measure how much the products depend
+    on the numbering (config 5) and to undo it with the RCM ordering of orc_mesh_partition."""
+    new_of_old = np.asarray(new_of_old, dtype=np.int64)
+    n = len(new_of_old)
+    old_of_new = np.empty(n, np.int64)
+    old_of_new[new_of_old] = np.arange(n)
+    c0, c1 = np.asarray(a["face_c0"]), np.asarray(a["face_c1"])
+    cfp, cf = np.asarray(a["cell_face_ptr"]), np.asarray(a["cell_faces"])
+    counts = np.diff(cfp)[old_of_new]
+    new_cfp = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    idx = np.concatenate([np.arange(cfp[o], cfp[o + 1]) for o in old_of_new]) if n else np.zeros(0, np.int64)
+    out = MeshArrays(a)
+    out.update(face_c0=new_of_old[c0], face_c1=np.where(c1 >= 0, new_of_old[np.maximum(c1, 0)], -1),
+               cell_centroid=np.asarray(a["cell_centroid"])[old_of_new].copy(), cell_volume=np.asarray(a["cell_volume"])[old_of_new].copy(),
+               cell_face_ptr=new_cfp, cell_faces=cf[idx].copy())
+    return out
+
+
 def set_channel_bcs(a, top_wall_velocity=0.0, dp_dx=5.0, dx=0.002):
     """Boundary conditions of tests::channel_flow::solve_channel_flow (tests.rs:60-76)."""
     T = FaceConditionTypes

@@ -79,6 +79,53 @@ def slab_arrays(nx, ny, nz_local, rank, world, lx=0.002, ly=0.001, dz=1e-4):
     return out, halo, global_ids
 
 
+# ------------------------------------------------------------------ general partitioner (orc_mesh_partition, host only)
+ORDER_ORC, ORDER_RCM, ORDER_GEOMETRIC = 0, 1, 2
+
+
+def partition_arrays(a, n_ranks, rank, ordering=ORDER_ORC):
+    """Rank `rank`'s part of ANY mesh `a` (MeshArrays of the whole mesh) cut into n_ranks contiguous blocks of `ordering`:
+    (MeshArrays of the local mesh, halo dict, global_ids[n_local]) — the same triple slab_arrays returns."""
+    L = lib()
+    L.orc_mesh_partition.restype = C.c_void_p
+    k = [np.ascontiguousarray(a["face_c0"], np.int64), np.ascontiguousarray(a["face_c1"], np.int64),
+         np.ascontiguousarray(a["face_zone"], np.int32), np.ascontiguousarray(a["face_area"], np.float64),
+         np.ascontiguousarray(a["face_normal"], np.float64), np.ascontiguousarray(a["face_centroid"], np.float64),
+         np.ascontiguousarray(a["cell_centroid"], np.float64), np.ascontiguousarray(a["cell_volume"], np.float64),
+         np.ascontiguousarray(a["cell_face_ptr"], np.int64), np.ascontiguousarray(a["cell_faces"], np.int64)]
+    st = C.c_int(0)
+    ptr = L.orc_mesh_partition(C.c_int64(len(k[7])), C.c_int64(len(k[3])), k[0].ctypes.data_as(_I64), k[1].ctypes.data_as(_I64),
+                               k[2].ctypes.data_as(_I32), k[3].ctypes.data_as(_F64), k[4].ctypes.data_as(_F64), k[5].ctypes.data_as(_F64),
+                               k[6].ctypes.data_as(_F64), k[7].ctypes.data_as(_F64), k[8].ctypes.data_as(_I64), k[9].ctypes.data_as(_I64),
+                               C.c_int32(n_ranks), C.c_int32(rank), C.c_int32(ordering), C.byref(st))
+    check(st.value)
+    ptr = C.c_void_p(ptr)
+    try:
+        no, nl, ng, nf, ncf, ns = (C.c_int64() for _ in range(6))
+        npeer = C.c_int32()
+        check(L.orc_partition_sizes(ptr, C.byref(no), C.byref(nl), C.byref(ng), C.byref(nf), C.byref(ncf), C.byref(npeer), C.byref(ns)))
+        F, n, P = nf.value, nl.value, npeer.value
+        out = MeshArrays(
+            face_c0=np.empty(F, np.int64), face_c1=np.empty(F, np.int64), face_zone=np.empty(F, np.int32), face_area=np.empty(F),
+            face_normal=np.empty((F, 3)), face_centroid=np.empty((F, 3)), cell_centroid=np.empty((n, 3)), cell_volume=np.empty(n),
+            cell_face_ptr=np.empty(n + 1, np.int64), cell_faces=np.empty(ncf.value, np.int64),
+            zone_type=np.array(a["zone_type"], dtype=np.int32).copy(), zone_scalar=np.array(a["zone_scalar"], dtype=np.float64).copy(),
+            zone_vector=np.array(a["zone_vector"], dtype=np.float64).copy(), zone_names=list(a.get("zone_names", [])))
+        gids, gfaces = np.empty(n, np.int64), np.empty(F, np.int64)
+        peers, sp, si, rp = np.empty(P, np.int32), np.empty(P + 1, np.int64), np.empty(ns.value, np.int64), np.empty(P + 1, np.int64)
+        check(L.orc_partition_arrays(ptr, out["face_c0"].ctypes.data_as(_I64), out["face_c1"].ctypes.data_as(_I64),
+                                     out["face_zone"].ctypes.data_as(_I32), out["face_area"].ctypes.data_as(_F64),
+                                     out["face_normal"].ctypes.data_as(_F64), out["face_centroid"].ctypes.data_as(_F64),
+                                     out["cell_centroid"].ctypes.data_as(_F64), out["cell_volume"].ctypes.data_as(_F64),
+                                     out["cell_face_ptr"].ctypes.data_as(_I64), out["cell_faces"].ctypes.data_as(_I64),
+                                     gids.ctypes.data_as(_I64), gfaces.ctypes.data_as(_I64), peers.ctypes.data_as(_I32),
+                                     sp.ctypes.data_as(_I64), si.ctypes.data_as(_I64), rp.ctypes.data_as(_I64)))
+    finally:
+        L.orc_partition_destroy(ptr)
+    halo = dict(n_owned=no.value, n_global=ng.value, peers=peers, send_ptr=sp, send_idx=si, recv_ptr=rp, global_face_ids=gfaces)
+    return out, halo, gids
+
+
 class PartitionedMesh(Mesh):
     """Device mesh of one rank (orc_mesh_create_partitioned)."""
 

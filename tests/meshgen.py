@@ -142,3 +142,10 @@ def mixed_channel_bcs(set_zone, zone_names, top_wall_velocity=0.0, dp=0.01):
             set_zone(name, 5, 0.0, (0.0, 0.0, 0.0))
         else:
             set_zone(name, 7, 0.0, (0.0, 0.0, 0.0))
+
+
+def shuffle_cells(a, seed=1):
+    """MeshArrays with the cells renumbered by a seeded random permutation (an "arbitrarily numbered" mesh)."""
+    from orc_amd.mesh import renumber_cells
+    n = len(a["cell_volume"])
+    return renumber_cells(a, np.random.default_rng(seed).permutation(n))

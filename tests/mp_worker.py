@@ -30,10 +30,86 @@ def global_fields(a):
     return u, v, w, p
 
 
+def general_partition_checks(rank, world):
+    """orc_mesh_partition on meshes that were READ (channel_flow.msh, the skewed prism + hexahedron mesh) with every
+    ordering: the ranks' owned blocks tile the mesh, ghost blocks and send lists agree across ranks (checked by really
+    exchanging global ids over gloo), every owned cell keeps its faces with the global orientation, and a distributed
+    product on the local patterns equals the global one."""
+    import tempfile
+    import scipy.sparse as sps
+    import meshgen
+    from orc_amd import io as orc_io
+    cases = []
+    d = orc_io.read_mesh(os.path.join(ROOT, "tests", "golden", "meshes", "channel_flow.msh"))
+    cases.append(("channel_flow", d.arrays()))
+    tmp = os.path.join(tempfile.gettempdir(), "orc_mixed_%d.msh" % os.getpid())
+    meshgen.write_mixed_channel_msh(tmp, 7, 5, 4, skew=0.2)
+    cases.append(("prism_hex", orc_io.read_mesh(tmp).arrays()))
+    os.remove(tmp)
+    for name, ag in cases:
+        ng = len(ag["cell_volume"])
+        c0g, c1g = np.asarray(ag["face_c0"]), np.asarray(ag["face_c1"])
+        m = c1g >= 0
+        A_glob = sps.csr_matrix((1.0 + 0.001 * np.arange(2 * m.sum()), (np.r_[c0g[m], c1g[m]], np.r_[c1g[m], c0g[m]])), shape=(ng, ng)).tocsr()
+        truth = 1000.0 + np.arange(ng, dtype=np.float64) * 0.5
+        for ordering in (parallel.ORDER_ORC, parallel.ORDER_RCM, parallel.ORDER_GEOMETRIC):
+            a, halo, gids = parallel.partition_arrays(ag, world, rank, ordering)
+            n_own = halo["n_owned"]
+            owned = [None] * world
+            dist.all_gather_object(owned, gids[:n_own].tolist())
+            allc = np.concatenate([np.asarray(o, dtype=np.int64) for o in owned])
+            assert len(allc) == ng and np.array_equal(np.sort(allc), np.arange(ng)), "owned blocks do not tile the mesh"
+            assert np.array_equal(np.asarray(a["cell_centroid"]), np.asarray(ag["cell_centroid"])[gids])
+            # faces of every owned cell: same count, ascending, global orientation and geometry
+            cfp, cf = np.asarray(a["cell_face_ptr"]), np.asarray(a["cell_faces"])
+            gcfp, gcf = np.asarray(ag["cell_face_ptr"]), np.asarray(ag["cell_faces"])
+            gf = halo["global_face_ids"]
+            assert np.all(np.diff(gf) > 0)
+            for c in range(n_own):
+                lf = cf[cfp[c]:cfp[c + 1]]
+                assert np.array_equal(gf[lf], gcf[gcfp[gids[c]]:gcfp[gids[c] + 1]])
+            assert np.array_equal(cfp[n_own:], np.full(len(gids) - n_own + 1, cfp[n_own])[:len(cfp[n_own:])])  # ghosts: no faces
+            assert np.array_equal(gids[np.asarray(a["face_c0"])], c0g[gf])
+            l1 = np.asarray(a["face_c1"])
+            assert np.array_equal(np.where(l1 >= 0, gids[np.maximum(l1, 0)], -1), c1g[gf])
+            assert np.array_equal(np.asarray(a["face_normal"]), np.asarray(ag["face_normal"])[gf])
+            # halo: what the peers send must be exactly my ghost cells, in order
+            x = np.full(len(gids), np.nan)
+            x[:n_own] = truth[gids[:n_own]]
+            peers = list(halo["peers"])
+            sp, rp = halo["send_ptr"], halo["recv_ptr"]
+            assert rp[-1] == len(gids) - n_own
+            send = x[halo["send_idx"]]
+            recv = np.empty(int(rp[-1]))
+            parallel.exchange_over_dist(dist, rank, peers, send, list(sp[:-1]), list(np.diff(sp)), recv, list(rp[:-1]), list(np.diff(rp)))
+            x[n_own:] = recv
+            assert np.array_equal(x, truth[gids]), "%s ordering %d: ghost values differ from the owners'" % (name, ordering)
+            # distributed product on the local pattern (ghost columns included) == global product
+            rows, cols, vals = [], [], []
+            lc0, lc1 = np.asarray(a["face_c0"]), np.asarray(a["face_c1"])
+            for f in range(len(lc0)):
+                if lc1[f] >= 0:
+                    for r_, c_ in ((lc0[f], lc1[f]), (lc1[f], lc0[f])):
+                        if r_ < n_own:
+                            rows.append(r_); cols.append(c_); vals.append(A_glob[gids[r_], gids[c_]])
+            A_loc = sps.csr_matrix((vals, (rows, cols)), shape=(n_own, len(gids)))
+            assert np.allclose(A_loc @ x, (A_glob @ truth)[gids[:n_own]], rtol=1e-14, atol=0)
+    return True
+
+
 def main():
     mode = sys.argv[1]
     dist.init_process_group(backend="gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
+    if mode == "cpu_general":
+        ok = general_partition_checks(rank, world)
+        t = torch.tensor([1.0 if ok else 0.0])
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        dist.barrier()
+        if rank == 0:
+            print("MP_WORKER_OK" if t.item() == 1.0 else "MP_WORKER_FAIL", flush=True)
+        dist.destroy_process_group()
+        return
     nx, ny, nzl = 6, 5, 3
     a, halo, gids = parallel.slab_arrays(nx, ny, nzl, rank, world)
     ag = hex_channel(nx, ny, nzl * world)  # the global mesh (every rank builds it: small)
