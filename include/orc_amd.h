@@ -49,6 +49,21 @@ OrcMesh *orc_mesh_create(int64_t n_cells, int64_t n_faces, int32_t n_zones,
                          const int64_t *cell_face_ptr /*[n+1]*/, const int64_t *cell_faces,
                          const int32_t *zone_type, const double *zone_scalar, const double *zone_vector /*[3Z]*/,
                          int *status);
+/* The same mesh with its cells renumbered internally by `ordering` (OrcCellOrdering; ORC_ORDER_RCM = the north star's
+ * "rows sorted by RCM"): for meshes whose generator numbered the cells arbitrarily.  orc_solver_set_fields /
+ * orc_solver_get_fields / orc_solve_steady keep taking and returning fields in ORC order; matrices, patterns and the
+ * per-cell arrays of the assembly entry points are in the internal order, which orc_mesh_cell_order reports
+ * (global_ids[c] = ORC index of internal cell c).  A renumbered run is the reference's algorithm on a renumbered mesh: its
+ * iterates differ from the ORC-order run wherever the reference depends on the numbering (pairwise aggregation by row
+ * index), its converged fields do not. */
+OrcMesh *orc_mesh_create_reordered(int64_t n_cells, int64_t n_faces, int32_t n_zones,
+                                   const int64_t *face_c0, const int64_t *face_c1, const int32_t *face_zone,
+                                   const double *face_area, const double *face_normal, const double *face_centroid,
+                                   const double *cell_centroid, const double *cell_volume,
+                                   const int64_t *cell_face_ptr, const int64_t *cell_faces,
+                                   const int32_t *zone_type, const double *zone_scalar, const double *zone_vector,
+                                   int32_t ordering, int *status);
+int orc_mesh_cell_order(const OrcMesh *m, int64_t *global_ids /*[n]*/);
 /* One rank's part of a cell-partitioned mesh: local cells are numbered owned first [0, n_owned), then one
  * contiguous block of ghost cells per peer (recv_ptr, in peer order); cell_face_ptr gives ghost cells empty face lists;
  * faces are those touching an owned cell, in ascending global id with the global c0/c1 orientation.
@@ -270,6 +285,14 @@ int orc_hex_channel_generate(int64_t nx, int64_t ny, int64_t nz, double lx, doub
                              int64_t *cell_face_ptr, int64_t *cell_faces);
 /* writes the same mesh as an ASCII TGRID .msh that ORC's read_mesh (io.rs:32) accepts */
 int orc_hex_channel_write_msh(const char *path, int64_t nx, int64_t ny, int64_t nz, double lx, double ly, double lz);
+
+/* BASELINE config 5 workload: a box of nx x ny x nz blocks (nx >= 20) cut along x into regions of hexahedra, columns of
+ * triangular prisms, Kuhn tetrahedra (six per block) and one-block transition layers of pyramids, conforming
+ * throughout; about 2.7 cells per block, matrix rows of 5 / 6 / 7 entries.  Written as a TGRID .msh with triangular and
+ * quadrilateral faces in separate zones (the reference's reader cannot parse mixed sections, io.rs:232); zones FLUID,
+ * INLET, OUTLET, WALL, PERIODIC_-Z, PERIODIC_+Z and their "_TRI" twins, boundary zones of type 3 (wall). */
+int orc_mixed_channel_write_msh(const char *path, int64_t nx, int64_t ny, int64_t nz, double lx, double ly, double lz,
+                                int64_t *n_cells, int64_t *n_faces);
 
 /* ---------- multi-GPU (one process per GPU, RCCL over xGMI) ---------- */
 #define ORC_COMM_ID_BYTES 128

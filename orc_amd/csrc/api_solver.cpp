@@ -84,6 +84,39 @@ OrcMesh *orc_mesh_create_partitioned(int64_t n_owned, int64_t n_cells, int64_t n
     return m;
 }
 
+// The whole mesh renumbered by `ordering` (orc_mesh_partition with one rank): rows sorted by RCM for coalesced reads when
+// the generator's numbering is arbitrary.  Fields still go in and out in ORC order.
+OrcMesh *orc_mesh_create_reordered(int64_t n_cells, int64_t n_faces, int32_t n_zones, const int64_t *face_c0, const int64_t *face_c1,
+                                   const int32_t *face_zone, const double *face_area, const double *face_normal, const double *face_centroid,
+                                   const double *cell_centroid, const double *cell_volume, const int64_t *cell_face_ptr,
+                                   const int64_t *cell_faces, const int32_t *zone_type, const double *zone_scalar, const double *zone_vector,
+                                   int32_t ordering, int *status) {
+    int st = ORC_OK;
+    OrcPartition *P = orc_mesh_partition(n_cells, n_faces, face_c0, face_c1, face_zone, face_area, face_normal, face_centroid, cell_centroid,
+                                         cell_volume, cell_face_ptr, cell_faces, 1, 0, ordering, &st);
+    OrcMesh *m = nullptr;
+    if (P) {
+        m = orc_partition_upload(P, n_zones, zone_type, zone_scalar, zone_vector, &st);
+        if (m) {
+            m->h_global_ids.resize((size_t)n_cells);
+            st = orc_partition_arrays(P, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, m->h_global_ids.data(),
+                                      nullptr, nullptr, nullptr, nullptr, nullptr);
+            bool identity = true;
+            for (int64_t c = 0; c < n_cells && identity; ++c) identity = m->h_global_ids[(size_t)c] == c;
+            if (identity) m->h_global_ids.clear();
+        }
+        orc_partition_destroy(P);
+    }
+    if (status) *status = st;
+    return m;
+}
+
+int orc_mesh_cell_order(const OrcMesh *m, int64_t *global_ids) {
+    if (!m || !global_ids) return set_error(ORC_ERR_BAD_ARGUMENT, "null argument");
+    for (int64_t c = 0; c < m->n_cells; ++c) global_ids[c] = m->h_global_ids.empty() ? c : m->h_global_ids[(size_t)c];
+    return ORC_OK;
+}
+
 int orc_mesh_update_zones(OrcMesh *m, const int32_t *zone_type, const double *zone_scalar, const double *zone_vector) {
     if (!m) return set_error(ORC_ERR_BAD_ARGUMENT, "null mesh");
     ORC_TRY(m->ztype.upload(zone_type, (size_t)m->n_zones));
@@ -126,20 +159,32 @@ void orc_solver_destroy(OrcSolver *s) { delete s; }
 int orc_solver_set_fields(OrcSolver *s, const double *u, const double *v, const double *w, const double *p) {
     if (!s) return set_error(ORC_ERR_BAD_ARGUMENT, "null solver");
     const size_t n = (size_t)s->st.n;
-    ORC_TRY(s->st.u.upload(u, n));
-    ORC_TRY(s->st.v.upload(v, n));
-    ORC_TRY(s->st.w.upload(w, n));
-    ORC_TRY(s->st.p.upload(p, n));
+    const std::vector<int64_t> &g = s->st.mesh->h_global_ids;  // reordered mesh: internal cell c holds ORC cell g[c]
+    const double *src[4] = {u, v, w, p};
+    DevBuf<double> *dst[4] = {&s->st.u, &s->st.v, &s->st.w, &s->st.p};
+    std::vector<double> tmp;
+    for (int k = 0; k < 4; ++k) {
+        if (g.empty()) { ORC_TRY(dst[k]->upload(src[k], n)); continue; }
+        tmp.resize(n);
+        for (size_t c = 0; c < n; ++c) tmp[c] = src[k][g[c]];
+        ORC_TRY(dst[k]->upload(tmp.data(), n));
+    }
     return ORC_OK;
 }
 
 int orc_solver_get_fields(OrcSolver *s, double *u, double *v, double *w, double *p) {
     if (!s) return set_error(ORC_ERR_BAD_ARGUMENT, "null solver");
     const size_t n = (size_t)s->st.n;
-    ORC_TRY(s->st.u.download(u, n));
-    ORC_TRY(s->st.v.download(v, n));
-    ORC_TRY(s->st.w.download(w, n));
-    ORC_TRY(s->st.p.download(p, n));
+    const std::vector<int64_t> &g = s->st.mesh->h_global_ids;
+    double *dst[4] = {u, v, w, p};
+    DevBuf<double> *src[4] = {&s->st.u, &s->st.v, &s->st.w, &s->st.p};
+    std::vector<double> tmp;
+    for (int k = 0; k < 4; ++k) {
+        if (g.empty()) { ORC_TRY(src[k]->download(dst[k], n)); continue; }
+        tmp.resize(n);
+        ORC_TRY(src[k]->download(tmp.data(), n));
+        for (size_t c = 0; c < n; ++c) dst[k][g[c]] = tmp[c];
+    }
     return ORC_OK;
 }
 

@@ -38,6 +38,8 @@ struct OrcMesh {
     orc::DevBuf<double> area, nx, ny, nz, fcx, fcy, fcz, ccx, ccy, ccz, vol, zscal, zvec;
     orc::SellMatrix pat;  // shared sparsity of a_di, a_u, a_v, a_w, A_p
     std::vector<int64_t> h_row_ptr, h_col;  // the same pattern in CSR (ORC order) for the C ABI
+    std::vector<int64_t> h_global_ids;      // orc_mesh_create_reordered: ORC index of every internal cell (empty = identity);
+                                            // orc_solver_set_fields / get_fields / orc_solve_steady permute through it
     orc::MeshDev dev() const;
 };
 

@@ -216,3 +216,209 @@ extern "C" int orc_hex_channel_write_msh(const char *path, int64_t nx, int64_t n
     std::fclose(fp);
     return ORC_OK;
 }
+
+// ------------------------------------------------------------------ mixed tetrahedron / pyramid / prism / hexahedron channel (BASELINE config 5)
+// Not a restatement: the reference ships neither a generator nor a mixed-element fixture.  A box of nx x ny x nz blocks is
+// cut along x into regions — hexahedra | columns of triangular prisms | hexahedra | transition | Kuhn tetrahedra |
+// transition | hexahedra — that stay conforming: prism columns keep quadrilateral sides, the six Kuhn tetrahedra of a
+// block share its main diagonal (translation invariant, so neighbouring blocks agree on every face diagonal), and a
+// transition block is six pyramids about its centre whose pyramid facing the tetrahedra is itself split along the
+// Kuhn diagonal of that face.  Rows of the resulting matrices hold 5 (tet), 6 (pyramid, prism) or 7 (hex) entries.
+// The file is the TGRID subset ORC reads (io.rs:32-515): triangular and quadrilateral faces in SEPARATE zones, because
+// the reference's reader takes "tokens - 2" as the node count and cannot parse mixed sections (io.rs:232).  Faces are
+// oriented so that the reader's normal (n2 - n1) x (n1 - n0) points out of cell 0.
+namespace {
+
+struct FaceRec {
+    int64_t key[4];  // sorted node ids (key[3] = -1 for triangles)
+    int64_t nodes[4];
+    int64_t cell;
+    int nn;
+};
+
+struct MixedBuilder {
+    int64_t nx, ny, nz;
+    double lx, ly, lz;
+    std::vector<V3> coords;
+    std::vector<FaceRec> recs;
+    std::vector<V3> cell_sum;
+    std::vector<int> cell_cnt;
+    int64_t n_cells = 0;
+    int64_t grid_nodes;
+    int64_t node(int64_t i, int64_t j, int64_t k) const { return i + (nx + 1) * (j + (ny + 1) * k); }
+    int64_t new_cell() {
+        cell_sum.push_back({0., 0., 0.});
+        cell_cnt.push_back(0);
+        return n_cells++;
+    }
+    void face(int64_t cell, std::initializer_list<int64_t> ns) {
+        FaceRec r;
+        r.nn = (int)ns.size();
+        int q = 0;
+        for (int64_t v : ns) { r.nodes[q] = v; r.key[q] = v; ++q; }
+        if (r.nn == 3) { r.nodes[3] = -1; r.key[3] = -1; }
+        std::sort(r.key, r.key + r.nn);
+        r.cell = cell;
+        recs.push_back(r);
+        for (int t = 0; t < r.nn; ++t) { cell_sum[(size_t)cell] = add(cell_sum[(size_t)cell], coords[(size_t)r.nodes[t]]); ++cell_cnt[(size_t)cell]; }
+    }
+    void tet(int64_t a, int64_t b, int64_t c, int64_t d) {
+        const int64_t t = new_cell();
+        face(t, {a, b, c}); face(t, {a, b, d}); face(t, {a, c, d}); face(t, {b, c, d});
+    }
+    // pyramid over the quadrilateral q[0..3] (cyclic order) with apex p; split = two tetrahedra along the diagonal q[s] - q[s+2]
+    void pyramid(int64_t p, const int64_t q[4], int split) {
+        if (split < 0) {
+            const int64_t c = new_cell();
+            face(c, {q[0], q[1], q[2], q[3]});
+            for (int e = 0; e < 4; ++e) face(c, {q[e], q[(e + 1) & 3], p});
+        } else {
+            tet(p, q[split], q[(split + 1) & 3], q[(split + 2) & 3]);
+            tet(p, q[split], q[(split + 2) & 3], q[(split + 3) & 3]);
+        }
+    }
+};
+
+enum BlockKind { kHexBlock, kPrismBlock, kTetBlock, kTransitionBlock };
+
+}  // namespace
+
+extern "C" int orc_mixed_channel_write_msh(const char *path, int64_t nx, int64_t ny, int64_t nz, double lx, double ly, double lz,
+                                           int64_t *n_cells_out, int64_t *n_faces_out) {
+    if (!path || nx < 20 || ny < 1 || nz < 1) return ORC_ERR_BAD_ARGUMENT;
+    MixedBuilder B;
+    B.nx = nx; B.ny = ny; B.nz = nz; B.lx = lx; B.ly = ly; B.lz = lz;
+    B.grid_nodes = (nx + 1) * (ny + 1) * (nz + 1);
+    const int64_t ip0 = nx * 3 / 10, ip1 = nx * 45 / 100;         // prism columns
+    const int64_t it0 = nx / 2 + 1, it1 = nx * 85 / 100;          // Kuhn tetrahedra, one transition block either side
+    auto kind = [&](int64_t i) {
+        if (i >= ip0 && i < ip1) return kPrismBlock;
+        if (i >= it0 && i < it1) return kTetBlock;
+        if (i == it0 - 1 || i == it1) return kTransitionBlock;
+        return kHexBlock;
+    };
+    B.coords.reserve((size_t)B.grid_nodes + (size_t)(2 * ny * nz));
+    for (int64_t k = 0; k <= nz; ++k)
+        for (int64_t j = 0; j <= ny; ++j)
+            for (int64_t i = 0; i <= nx; ++i) B.coords.push_back({lx * (double)i / (double)nx, ly * (double)j / (double)ny, lz * (double)k / (double)nz});
+    for (int64_t k = 0; k < nz; ++k)
+        for (int64_t j = 0; j < ny; ++j)
+            for (int64_t i = 0; i < nx; ++i) {
+                // corners: v[dx + 2 dy + 4 dz]
+                int64_t v[8];
+                for (int c = 0; c < 8; ++c) v[c] = B.node(i + (c & 1), j + ((c >> 1) & 1), k + ((c >> 2) & 1));
+                const BlockKind kd = kind(i);
+                if (kd == kHexBlock) {
+                    const int64_t c = B.new_cell();
+                    B.face(c, {v[0], v[1], v[3], v[2]}); B.face(c, {v[4], v[5], v[7], v[6]});
+                    B.face(c, {v[0], v[1], v[5], v[4]}); B.face(c, {v[2], v[3], v[7], v[6]});
+                    B.face(c, {v[0], v[2], v[6], v[4]}); B.face(c, {v[1], v[3], v[7], v[5]});
+                } else if (kd == kPrismBlock) {  // two prisms along the diagonal v0 - v3 of the base
+                    const int64_t tri[2][3] = {{0, 1, 3}, {0, 3, 2}};
+                    for (int t = 0; t < 2; ++t) {
+                        const int64_t c = B.new_cell();
+                        const int64_t a = tri[t][0], b = tri[t][1], d = tri[t][2];
+                        B.face(c, {v[a], v[b], v[d]});
+                        B.face(c, {v[a + 4], v[b + 4], v[d + 4]});
+                        B.face(c, {v[a], v[b], v[b + 4], v[a + 4]});
+                        B.face(c, {v[b], v[d], v[d + 4], v[b + 4]});
+                        B.face(c, {v[d], v[a], v[a + 4], v[d + 4]});
+                    }
+                } else if (kd == kTetBlock) {  // Kuhn: one tetrahedron per ordering of the axes, all through v0 - v7
+                    const int perm[6][3] = {{1, 2, 4}, {1, 4, 2}, {2, 1, 4}, {2, 4, 1}, {4, 1, 2}, {4, 2, 1}};
+                    for (int t = 0; t < 6; ++t) B.tet(v[0], v[perm[t][0]], v[perm[t][0] + perm[t][1]], v[7]);
+                } else {  // six pyramids about the block centre
+                    const int64_t p = (int64_t)B.coords.size();
+                    V3 s = {0., 0., 0.};
+                    for (int c = 0; c < 8; ++c) s = add(s, B.coords[(size_t)v[c]]);
+                    B.coords.push_back({s.x / 8., s.y / 8., s.z / 8.});
+                    const int64_t quads[6][4] = {{v[0], v[2], v[6], v[4]}, {v[1], v[3], v[7], v[5]}, {v[0], v[1], v[5], v[4]},
+                                                 {v[2], v[3], v[7], v[6]}, {v[0], v[1], v[3], v[2]}, {v[4], v[5], v[7], v[6]}};
+                    // the x- / x+ quadrilateral is listed from its lowest corner, so its Kuhn diagonal is q[0] - q[2]
+                    B.pyramid(p, quads[0], (i > 0 && kind(i - 1) == kTetBlock) ? 0 : -1);
+                    B.pyramid(p, quads[1], (i + 1 < nx && kind(i + 1) == kTetBlock) ? 0 : -1);
+                    for (int q = 2; q < 6; ++q) B.pyramid(p, quads[q], -1);
+                }
+            }
+    // pair the face records
+    auto key_less = [](const FaceRec &a, const FaceRec &b) {
+        if (a.nn != b.nn) return a.nn < b.nn;
+        for (int q = 0; q < 4; ++q)
+            if (a.key[q] != b.key[q]) return a.key[q] < b.key[q];
+        return a.cell < b.cell;
+    };
+    std::sort(B.recs.begin(), B.recs.end(), key_less);
+    struct OutFace { int64_t n[4]; int64_t c0, c1; int nn; };
+    // zones: 0 FLUID (quad), 1 FLUID_TRI, then per location quad / tri
+    const char *zone_names[12] = {"FLUID", "FLUID_TRI", "INLET", "INLET_TRI", "OUTLET", "OUTLET_TRI", "PERIODIC_+Z", "PERIODIC_+Z_TRI",
+                                  "PERIODIC_-Z", "PERIODIC_-Z_TRI", "WALL", "WALL_TRI"};
+    std::vector<OutFace> zones[12];
+    const double eps = 1e-12 * std::max(lx, std::max(ly, lz));
+    for (size_t r = 0; r < B.recs.size();) {
+        const FaceRec &a = B.recs[r];
+        const bool paired = r + 1 < B.recs.size() && B.recs[r + 1].nn == a.nn && std::equal(a.key, a.key + 4, B.recs[r + 1].key);
+        OutFace o;
+        o.nn = a.nn;
+        o.c0 = a.cell;
+        o.c1 = paired ? B.recs[r + 1].cell : -1;
+        for (int q = 0; q < 4; ++q) o.n[q] = a.nodes[q];
+        // orientation: (n2 - n1) x (n1 - n0) out of c0 (io.rs:322-326, mesh.rs:216-222)
+        const V3 p0 = B.coords[(size_t)o.n[0]], p1 = B.coords[(size_t)o.n[1]], p2 = B.coords[(size_t)o.n[2]];
+        const V3 nrm = cross(sub(p2, p1), sub(p1, p0));
+        V3 fc = {0., 0., 0.};
+        for (int q = 0; q < o.nn; ++q) fc = add(fc, B.coords[(size_t)o.n[q]]);
+        fc = {fc.x / o.nn, fc.y / o.nn, fc.z / o.nn};
+        const V3 cs = B.cell_sum[(size_t)o.c0];
+        const double cnt = (double)B.cell_cnt[(size_t)o.c0];
+        const V3 cc = {cs.x / cnt, cs.y / cnt, cs.z / cnt};
+        if (dot(sub(fc, cc), nrm) < 0.) std::reverse(o.n, o.n + o.nn);
+        int z;
+        if (paired) z = 0;
+        else {
+            auto all_on = [&](int axis, double val) {
+                for (int q = 0; q < o.nn; ++q) {
+                    const V3 p = B.coords[(size_t)o.n[q]];
+                    const double c = axis == 0 ? p.x : (axis == 1 ? p.y : p.z);
+                    if (std::fabs(c - val) > eps) return false;
+                }
+                return true;
+            };
+            if (all_on(2, 0.)) z = 8;
+            else if (all_on(2, lz)) z = 6;
+            else if (all_on(0, 0.)) z = 2;
+            else if (all_on(0, lx)) z = 4;
+            else if (all_on(1, 0.) || all_on(1, ly)) z = 10;
+            else return ORC_ERR_BAD_ARGUMENT;  // an unpaired face inside the box: the decomposition is not conforming
+        }
+        zones[z + (o.nn == 3 ? 1 : 0)].push_back(o);
+        r += paired ? 2 : 1;
+    }
+    int64_t n_faces = 0;
+    for (auto &z : zones) n_faces += (int64_t)z.size();
+    FILE *fp = std::fopen(path, "w");
+    if (!fp) return ORC_ERR_IO;
+    const int64_t nv = (int64_t)B.coords.size();
+    std::fprintf(fp, "(0 \"Created by: orc_amd mixed tet/pyramid/prism/hex channel generator\")\n(0 \"Units: Meters\")\n(2 3)\n(0 \"Node Section\")\n");
+    std::fprintf(fp, "(10 (0 1 %" PRIx64 " 0 3))\n(10 (1 1 %" PRIx64 " 1 3)(\n", (uint64_t)nv, (uint64_t)nv);
+    for (const V3 &p : B.coords) std::fprintf(fp, "%.17g %.17g %.17g\n", p.x, p.y, p.z);
+    std::fprintf(fp, "))\n(12 (0 1 %" PRIx64 " 0))\n(12 (2 1 %" PRIx64 " 1 0))\n(13 (0 1 %" PRIx64 " 0))\n", (uint64_t)B.n_cells, (uint64_t)B.n_cells,
+                 (uint64_t)n_faces);
+    int64_t start = 1;
+    int zone_id = 3;
+    for (int z = 0; z < 12; ++z) {
+        if (zones[z].empty()) continue;
+        std::fprintf(fp, "(0 \"Faces of zone %s\")\n", zone_names[z]);
+        std::fprintf(fp, "(13 (%x %" PRIx64 " %" PRIx64 " %x %x)(\n", (unsigned)zone_id++, (uint64_t)start, (uint64_t)(start + (int64_t)zones[z].size() - 1),
+                     z < 2 ? 2u : 3u, (z & 1) ? 3u : 4u);
+        for (const OutFace &o : zones[z]) {
+            for (int q = 0; q < o.nn; ++q) std::fprintf(fp, "%" PRIx64 " ", (uint64_t)(o.n[q] + 1));
+            std::fprintf(fp, "%" PRIx64 " %" PRIx64 "\n", (uint64_t)(o.c0 + 1), (uint64_t)(o.c1 + 1));
+        }
+        std::fprintf(fp, "))\n");
+        start += (int64_t)zones[z].size();
+    }
+    std::fclose(fp);
+    if (n_cells_out) *n_cells_out = B.n_cells;
+    if (n_faces_out) *n_faces_out = n_faces;
+    return ORC_OK;
+}

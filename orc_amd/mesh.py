@@ -98,6 +98,17 @@ def write_hex_channel_msh(path, nx, ny, nz, lx=0.002, ly=0.001, lz=None):
                                           C.c_double(ly), C.c_double(lz)))
 
 
+def write_mixed_channel_msh(path, nx, ny, nz, lx=0.002, ly=0.001, lz=None):
+    """BASELINE config 5 workload (orc_mixed_channel_write_msh): tet / pyramid / prism / hex channel as a TGRID file.
+    Returns (n_cells, n_faces)."""
+    if lz is None:
+        lz = 1e-4 * nz
+    nc, nf = C.c_int64(), C.c_int64()
+    check(lib().orc_mixed_channel_write_msh(path.encode(), C.c_int64(nx), C.c_int64(ny), C.c_int64(nz), C.c_double(lx), C.c_double(ly),
+                                            C.c_double(lz), C.byref(nc), C.byref(nf)))
+    return nc.value, nf.value
+
+
 def renumber_cells(a, new_of_old):
     """The same mesh with cell `c` renamed new_of_old[c] (faces keep their ids, orientation and per-cell ascending order):
     what a mesh generator with another cell numbering would have written.  Used to measure how much the products depend
@@ -133,10 +144,28 @@ def set_channel_bcs(a, top_wall_velocity=0.0, dp_dx=5.0, dx=0.002):
     return a
 
 
+def set_mixed_channel_bcs(a, top_wall_velocity=0.0, dp_dx=5.0, dx=0.002):
+    """tests.rs:60-76 on the zones of orc_mixed_channel_write_msh (every location has a quadrilateral zone and a "_TRI" twin)."""
+    T = FaceConditionTypes
+    for name in list(a["zone_names"]):
+        base = name[:-4] if name.endswith("_TRI") else name
+        if base == "WALL":
+            a.set_zone(name, T.Wall, 0.0, (top_wall_velocity, 0.0, 0.0))
+        elif base == "INLET":
+            a.set_zone(name, T.PressureInlet, -dp_dx * dx)
+        elif base == "OUTLET":
+            a.set_zone(name, T.PressureOutlet, 0.0)
+        elif base.startswith("PERIODIC"):
+            a.set_zone(name, T.Symmetry)
+    return a
+
+
 class Mesh:
     """Device-resident mesh (OrcMesh*)."""
 
-    def __init__(self, arrays):
+    def __init__(self, arrays, ordering=None):
+        """ordering: None = ORC's numbering; 1 = RCM, 2 = geometric (orc_mesh_create_reordered: internal renumbering,
+        fields still in ORC order)."""
         a = arrays
         self.arrays = a
         self._keep = [_i64(a["face_c0"]), _i64(a["face_c1"]), _i32(a["face_zone"]), _f64(a["face_area"]),
@@ -145,12 +174,15 @@ class Mesh:
                       _f64(a["zone_vector"])]
         k = self._keep
         st = C.c_int(0)
-        self.ptr = lib().orc_mesh_create(
-            C.c_int64(len(k[7])), C.c_int64(len(k[3])), C.c_int32(len(k[10])), k[0].ctypes.data_as(_I64),
-            k[1].ctypes.data_as(_I64), k[2].ctypes.data_as(_I32), k[3].ctypes.data_as(_F64), k[4].ctypes.data_as(_F64),
-            k[5].ctypes.data_as(_F64), k[6].ctypes.data_as(_F64), k[7].ctypes.data_as(_F64), k[8].ctypes.data_as(_I64),
-            k[9].ctypes.data_as(_I64), k[10].ctypes.data_as(_I32), k[11].ctypes.data_as(_F64), k[12].ctypes.data_as(_F64),
-            C.byref(st))
+        args = [C.c_int64(len(k[7])), C.c_int64(len(k[3])), C.c_int32(len(k[10])), k[0].ctypes.data_as(_I64),
+                k[1].ctypes.data_as(_I64), k[2].ctypes.data_as(_I32), k[3].ctypes.data_as(_F64), k[4].ctypes.data_as(_F64),
+                k[5].ctypes.data_as(_F64), k[6].ctypes.data_as(_F64), k[7].ctypes.data_as(_F64), k[8].ctypes.data_as(_I64),
+                k[9].ctypes.data_as(_I64), k[10].ctypes.data_as(_I32), k[11].ctypes.data_as(_F64), k[12].ctypes.data_as(_F64)]
+        if ordering:
+            lib().orc_mesh_create_reordered.restype = C.c_void_p
+            self.ptr = lib().orc_mesh_create_reordered(*args, C.c_int32(int(ordering)), C.byref(st))
+        else:
+            self.ptr = lib().orc_mesh_create(*args, C.byref(st))
         check(st.value)
         self.ptr = C.c_void_p(self.ptr)
         self._keep = None
@@ -161,6 +193,12 @@ class Mesh:
         if getattr(self, "ptr", None):
             lib().orc_mesh_destroy(self.ptr)
             self.ptr = None
+
+    def cell_order(self):
+        """global_ids[c] = ORC index of internal cell c (identity unless the mesh was created reordered)"""
+        g = np.empty(self.n_cells, np.int64)
+        check(lib().orc_mesh_cell_order(self.ptr, g.ctypes.data_as(_I64)))
+        return g
 
     def update_zones(self):
         a = self.arrays

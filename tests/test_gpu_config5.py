@@ -1,0 +1,137 @@
+"""BASELINE config 5 (mixed tet / pyramid / prism / hex channel) at about a million cells on the device: size-independent
+properties through the product reader, the product kernels, the full default-stack SIMPLE loop and the internal RCM
+renumbering — the oracle cannot finish this size in seconds, so parity here is by properties (bit-exact product against
+an independent CSR evaluation, conservation of the assembled systems, reordering invariance), as tests/test_gpu_full_size.py
+does for the hexahedral workload."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+NX, NY, NZ = 100, 60, 50  # 300 000 blocks -> ~0.98 M cells
+
+
+@pytest.fixture(scope="module")
+def mixed(gpu, tmp_path_factory):
+    from orc_amd import io as orc_io
+    from orc_amd.mesh import MeshArrays, set_mixed_channel_bcs, write_mixed_channel_msh
+    path = str(tmp_path_factory.mktemp("config5") / "mixed.msh")
+    nc, nf = write_mixed_channel_msh(path, NX, NY, NZ)
+    d = orc_io.read_mesh(path)
+    os.remove(path)
+    a = MeshArrays(d.arrays())
+    set_mixed_channel_bcs(a)
+    assert a.n_cells == nc and a.n_faces == nf and nc > 900_000
+    return a
+
+
+def start_fields(a):
+    from orc_amd.mesh import splitmix64_uniform
+    cc = np.asarray(a["cell_centroid"])
+    n = len(cc)
+    y = cc[:, 1]
+    u = 1.0 / 2e-3 * 5.0 * (y * y - 1e-3 * y) * (1 + 1e-6 * splitmix64_uniform(n, 1))
+    v = 1e-12 * splitmix64_uniform(n, 2)
+    w = 1e-12 * splitmix64_uniform(n, 3)
+    p = -0.01 * (1 - cc[:, 0] / 0.002) * (1 + 1e-6 * splitmix64_uniform(n, 4))
+    return u, v, w, p
+
+
+def test_generated_mesh_is_closed_and_fills_the_box(mixed):
+    a = mixed
+    n = a.n_cells
+    nf = np.diff(a["cell_face_ptr"])
+    assert set(np.unique(nf).tolist()) == {4, 5, 6}                       # tetrahedra, pyramids + prisms, hexahedra
+    vol = np.asarray(a["cell_volume"])
+    assert vol.min() > 0 and abs(vol.sum() - 0.002 * 0.001 * 1e-4 * NZ) < 1e-12 * vol.sum() * n ** 0.5
+    c0, c1 = np.asarray(a["face_c0"]), np.asarray(a["face_c1"])
+    An = np.asarray(a["face_normal"]) * np.asarray(a["face_area"])[:, None]
+    S = np.zeros((n, 3))
+    np.add.at(S, c0, An)
+    m = c1 >= 0
+    np.add.at(S, c1[m], -An[m])
+    assert np.abs(S).max() < 1e-18                                          # every cell is closed: sum of outward area vectors = 0
+
+
+def test_product_bit_exact_and_system_conservation(mixed):
+    """y = A x on the assembled momentum matrix against scipy's CSR product evaluated row by row in ascending column
+    order (bit-exact), and the pressure-correction matrix's zero row sums away from pressure boundaries."""
+    import scipy.sparse as sp
+    from orc_amd.linear_algebra import csr_spmv
+    from orc_amd.mesh import Mesh, splitmix64_uniform
+    from orc_amd.settings import NumericalSettings
+    from orc_amd.solver import Solver
+    a = mixed
+    dm = Mesh(a)
+    s = Solver(dm, NumericalSettings.default(momentum=5), 1000.0, 1e-3)
+    s.set_fields(*start_fields(a))
+    au, av, aw, bu, bv, bw, pe = s.assemble_momentum()
+    rp, ci = dm.matrix_pattern()
+    n = dm.n_cells
+    assert set(np.unique(np.diff(rp)).tolist()) <= {3, 4, 5, 6, 7} and np.isfinite(au).all()
+    x = splitmix64_uniform(n, 9)
+    A = sp.csr_matrix((au, ci, rp), shape=(n, n))
+    y, _ = csr_spmv(A, x)
+    # independent evaluation in the same association: per row, ascending column, from 0.0
+    ref = np.zeros(n)
+    k = np.diff(rp)
+    for depth in range(int(k.max())):
+        m = k > depth
+        pos = rp[:-1][m] + depth
+        ref[m] = ref[m] + au[pos] * x[ci[pos]]
+    assert np.array_equal(y, ref)
+    ap, bp = s.assemble_pressure()
+    Ap = sp.csr_matrix((ap, ci, rp), shape=(n, n))
+    rs = np.asarray(Ap.sum(axis=1)).ravel()
+    assert (np.abs(rs) > 1e-9 * np.abs(Ap.diagonal())).sum() < 0.2 * n   # row sums vanish except next to boundaries (every boundary face adds to the diagonal, discretization.rs:425-436)
+
+
+def test_default_stack_iterations_are_finite_and_reproducible(mixed):
+    from orc_amd.mesh import Mesh
+    from orc_amd.settings import NumericalSettings
+    from orc_amd.solver import Solver
+    a = mixed
+    dm = Mesh(a)
+    runs = []
+    for _ in range(2):
+        s = Solver(dm, NumericalSettings.default(momentum=5, momentum_relaxation=0.1, pressure_relaxation=0.001), 1000.0, 1e-3)
+        s.set_fields(*start_fields(a))
+        st = s.iterate(2, raise_on_error=False)
+        assert st == 0
+        runs.append(s.get_fields())
+    for x, y in zip(*runs):
+        assert np.isfinite(x).all() and np.array_equal(x, y)
+
+
+def test_internal_rcm_renumbering_keeps_fields_in_orc_order(mixed):
+    """A randomly renumbered copy of the mesh, run with the internal RCM ordering, against the same copy without it: the
+    reduction-free configuration (UD + Jacobi solver) gives the same fields up to the renumbering-dependent summation
+    order of the face loops (1e-12), i.e. the permutation really is internal; and the RCM numbering brings the matrix
+    bandwidth back to the generator's order of magnitude."""
+    from orc_amd.mesh import Mesh, renumber_cells
+    from orc_amd.settings import NumericalSettings
+    from orc_amd.solver import Solver
+    a = mixed
+    n = a.n_cells
+    perm = np.random.default_rng(3).permutation(n)
+    sh = renumber_cells(a, perm)
+    inv = np.empty(n, np.int64)
+    inv[perm] = np.arange(n)
+    f = tuple(x[inv] for x in start_fields(a))
+    out = []
+    bws = []
+    for ordering in (None, 1):
+        dm = Mesh(sh, ordering=ordering)
+        rp, ci = dm.matrix_pattern()
+        bws.append(int(np.abs(np.repeat(np.arange(n), np.diff(rp)) - ci).max()))
+        s = Solver(dm, NumericalSettings.default(momentum=0, solver_type=1), 1000.0, 1e-3)
+        s.set_fields(*f)
+        assert s.iterate(2, raise_on_error=False) == 0
+        out.append(s.get_fields())
+        g = dm.cell_order()
+        assert sorted(g.tolist()) == list(range(n)) if ordering else np.array_equal(g, np.arange(n))
+    for x, y in zip(*out):
+        assert np.linalg.norm(x - y) <= 1e-10 * max(np.linalg.norm(x), 1e-300)
+    assert bws[1] * 20 < bws[0]
