@@ -10,7 +10,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-NX, NY, NZ = 100, 60, 50  # 300 000 blocks -> ~0.98 M cells
+NX, NY, NZ = 120, 60, 50  # 360 000 blocks -> about a million cells
 
 
 @pytest.fixture(scope="module")
@@ -23,7 +23,7 @@ def mixed(gpu, tmp_path_factory):
     os.remove(path)
     a = MeshArrays(d.arrays())
     set_mixed_channel_bcs(a)
-    assert a.n_cells == nc and a.n_faces == nf and nc > 900_000
+    assert a.n_cells == nc and a.n_faces == nf and nc > 1_000_000
     return a
 
 
