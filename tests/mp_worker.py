@@ -101,6 +101,15 @@ def main():
     mode = sys.argv[1]
     dist.init_process_group(backend="gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
+    if mode == "gpu_general":
+        ok = gpu_general_checks(rank, world)
+        t = torch.tensor([1.0 if ok else 0.0])
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        dist.barrier()
+        if rank == 0:
+            print("MP_WORKER_OK" if t.item() == 1.0 else "MP_WORKER_FAIL", flush=True)
+        dist.destroy_process_group()
+        return
     if mode == "cpu_general":
         ok = general_partition_checks(rank, world)
         t = torch.tensor([1.0 if ok else 0.0])
@@ -165,6 +174,50 @@ def main():
     if rank == 0:
         print("MP_WORKER_OK" if t.item() == 1.0 else "MP_WORKER_FAIL", flush=True)
     dist.destroy_process_group()
+
+
+def gpu_general_checks(rank, world):
+    """orc_mesh_partition on the READ prism + hexahedron mesh (geometric and RCM orderings), the ranks sharing cuda:0 through
+    the host transport: partitioned SIMPLE iterations against the single-rank run on the whole mesh."""
+    import tempfile
+    import meshgen
+    import orc_amd
+    from orc_amd import io as orc_io
+    from orc_amd.mesh import Mesh, MeshArrays
+    from orc_amd.settings import NumericalSettings
+    from orc_amd.solver import Solver
+    orc_amd.init(0)
+    parallel.init_host_transport(dist, rank, world)
+    tmp = os.path.join(tempfile.gettempdir(), "orc_mixed_gpu_%d.msh" % os.getpid())
+    info = meshgen.write_mixed_channel_msh(tmp, 12, 8, 6, skew=0.2)
+    d = orc_io.read_mesh(tmp)
+    os.remove(tmp)
+    meshgen.mixed_channel_bcs(d.set_zone, info["zone_names"], top_wall_velocity=5e-4)
+    ag = MeshArrays(d.arrays())
+    ug = global_fields(ag)
+    ok = True
+    for ordering in (parallel.ORDER_GEOMETRIC, parallel.ORDER_RCM):
+        a, halo, gids = parallel.partition_arrays(ag, world, rank, ordering)
+        n_own = halo["n_owned"]
+        for name, kw, tol in (("jacobi", dict(momentum=0, solver_type=1, relative_convergence_threshold=1e-30), 1e-12),
+                              ("bicgstab", dict(momentum=5, solver_type=3, iterations=5), 1e-9)):
+            s = NumericalSettings.default(**kw)
+            pm = parallel.PartitionedMesh(a, halo)
+            sol = Solver(pm, s, 1000.0, 1e-3)
+            sol.set_fields(*[f[gids] for f in ug])
+            st = sol.iterate(2, raise_on_error=False)
+            loc = sol.get_fields()
+            ref = Solver(Mesh(ag), s, 1000.0, 1e-3)
+            ref.set_fields(*ug)
+            st_ref = ref.iterate(2, raise_on_error=False)
+            glob = ref.get_fields()
+            err = max(np.linalg.norm(l[:n_own] - g[gids[:n_own]]) / max(np.linalg.norm(g), 1e-300) for l, g in zip(loc, glob))
+            good = (st == st_ref == 0) and err <= tol
+            if rank == 0:
+                print("  ordering %d %-9s status %d/%d  max rel err vs single rank %.3e  %s" % (ordering, name, st, st_ref, err, "ok" if good else "FAIL"), flush=True)
+            ok = ok and good
+    parallel.finalize()
+    return ok
 
 
 def gpu_checks(rank, world, a, halo, gids, ag):

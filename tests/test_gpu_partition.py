@@ -13,6 +13,13 @@ def test_two_ranks_match_single_rank(gpu):
     assert "MP_WORKER_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-4000:]
 
 
+def test_general_partitioner_two_ranks_match_single_rank(gpu):
+    """orc_mesh_partition (geometric and RCM orderings) on the read prism + hexahedron mesh: two ranks on one GPU."""
+    r = launch(2, "gpu_general", timeout=900)
+    print(r.stdout[-1500:])
+    assert "MP_WORKER_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-4000:]
+
+
 def test_rccl_selftest_single_rank(gpu):
     """The RCCL branch of HaloPlan::exchange / all-reduce / status agreement on one GPU: a single-rank communicator
     with rank 0 as its own neighbour.  (Two real ranks need two GPUs: the driver's scaling run.)"""
