@@ -242,12 +242,13 @@ def main():
     workload_name = ("BASELINE configs[3]" if key == (400, 160, 160, "umist", "multigrid")
                      else "BASELINE configs[2]" if key == (512, 2016, 1, "quick", "bicgstab_gs") else "custom")
     bicg_bytes = 2.0 * spmv_bytes + 104.0 * n_local
-    # HBM traffic per launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes,
-    # MI355X_MICROARCH.md §HBM): bench.py cannot collect counters itself, so it quotes the committed profile of the
-    # same kernel on the same matrix when one exists, else null.
+    # Memory-side traffic per launch from the PMC counters (TCC_EA0_RDREQ by request size + TCC_EA0_WRREQ, separate rocprofv3
+    # --pmc passes: scripts/gpu_pmc_r02.sh; equal to FETCH_SIZE x 2 + WRITE_SIZE of MI355X_MICROARCH.md §HBM for this
+    # kernel): bench.py cannot collect counters itself, so it quotes the committed profile of the same kernel on the same
+    # matrix when one exists, else null.
     traffic = None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_spmv_pmc.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_spmv_pmc.json")))
         if pmc["n"] == n_local and pmc["nnz"] == nnz_local:
             traffic = pmc["hbm_bytes_per_launch"]
     except Exception:
@@ -286,14 +287,14 @@ def main():
                 "hbm_used_gb": round(hbm_used_gb, 1),
             },
             "roofline": {
-                "kernel": "spmv_k<EpiStore> (CSR/SELL-64 SpMV, a_u of the momentum system)",
+                "kernel": "spmv_k<EpiStore, kSpmvPlain> (CSR/SELL-64 SpMV inside BiCGSTAB, a_u of the momentum system)",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "traffic_source": "profiles/r01_spmv_pmc.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)" if traffic else None,
+                "traffic_source": "profiles/r02_spmv_pmc.json (rocprofv3 --pmc TCC_EA0_RDREQ_{32B,64B,128B} + TCC_EA0_WRREQ, bytes by request size)" if traffic else None,
                 "avg_launch_ms": spmv_ms,
                 "algorithmic_bytes_per_launch": spmv_bytes,
                 "bicgstab_iteration_ms": bicg_ms,

@@ -1106,7 +1106,7 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
     ORC_TRY(arena.alloc((size_t)std::max<int64_t>(padded, 1), &col));
     ORC_TRY(arena.alloc((size_t)std::max<int64_t>(padded, 1), &val));
     SellDev Pc;
-    Pc.n = nc; Pc.ncols = nc; Pc.n_slices = n_slices; Pc.ragged = 1; Pc.slice_ptr = slice_ptr; Pc.row_len = row_len; Pc.col = col; Pc.diag_pos = diag;
+    Pc.n = nc; Pc.ncols = nc; Pc.n_slices = n_slices; Pc.ragged = padded < 24 * nc ? 2 : 1; Pc.slice_ptr = slice_ptr; Pc.row_len = row_len; Pc.col = col; Pc.diag_pos = diag;
     hipLaunchKernelGGL(galerkin_pack_k, dim3(grid_for(nc)), dim3(kBlock), 0, st, Pc, slice_base, intra_off, s_col, s_val, col, val, diag);
     ORC_HIP(hipGetLastError());
     L.P = Pc; L.val = val; L.n = nc; L.padded = padded;

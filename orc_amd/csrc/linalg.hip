@@ -139,7 +139,7 @@ int sell_from_csr_host(int64_t n, int64_t ncols, const int64_t *row_ptr, const i
         for (int64_t k = e - b; k < width; ++k) scol[base + k * 64] = (int32_t)r;
     }
     out.n = n; out.ncols = ncols; out.nnz = nnz; out.padded = padded; out.n_slices = n_slices; out.symmetric = symmetric;
-    out.ragged = (double)padded > 1.08 * (double)std::max<int64_t>(nnz, 1);
+    out.ragged = (double)padded > 1.08 * (double)std::max<int64_t>(nnz, 1) ? (padded < 24 * std::max<int64_t>(n, 1) ? 2 : 1) : 0;
     ORC_TRY(out.slice_ptr.upload(slice_ptr.data(), slice_ptr.size()));
     ORC_TRY(out.row_len.upload(row_len.data(), (size_t)n));
     ORC_TRY(out.col.upload(scol.data(), (size_t)padded));
@@ -290,16 +290,20 @@ static int launch_spmv(const MatView &A, const double *x, const Epi &epi, double
     } else if (variant != 0) {
         if (variant == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi, kSpmvPlain>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
         else if (variant == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi, kSpmvRagged>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
+        else if (variant == 6) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi, kSpmvPlain, false, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
+        else if (variant == 7) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi, kSpmvRagged, false, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
         else if (variant == 4 && A.pk.ptr) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi, kSpmvPacked, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
         else if (variant == 5 || variant == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi, kSpmvPlain, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
         else if (A.pk.ptr) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi, kSpmvPacked>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi, kSpmvPlain>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
     } else if (A.pk.ptr)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi, kSpmvPacked>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
-    else if (ragged_enabled && A.P.ragged)
+    else if (ragged_enabled && A.P.ragged == 1)  // long ragged rows without a mirror: every slot clamped, nothing skipped
         hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi, kSpmvRagged>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
-    else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi, kSpmvPlain>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
+    else if (ragged_enabled && A.P.ragged == 2)  // short ragged rows (first coarse level): slots past the slice width skipped too
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi, kSpmvRagged, false, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
+    else  // mesh-pattern matrices (width 5-7: one chunk per slice, its unused slots skipped by wave-uniform branches)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi, kSpmvPlain, false, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
     ORC_HIP(hipGetLastError());
     return ORC_OK;
 }

@@ -14,7 +14,7 @@ struct SellDev {
     int64_t n = 0;      // rows (owned cells)
     int64_t ncols = 0;  // vector length: rows + ghost columns of a partitioned matrix (== n otherwise)
     int32_t n_slices = 0;
-    int32_t ragged = 0;  // padding > 8 % of the stored entries (coarse AMG levels): the product skips the padding slots
+    int32_t ragged = 0;  // padding > 8 % of the stored entries (coarse AMG levels): 1 = long rows, 2 = short rows (< 24 slots per row); picks the product variant
     const int64_t *slice_ptr = nullptr;  // [n_slices+1], element offsets (multiples of 64)
     const int32_t *row_len = nullptr;    // [n]
     const int32_t *col = nullptr;        // [padded]
@@ -83,13 +83,13 @@ struct SellMatrix {
     int64_t n = 0, ncols = 0, nnz = 0, padded = 0;
     int32_t n_slices = 0;
     bool symmetric = true;
-    bool ragged = false;
+    int ragged = 0;
     DevBuf<int64_t> slice_ptr;
     DevBuf<int32_t> row_len, col, diag_pos;
     DevBuf<int64_t> csr_row_ptr;  // for value import/export in CSR (ORC) order
     SellDev dev() const {
         SellDev d;
-        d.n = n; d.ncols = ncols; d.n_slices = n_slices; d.ragged = ragged ? 1 : 0; d.slice_ptr = slice_ptr.p; d.row_len = row_len.p; d.col = col.p; d.diag_pos = diag_pos.p;
+        d.n = n; d.ncols = ncols; d.n_slices = n_slices; d.ragged = ragged; d.slice_ptr = slice_ptr.p; d.row_len = row_len.p; d.col = col.p; d.diag_pos = diag_pos.p;
         return d;
     }
 };

@@ -45,7 +45,8 @@ struct SliceWalk {
 //          2 = packed mirror (PackedDev): no padding in memory at all.
 enum { kSpmvPlain = 0, kSpmvRagged = 1, kSpmvPacked = 2 };
 // kNoGather (diagnostic, orc_debug_set_spmv_variant): x[row] instead of x[col] — the matrix stream without the gathers
-template <class Epi, int kLayout = kSpmvPlain, bool kNoGather = false>
+// kGuard: slots at or beyond the slice width are skipped by wave-uniform branches instead of re-reading the last slot
+template <class Epi, int kLayout = kSpmvPlain, bool kNoGather = false, bool kGuard = false>
 __global__ __launch_bounds__(kBlock) void spmv_k(MatView A, const double *__restrict__ x, Epi epi, double *__restrict__ partials,
                                                  const double *__restrict__ skip_flags /* 2 doubles or null: non-zero = no-op */) {
     __shared__ double lds[8];
@@ -89,6 +90,13 @@ __global__ __launch_bounds__(kBlock) void spmv_k(MatView A, const double *__rest
                     c[u] = A.pk.col[p];
                     v[u] = A.pk.val[p];
                     pk_off += __popcll(m);
+                } else if (kGuard) {
+                    if (k0 + u < width) {  // wave-uniform
+                        const int kk = k0 + u < last ? k0 + u : last;
+                        const int64_t p = base + (int64_t)kk * 64 + lane_c;
+                        c[u] = A.P.col[p];
+                        v[u] = A.val[p];
+                    } else { c[u] = 0; v[u] = 0.; }
                 } else {
                     const int kk = k0 + u < last ? k0 + u : last;
                     const int64_t p = base + (int64_t)kk * 64 + lane_c;
@@ -97,7 +105,10 @@ __global__ __launch_bounds__(kBlock) void spmv_k(MatView A, const double *__rest
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) xv[u] = x[kNoGather ? (int)(live ? row : 0) + (c[u] & 0) : c[u]];
+            for (int u = 0; u < 8; ++u) {
+                if (kGuard) { if (k0 + u < width) xv[u] = x[c[u]]; else xv[u] = 0.; }
+                else xv[u] = x[kNoGather ? (int)(live ? row : 0) + (c[u] & 0) : c[u]];
+            }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 double t = v[u];

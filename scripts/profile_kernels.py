@@ -20,6 +20,7 @@ m = Mesh(a)
 s = Solver(m, NumericalSettings.default(momentum=5, momentum_relaxation=0.1, pressure_relaxation=0.001), 1000.0, 1e-3)
 s.set_fields(*initial_fields(np.asarray(a["cell_centroid"])))
 s.assemble_momentum()
+s.assemble_pressure()
 ms, _ = s.bench_spmv(20)
 bi = s.bench_bicgstab_iteration(5)
 n, nnz = m.n_cells, m.nnz
