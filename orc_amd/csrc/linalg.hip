@@ -290,6 +290,8 @@ static int launch_spmv(const MatView &A, const double *x, const Epi &epi, double
     } else if (variant != 0) {
         if (variant == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi, kSpmvPlain>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
         else if (variant == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi, kSpmvRagged>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
+        else if (variant == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_uniform_k<Epi, false>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
+        else if (variant == 9) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_uniform_k<Epi, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
         else if (variant == 6) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi, kSpmvPlain, false, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
         else if (variant == 7) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi, kSpmvRagged, false, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
         else if (variant == 4 && A.pk.ptr) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi, kSpmvPacked, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
@@ -300,10 +302,8 @@ static int launch_spmv(const MatView &A, const double *x, const Epi &epi, double
         hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi, kSpmvPacked>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
     else if (ragged_enabled && A.P.ragged == 1)  // long ragged rows without a mirror: every slot clamped, nothing skipped
         hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi, kSpmvRagged>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
-    else if (ragged_enabled && A.P.ragged == 2)  // short ragged rows (first coarse level): slots past the slice width skipped too
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi, kSpmvRagged, false, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
-    else  // mesh-pattern matrices (width 5-7: one chunk per slice, its unused slots skipped by wave-uniform branches)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi, kSpmvPlain, false, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
+    else  // mesh-pattern matrices and short ragged rows (first coarse level): wave-uniform loads, predicated gathers
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_uniform_k<Epi, false>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
     ORC_HIP(hipGetLastError());
     return ORC_OK;
 }

@@ -23,7 +23,7 @@ s = Solver(mesh, NumericalSettings.default(momentum=5, momentum_relaxation=0.1, 
 s.set_fields(u, v, w, p)
 s.iterate(2)
 L = orc_amd._lib.lib()
-names = {0: "production", 1: "padded", 2: "padded-predicated", 3: "packed", 4: "packed-nogather", 5: "padded-nogather", 6: "padded-guarded", 7: "predicated-guarded",
+names = {0: "production", 1: "padded", 2: "padded-predicated", 3: "packed", 4: "packed-nogather", 5: "padded-nogather", 8: "r01-kernel", 9: "r01-kernel-ragged", 6: "padded-guarded", 7: "predicated-guarded",
          20: "lds-window", 21: "lds-no-window-load", 22: "lds-window-load-only", 10: "pipelined", 11: "pipelined-padded", 12: "pipelined-predicated"}
 for var in [int(x) for x in args.variants.split(",")]:
     L.orc_debug_set_spmv_variant(ctypes.c_int(var))
