@@ -443,8 +443,10 @@ struct FaceArgs {
     double rho;
 };
 
-// get_face_flux seen from cell_indices[0] (solver.rs:1007-1102); the other side is the exact negative
-__device__ __forceinline__ double face_flux_c0(const MeshDev &M, const FaceArgs &A, int f, int zt, int z, int *status) {
+// get_face_flux seen from cell_indices[0] (solver.rs:1007-1102); the other side is the exact negative GIVEN the same two
+// momentum diagonals.  d_i / d_j: a_{u,v,w}.get(i,i) / get(j,j) as the visiting cell sees them (both from the previous
+// iteration with frozen diagonals; the reference's in-place mix otherwise, momentum_k<true>).
+__device__ __forceinline__ double face_flux_c0(const MeshDev &M, const FaceArgs &A, int f, int zt, int z, int *status, V3 d_i, V3 d_j) {
     const int i = M.c0[f];
     const V3 n = face_normal(M, f);
     if (zt == ORC_BC_WALL || zt == ORC_BC_SYMMETRY) return 0.;  // :1026
@@ -462,8 +464,8 @@ __device__ __forceinline__ double face_flux_c0(const MeshDev &M, const FaceArgs 
     // Rhie-Chow (:1051-1095)
     const int64_t nc = M.n_cells;
     const V3 ccv = vsub(cell_centroid(M, j), cell_centroid(M, i));
-    const double a_i = vnorm(mk(A.du[i] * n.x, A.dv[i] * n.y, A.dw[i] * n.z));  // discretization.rs:14-23
-    const double a_j = vnorm(mk(A.du[j] * n.x, A.dv[j] * n.y, A.dw[j] * n.z));
+    const double a_i = vnorm(mk(d_i.x * n.x, d_i.y * n.y, d_i.z * n.z));  // discretization.rs:14-23
+    const double a_j = vnorm(mk(d_j.x * n.x, d_j.y * n.y, d_j.z * n.z));
     const V3 g_i = mk(A.gp[i], A.gp[nc + i], A.gp[2 * nc + i]), g_j = mk(A.gp[j], A.gp[nc + j], A.gp[2 * nc + j]);
     const double vol_i = M.vol[i], vol_j = M.vol[j];
     const double len = vnorm(ccv);
@@ -498,7 +500,10 @@ __global__ void face_k(MeshDev M, FaceArgs A, double *__restrict__ flux, double 
     GRID_STRIDE(f, M.n_faces) {
         const int z = M.fzone[f];
         const int zt = M.ztype[z];
-        flux[f] = face_flux_c0(M, A, (int)f, zt, z, status);
+        {
+            const int i0 = M.c0[f], j0 = M.c1[f] >= 0 ? M.c1[f] : M.c0[f];
+            flux[f] = face_flux_c0(M, A, (int)f, zt, z, status, mk(A.du[i0], A.dv[i0], A.dw[i0]), mk(A.du[j0], A.dv[j0], A.dw[j0]));
+        }
         if (MODE == 0) {
             pf[f] = bc_supported(zt) ? face_pressure(M, A, (int)f, zt, z) : 0.;
         } else {
@@ -559,13 +564,29 @@ struct MomentumArgs {
     double rho;
 };
 
+// The reference's in-place diagonal reads (discretization.rs:182-197, 340-351; frozen_diagonals = 0): while cell
+// c is assembled, Rhie-Chow sees THIS iteration's diagonal of a neighbour j < c (its row is already rewritten) and LAST
+// iteration's of c itself and of every j > c.  New diagonals thus form a triangular recurrence over the cell order; it
+// is evaluated level by level (level(c) = 1 + max level of the neighbours below c): the cells of one level only read new
+// diagonals of lower levels, so a level is one parallel launch over its cell list.
+struct InplaceArgs {
+    const int32_t *cells;  // cells of this level (ascending)
+    int64_t count;
+    const double *du_old, *dv_old, *dw_old;  // diagonals of the previous iteration
+    double *pe;                              // [3][n] per-cell Peclet terms, folded after the last level
+    FaceArgs F;                              // what get_face_flux reads
+    int *status;
+};
+
 // discretization.rs:134-356, one thread per cell (= per matrix row)
-__global__ __launch_bounds__(kBlock) void momentum_k(MeshDev M, SellDev P, MomentumArgs A, double *__restrict__ partials) {
+template <bool kInplace>
+__global__ __launch_bounds__(kBlock) void momentum_k(MeshDev M, SellDev P, MomentumArgs A, double *__restrict__ partials, InplaceArgs I) {
     __shared__ double lds[8];
     const int64_t n = M.n_cells;
     double pe_sum = 0., pe_min = INFINITY, pe_max = -INFINITY;
     const bool tvd = A.momentum >= ORC_MOMENTUM_TVD_LUD;
-    GRID_STRIDE(c, M.n_own) {
+    GRID_STRIDE(idx, kInplace ? I.count : M.n_own) {
+        const int64_t c = kInplace ? (int64_t)I.cells[idx] : idx;
         V3 s_u = mk(0., 0., 0.);  // get_momentum_source_term (solver.rs:698-701)
         const int dpos = P.diag_pos[c];
         const double a_ii_di = A.a_di[dpos];  // :176
@@ -576,7 +597,16 @@ __global__ __launch_bounds__(kBlock) void momentum_k(MeshDev M, SellDev P, Momen
             const bool side0 = M.c0[f] == c;
             V3 n_out = face_normal(M, f);
             if (!side0) n_out = vneg(n_out);
-            const double face_flux = side0 ? A.flux[f] : -A.flux[f];
+            double face_flux = side0 ? A.flux[f] : -A.flux[f];
+            if (kInplace && M.c1[f] >= 0 && I.F.vinterp == ORC_VINTERP_RHIE_CHOW) {
+                // the visiting cell's own mix of old and new diagonals (get() on the matrices being rewritten)
+                const int i0 = M.c0[f], j0 = M.c1[f];
+                const int other = side0 ? j0 : i0;
+                const V3 d_self = mk(I.du_old[c], I.dv_old[c], I.dw_old[c]);
+                const V3 d_other = other < c ? mk(A.du[other], A.dv[other], A.dw[other]) : mk(I.du_old[other], I.dv_old[other], I.dw_old[other]);
+                const double fl = face_flux_c0(M, I.F, f, ORC_BC_INTERIOR, M.fzone[f], I.status, side0 ? d_self : d_other, side0 ? d_other : d_self);
+                face_flux = side0 ? fl : -fl;
+            }
             const double ar = M.area[f];
             const double f_i = face_flux * ar * A.rho;  // :202
             const double face_pressure = A.pf[f];
@@ -629,12 +659,34 @@ __global__ __launch_bounds__(kBlock) void momentum_k(MeshDev M, SellDev P, Momen
         A.b_v[c] = total.y + A.b_v_di[c];
         A.b_w[c] = total.z + A.b_w_di[c];
         const double px = a_p.x / a_ii_di, py = a_p.y / a_ii_di, pz = a_p.z / a_ii_di;  // :331-333
+        if (kInplace) { I.pe[c] = px; I.pe[n + c] = py; I.pe[2 * n + c] = pz; }
         pe_max = fmax(pe_max, fmax(px, fmax(py, pz)));
         pe_min = fmin(pe_min, fmin(px, fmin(py, pz)));
         pe_sum += (((0. + px) + py) + pz) / 3.;  // :338
         const double d_u = a_p.x + a_ii_di, d_v = a_p.y + a_ii_di, d_w = a_p.z + a_ii_di;  // :340-351
         A.a_u[dpos] = d_u; A.a_v[dpos] = d_v; A.a_w[dpos] = d_w;
         A.du[c] = d_u; A.dv[c] = d_v; A.dw[c] = d_w;
+    }
+    if (kInplace) return;  // the statistics are folded by peclet_stats_k once every level is done
+    const double t = block_sum(pe_sum, lds);
+    const double mn = -block_max(-pe_min, lds);
+    const double mx = block_max(pe_max, lds);
+    if (threadIdx.x == 0) {
+        partials[blockIdx.x] = t;
+        partials[gridDim.x + blockIdx.x] = mn;
+        partials[2 * gridDim.x + blockIdx.x] = mx;
+    }
+}
+
+// the Peclet statistics of momentum_k from the stored per-cell terms (same per-workgroup partial layout)
+__global__ __launch_bounds__(kBlock) void peclet_stats_k(const double *__restrict__ pe, int64_t n_own, int64_t n, double *__restrict__ partials) {
+    __shared__ double lds[8];
+    double pe_sum = 0., pe_min = INFINITY, pe_max = -INFINITY;
+    GRID_STRIDE(c, n_own) {
+        const double px = pe[c], py = pe[n + c], pz = pe[2 * n + c];
+        pe_max = fmax(pe_max, fmax(px, fmax(py, pz)));
+        pe_min = fmin(pe_min, fmin(px, fmin(py, pz)));
+        pe_sum += (((0. + px) + py) + pz) / 3.;
     }
     const double t = block_sum(pe_sum, lds);
     const double mn = -block_max(-pe_min, lds);
@@ -842,9 +894,7 @@ static int validate_settings(const OrcSettings &s) {
     if (!(s.velocity_interpolation == ORC_VINTERP_LINEAR || s.velocity_interpolation == ORC_VINTERP_LINEAR_WEIGHTED ||
           s.velocity_interpolation == ORC_VINTERP_RHIE_CHOW))
         return set_error(ORC_ERR_UNSUPPORTED_SCHEME, "unsupported velocity interpolation");  // solver.rs:994,1097
-    if (s.frozen_diagonals == 0)  // the device does not evaluate the reference's order-dependent in-place reads
-        return set_error(ORC_ERR_UNSUPPORTED_SCHEME, "frozen_diagonals = 0 (in-place Rhie-Chow diagonal reads, discretization.rs:182-197) is "
-                                                     "not available on the device: set frozen_diagonals = 1");
+    if (s.frozen_diagonals != 0 && s.frozen_diagonals != 1) return set_error(ORC_ERR_BAD_ARGUMENT, "frozen_diagonals must be 0 or 1");
     if (s.reduction_order != ORC_REDUCTION_TREE && s.reduction_order != ORC_REDUCTION_REFERENCE)
         return set_error(ORC_ERR_BAD_ARGUMENT, "unknown reduction order %d", s.reduction_order);
     return ORC_OK;
@@ -899,6 +949,33 @@ int solver_init(SolverState &s, OrcMesh *m, const OrcSettings *settings, double 
     ORC_TRY(s.flux.alloc(F));
     ORC_TRY(s.pf.alloc(F));
     ORC_TRY(s.coef.alloc(F));
+    if (s.settings.frozen_diagonals == 0) {
+        // the order dependence is defined on ONE process's cell order; a partitioned mesh has no such order across ranks
+        if (m->halo.active()) return set_error(ORC_ERR_UNSUPPORTED_SCHEME, "frozen_diagonals = 0 (in-place diagonals) is not available on a partitioned mesh");
+        ORC_TRY(s.du_old.alloc(n));
+        ORC_TRY(s.dv_old.alloc(n));
+        ORC_TRY(s.dw_old.alloc(n));
+        ORC_TRY(s.pe.alloc(3 * n));
+        // level(c) = 1 + max level(j), j < c a neighbour of c (the matrix pattern is the face-neighbour graph + the diagonal)
+        std::vector<int32_t> level((size_t)s.n_own, 0);
+        int32_t n_levels = 0;
+        for (int64_t c = 0; c < s.n_own; ++c) {
+            int32_t lv = 0;
+            for (int64_t q = m->h_row_ptr[(size_t)c]; q < m->h_row_ptr[(size_t)c + 1]; ++q) {
+                const int64_t j = m->h_col[(size_t)q];
+                if (j < c) lv = std::max(lv, level[(size_t)j] + 1);
+            }
+            level[(size_t)c] = lv;
+            n_levels = std::max(n_levels, lv + 1);
+        }
+        s.level_ptr.assign((size_t)n_levels + 1, 0);
+        for (int64_t c = 0; c < s.n_own; ++c) ++s.level_ptr[(size_t)level[(size_t)c] + 1];
+        for (int32_t l = 0; l < n_levels; ++l) s.level_ptr[(size_t)l + 1] += s.level_ptr[(size_t)l];
+        std::vector<int32_t> cells((size_t)std::max<int64_t>(s.n_own, 1));
+        std::vector<int64_t> cur(s.level_ptr.begin(), s.level_ptr.end() - 1);
+        for (int64_t c = 0; c < s.n_own; ++c) cells[(size_t)cur[(size_t)level[(size_t)c]]++] = (int32_t)c;
+        ORC_TRY(s.level_cells.upload(cells.data(), cells.size()));
+    }
     ORC_TRY(s.partials.alloc((size_t)8 * kMaxPartials));
     ORC_TRY(s.scal.alloc(16));
     ORC_TRY(s.dev_status.alloc(1));
@@ -945,7 +1022,27 @@ int k_momentum(SolverState &s, double *peclet_host) {
                    s.a_u.p, s.a_v.p, s.a_w.p, s.b_u.p, s.b_v.p, s.b_w.p, s.du.p, s.dv.p, s.dw.p, s.settings.momentum,
                    s.settings.q1_compat, s.rho};
     const int g = grid_for(s.n);
-    hipLaunchKernelGGL(momentum_k, dim3(g), dim3(kBlock), 0, ctx().stream, m.dev(), m.pat.dev(), A, s.partials.p);
+    if (s.settings.frozen_diagonals == 0) {
+        // in-place diagonals (the reference's own mode): level by level over the cell order
+        ORC_TRY(vec_copy(s.du_old.p, s.du.p, s.n));
+        ORC_TRY(vec_copy(s.dv_old.p, s.dv.p, s.n));
+        ORC_TRY(vec_copy(s.dw_old.p, s.dw.p, s.n));
+        InplaceArgs I;
+        I.du_old = s.du_old.p; I.dv_old = s.dv_old.p; I.dw_old = s.dw_old.p;
+        I.pe = s.pe.p;
+        I.F = FaceArgs{s.u.p, s.v.p, s.w.p, s.p.p, s.gp.p, s.du.p, s.dv.p, s.dw.p, s.settings.velocity_interpolation,
+                       s.settings.pressure_interpolation, s.settings.q1_compat, s.rho};
+        I.status = s.dev_status.p;
+        for (size_t l = 0; l + 1 < s.level_ptr.size(); ++l) {
+            I.cells = s.level_cells.p + s.level_ptr[l];
+            I.count = s.level_ptr[l + 1] - s.level_ptr[l];
+            if (I.count == 0) continue;
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(momentum_k<true>), dim3(grid_for(I.count)), dim3(kBlock), 0, ctx().stream, m.dev(), m.pat.dev(), A, s.partials.p, I);
+        }
+        hipLaunchKernelGGL(peclet_stats_k, dim3(g), dim3(kBlock), 0, ctx().stream, s.pe.p, s.n_own, s.n, s.partials.p);
+    } else {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(momentum_k<false>), dim3(g), dim3(kBlock), 0, ctx().stream, m.dev(), m.pat.dev(), A, s.partials.p, InplaceArgs());
+    }
     hipLaunchKernelGGL(reduce_minmax_k, dim3(1), dim3(64), 0, ctx().stream, s.partials.p, g, s.scal.p + 8);
     ORC_HIP(hipGetLastError());
     if (peclet_host) {

@@ -60,6 +60,11 @@ struct SolverState {
     DevBuf<double> a_di, a_u, a_v, a_w, a_p;            // SELL value arrays (mesh pattern)
     DevBuf<double> b_u_di, b_v_di, b_w_di, b_u, b_v, b_w, b_p;
     DevBuf<double> du, dv, dw;                           // a_{u,v,w}.get(i,i): what Rhie-Chow reads
+    // frozen_diagonals = 0 (the reference's in-place reads): last iteration's diagonals, per-cell Peclet terms and
+    // the level schedule of the cell order (level_cells[level_ptr[l] .. level_ptr[l+1]) = cells of level l, ascending)
+    DevBuf<double> du_old, dv_old, dw_old, pe;
+    DevBuf<int32_t> level_cells;
+    std::vector<int64_t> level_ptr;
     DevBuf<double> gp;                                   // grad p  [3][n]
     DevBuf<double> gu;                                   // grad U  [9][n]  (TVD only)
     DevBuf<double> flux, pf, coef;                       // per face: outward (from c0) flux, face pressure, p' coefficient

@@ -169,7 +169,7 @@ def test_unsupported_settings_and_bcs_return_reference_panics(gpu, oracle, mesh_
     H.cube_bcs(om)
     dm = Mesh(MeshArrays(om.arrays()))
     for kw in (dict(momentum=CD2), dict(pressure_interpolation=2), dict(velocity_interpolation=3), dict(gradient_reconstruction=1),
-               dict(gradient_reconstruction=3), dict(frozen_diagonals=0)):
+               dict(gradient_reconstruction=3)):
         with pytest.raises(OrcError) as e:
             Solver(dm, NumericalSettings.default(**kw), 1000.0, 1e-3)
         assert e.value.status == 8
