@@ -288,7 +288,7 @@ int orc_hex_channel_write_msh(const char *path, int64_t nx, int64_t ny, int64_t 
 
 /* BASELINE config 5 workload: a box of nx x ny x nz blocks (nx >= 20) cut along x into regions of hexahedra, columns of
  * triangular prisms, Kuhn tetrahedra (six per block) and one-block transition layers of pyramids, conforming
- * throughout; about 2.7 cells per block, matrix rows of 5 / 6 / 7 entries.  Written as a TGRID .msh with triangular and
+ * throughout; about 3 cells per block, matrix rows of 5 / 6 / 7 entries.  Written as a TGRID .msh with triangular and
  * quadrilateral faces in separate zones (the reference's reader cannot parse mixed sections, io.rs:232); zones FLUID,
  * INLET, OUTLET, WALL, PERIODIC_-Z, PERIODIC_+Z and their "_TRI" twins, boundary zones of type 3 (wall). */
 int orc_mixed_channel_write_msh(const char *path, int64_t nx, int64_t ny, int64_t nz, double lx, double ly, double lz,
