@@ -1003,6 +1003,7 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
         // short the rounds continue inside one workgroup (tail_small_k) until the fixed point or until the list grows again.
         static const int small_enabled = getenv("ORC_AMG_TAIL_SMALL") ? atoi(getenv("ORC_AMG_TAIL_SMALL")) : 0;  // measured: exact, fewer launches, but +2-3 % wall at 10.24 M cells
         static const int small_max = getenv("ORC_AMG_TAIL_SMALL_MAX") ? atoi(getenv("ORC_AMG_TAIL_SMALL_MAX")) : 512;
+        static const int small_threads = getenv("ORC_AMG_TAIL_SMALL_THREADS") ? atoi(getenv("ORC_AMG_TAIL_SMALL_THREADS")) : 256;
         static const int big_batch = getenv("ORC_AMG_TAIL_BATCH") ? atoi(getenv("ORC_AMG_TAIL_BATCH")) : 2;
         const int kBatch = small_enabled ? big_batch : 16;  // four-kernel rounds per host round trip; a round past the fixed point is a no-op
         bool first = true, fin = false;
@@ -1018,7 +1019,7 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
                 first = false;
             }
             if (small_enabled)
-                hipLaunchKernelGGL(tail_small_k, dim3(1), dim3(1024), 0, st, A, choice, taken_by, T, listA, listB, flag, ch_row, ch_new, ch_old, ch_t_old, ch_t_new,
+                hipLaunchKernelGGL(tail_small_k, dim3(1), dim3(small_threads), 0, st, A, choice, taken_by, T, listA, listB, flag, ch_row, ch_new, ch_old, ch_t_old, ch_t_new,
                                    1 << 20, small_max);
             ORC_HIP(hipGetLastError());
             ORC_HIP(hipMemcpyAsync(&h, T, sizeof(h), hipMemcpyDeviceToHost, st));

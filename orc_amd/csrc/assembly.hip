@@ -1101,7 +1101,7 @@ static int create_stream(hipStream_t *out, int role, int lane) {
 }
 
 static int solve_field_on(SolverState &s, DevBuf<double> &a, DevBuf<double> &b, DevBuf<double> &x, int eq, Arena &arena, SolveStats &stats,
-                          SolveSide *side, Arena *side_arena) {
+                          SolveSide *side, Arena *side_arena, const AmgHierarchy *prepared = nullptr) {
     MatView A;
     A.P = s.mesh->pat.dev();
     A.val = a.p;
@@ -1113,7 +1113,7 @@ static int solve_field_on(SolverState &s, DevBuf<double> &a, DevBuf<double> &b, 
     ctx().reduction_order = t.reduction_order;
     stats.cache = &s.amg_cache[eq];
     stats.side = nullptr;
-    stats.hierarchy = (eq == 3 && s.p_hierarchy.n_levels > 0) ? &s.p_hierarchy : nullptr;
+    stats.hierarchy = prepared ? prepared : ((eq == 3 && s.p_hierarchy.n_levels > 0) ? &s.p_hierarchy : nullptr);
     if (side && s.two_stream_multigrid && t.solver_type == ORC_SOLVER_MULTIGRID) {
         if (!side->stream) {
             ORC_TRY(create_stream(&side->stream, kSolveStream, eq < 3 ? eq : 1));
@@ -1200,6 +1200,8 @@ struct PrepareThread {
     }
     ~PrepareThread() { if (running) th.join(); }
 };
+
+static int join_prepare(PrepareThread *prep) { return prep->join(); }
 
 // Partitioned runs (one rank of several): the same overlap with every RCCL call left where it was — on the library
 // stream, issued by the calling thread, in an order that is the same on all ranks.  Per momentum system the Multigrid
@@ -1342,34 +1344,73 @@ static int solve_momentum_partitioned(SolverState &s) {
 
 // The three momentum solves of one iteration on three streams, one host thread each (the set-up phases synchronise
 // their stream every few rounds).  Returns the first non-zero status in u, v, w order, like the sequential loop.
-static int solve_momentum_concurrently(SolverState &s) {
+struct PrepareThread;
+static int join_prepare(PrepareThread *prep);
+
+// The three momentum solves of one iteration on three streams, one host thread each (the set-up phases synchronise
+// their stream every few rounds).  Returns the first non-zero status in u, v, w order, like the sequential loop.
+// setup_first (Multigrid arm): phase 1 builds the three hierarchies side by side (beside the p' hierarchy of `prep`) with
+// no product running — the set-up rounds are chains of tiny dependent kernels, and behind other streams' 2048-workgroup
+// products every one of them waits for a free wave slot (tail kernels: 0.48 s of kernel time per iteration alone, 1.5 s
+// summed when stretched by that contention) — phase 2 runs the three solves on the prepared hierarchies.  Same kernels on
+// the same data in the same order per system: same bits.
+static int solve_momentum_concurrently(SolverState &s, bool setup_first, PrepareThread *prep) {
     Ctx &g = ctx();
     ORC_HIP(hipStreamSynchronize(g.stream));  // the assembled systems are complete
     DevBuf<double> *mats[3] = {&s.a_u, &s.a_v, &s.a_w}, *rhs[3] = {&s.b_u, &s.b_v, &s.b_w}, *sol[3] = {&s.u, &s.v, &s.w};
     int st[3] = {ORC_OK, ORC_OK, ORC_OK};
     Ctx local[3];
-    std::thread th[3];
     for (int k = 0; k < 3; ++k) {
         if (!s.lanes[k].stream) ORC_TRY(create_stream(&s.lanes[k].stream, kSetupStream, k));
         local[k] = g;
         local[k].stream = s.lanes[k].stream;
         local[k].last_error.clear();
     }
+    auto run_lanes = [&](auto &&work) {
+        std::thread th[3];
+        for (int k = 0; k < 3; ++k) {
+            try {
+                th[k] = std::thread(work, k);
+            } catch (...) {  // no thread to be had: this lane runs here, after the ones already started (nothing crosses the C ABI)
+                work(k);
+            }
+        }
+        for (int k = 0; k < 3; ++k)
+            if (th[k].joinable()) th[k].join();
+    };
+    if (setup_first) {
+        auto prepare = [&](int k) {
+            SolverState::Lane &L = s.lanes[k];
+            CtxScope scope(&local[k]);
+            if (hipSetDevice(local[k].device) != hipSuccess) { st[k] = set_error(ORC_ERR_HIP, "hipSetDevice failed in a set-up thread"); return; }
+            MatView A;
+            A.P = s.mesh->pat.dev();
+            A.val = mats[k]->p;
+            A.symmetric = s.mesh->pat.symmetric;
+            A.persistent_pattern = true;
+            L.arena.release(Arena::Mark{0, 0});
+            st[k] = multigrid_prepare_dev(A, s.settings.preconditioner, L.arena, L.hierarchy);
+            if (hipStreamSynchronize(local[k].stream) != hipSuccess && st[k] == ORC_OK) st[k] = set_error(ORC_ERR_HIP, "stream synchronisation failed in a set-up thread");
+        };
+        run_lanes(prepare);
+        const int pst = prep ? join_prepare(prep) : ORC_OK;  // the p' hierarchy was being built beside them
+        for (int k = 0; k < 3; ++k)
+            if (st[k] != ORC_OK) { g.last_error = local[k].last_error; return st[k]; }
+        if (pst != ORC_OK) return pst;
+    }
     auto work = [&](int k) {
+        SolverState::Lane &L = s.lanes[k];
         CtxScope scope(&local[k]);
         if (hipSetDevice(local[k].device) != hipSuccess) { st[k] = set_error(ORC_ERR_HIP, "hipSetDevice failed in a solve thread"); return; }
-        st[k] = solve_field_on(s, *mats[k], *rhs[k], *sol[k], k, s.lanes[k].arena, s.lanes[k].stats, &s.lanes[k].side, &s.lanes[k].side_arena);
+        if (setup_first) {
+            L.side_arena.release(Arena::Mark{0, 0});
+            st[k] = solve_field_on(s, *mats[k], *rhs[k], *sol[k], k, L.side_arena, L.stats, nullptr, nullptr, &L.hierarchy);
+        } else {
+            st[k] = solve_field_on(s, *mats[k], *rhs[k], *sol[k], k, L.arena, L.stats, &L.side, &L.side_arena);
+        }
         if (hipStreamSynchronize(local[k].stream) != hipSuccess && st[k] == ORC_OK) st[k] = set_error(ORC_ERR_HIP, "stream synchronisation failed in a solve thread");
     };
-    for (int k = 0; k < 3; ++k) {
-        try {
-            th[k] = std::thread(work, k);
-        } catch (...) {  // no thread to be had: this lane runs here, after the ones already started (nothing crosses the C ABI)
-            work(k);
-        }
-    }
-    for (int k = 0; k < 3; ++k)
-        if (th[k].joinable()) th[k].join();
+    run_lanes(work);
     s.stats = s.lanes[0].stats;
     for (int k = 0; k < 3; ++k)
         if (st[k] != ORC_OK) {
@@ -1417,7 +1458,9 @@ int solver_iterate(SolverState &s, uint64_t iterations, double *report) {
                                method == ORC_SOLVER_MULTIGRID_GS || method == ORC_SOLVER_BICGSTAB_GS_PRECOND || method == ORC_SOLVER_MULTICOLOR_GS);
         const bool lanes_partitioned = s.concurrent_momentum && H.active() && !dbg && !ctx().profile && method == ORC_SOLVER_MULTIGRID;
         if (lanes_ok) {
-            ORC_TRY(solve_momentum_concurrently(s));                    // :99-136, the three systems side by side
+            static const int setup_first_env = getenv("ORC_SETUP_FIRST") ? atoi(getenv("ORC_SETUP_FIRST")) : 0;  // measured: exact, +8 % wall (1.24 s against 1.15 s)
+            const bool setup_first = setup_first_env != 0 && method == ORC_SOLVER_MULTIGRID;
+            ORC_TRY(solve_momentum_concurrently(s, setup_first, prep.running ? &prep : nullptr));  // :99-136, the three systems side by side
         } else if (lanes_partitioned) {
             ORC_TRY(solve_momentum_partitioned(s));                     // the same with every RCCL call on the library stream
         } else {

@@ -9,9 +9,10 @@ rows = []
 for x in csv.DictReader(open(sys.argv[1])):
     rows.append((int(x["Start_Timestamp"]), int(x["End_Timestamp"]), x["Kernel_Name"].split("(")[0].replace("void ", "").replace("orc::", ""), x["Stream_Id"]))
 rows.sort()
-marks = [r[0] for r in rows if r[2] == "momentum_k"]
-a, b = marks[-1], rows[-1][1]
-it = [r for r in rows if r[0] >= a]
+marks = [r[0] for r in rows if r[2].startswith("momentum_k")]
+a = marks[-1]
+b = min(r[1] for r in rows if r[2].startswith("correction_k") and r[0] >= a)  # the iteration ends with the correction
+it = [r for r in rows if a <= r[0] <= b]
 pk = [r for r in it if r[2] == "pressure_k"]
 split = pk[-1][0]
 print("last iteration %.1f ms = momentum phase %.1f + p' phase %.1f" % ((b - a) / 1e6, (split - a) / 1e6, (b - split) / 1e6))
