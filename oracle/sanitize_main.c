@@ -45,6 +45,23 @@ int main(int argc, char **argv) {
         for (int64_t i = 0; i < 4 * n; ++i) checksum += g[i];
         free(g);
     }
+    {   /* round 2: least-squares gradient arms inside the SIMPLE loop + the post-loop pass, and the velocity initialisation */
+        OrcSettings s;
+        or_settings_default(&s);
+        s.solver_type = ORC_SOLVER_BICGSTAB;
+        s.momentum = ORC_MOMENTUM_TVD_UMIST;
+        s.gradient_reconstruction = ORC_GRAD_LEAST_SQUARES;
+        s.iterations = 8;
+        double *g = (double *)malloc(sizeof(double) * (size_t)(4 * n));
+        memcpy(g, f, sizeof(double) * (size_t)(4 * n));
+        double report[6 * 2];
+        CHECK(or_solve_steady(m, g, g + n, g + 2 * n, g + 3 * n, &s, 1000., 1e-3, 2, report));
+        for (int64_t i = 0; i < 4 * n; ++i) checksum += g[i];
+        CHECK(or_mesh_set_zone(m, "INLET", ORC_BC_VELOCITY_INLET, 0., 1e-3, 0., 0.));
+        CHECK(or_initialize_velocity_field(m, g, g + n, g + 2 * n, g + 3 * n));
+        for (int64_t i = 0; i < 4 * n; ++i) checksum += g[i];
+        free(g);
+    }
     free(f);
     or_mesh_free(m);
     printf("sanitize_main ok: %lld cells, checksum %.17g\n", (long long)n, checksum);

@@ -34,6 +34,12 @@ int orc_mesh_update_zones(OrcMesh *, const int32_t *, const double *, const doub
 int orc_calculate_gradients(const OrcMesh *, const double *, const double *, const double *, const double *, const OrcSettings *, double *, double *) {
     return ORC_ERR_NO_DEVICE;
 }
+OrcMesh *orc_mesh_create_partitioned(int64_t, int64_t, int64_t, int64_t, int32_t, const int64_t *, const int64_t *, const int32_t *, const double *,
+                                     const double *, const double *, const double *, const double *, const int64_t *, const int64_t *, const int32_t *,
+                                     const double *, const double *, int32_t, const int32_t *, const int64_t *, const int64_t *, const int64_t *, int *status) {
+    if (status) *status = ORC_ERR_NO_DEVICE;
+    return nullptr;
+}
 }
 
 static int run_file(const char *path, bool expect_ok) {
@@ -74,6 +80,36 @@ static int run_file(const char *path, bool expect_ok) {
         orc_mesh_data_destroy(d);
         return 1;
     }
+    // orc_mesh_partition (partition.cpp) in every ordering and at 1, 2 and 5 ranks: sizes, arrays, the (stubbed) upload
+    if (dims == 3 && nc > 0) {
+        bool rejected = false;  // a mesh the reader accepts but orc_mesh_create would not (a face without cells): a clean error, once
+        for (int ordering = 0; ordering < 3 && !rejected; ++ordering)
+            for (int ranks : {1, 2, 5}) {
+                int64_t owned_total = 0;
+                for (int r = 0; r < ranks; ++r) {
+                    int pst = 0;
+                    OrcPartition *P = orc_mesh_partition(nc, nf, c0.data(), c1.data(), fz.data(), area.data(), nrm.data(), fc.data(), cc.data(), vol.data(),
+                                                         cfp.data(), cf.data(), ranks, r, ordering, &pst);
+                    if (!P && pst == ORC_ERR_BAD_ARGUMENT && ordering == 0 && ranks == 1) { rejected = true; break; }
+                    if (!P) { fprintf(stderr, "%s: partition failed (%d: %s)\n", path, pst, orc::g_err.c_str()); orc_mesh_data_destroy(d); return 1; }
+                    int64_t no, nl, ng, pf, pcf, ns;
+                    int32_t np;
+                    orc_partition_sizes(P, &no, &nl, &ng, &pf, &pcf, &np, &ns);
+                    std::vector<int64_t> a0((size_t)pf), a1((size_t)pf), pcfp((size_t)nl + 1), pcfa((size_t)pcf), gid((size_t)nl), gfid((size_t)pf), sp((size_t)np + 1),
+                        si((size_t)ns), rp((size_t)np + 1);
+                    std::vector<int32_t> az((size_t)pf), peers((size_t)np);
+                    std::vector<double> pa((size_t)pf), pn((size_t)3 * pf), pfc((size_t)3 * pf), pcc((size_t)3 * nl), pv((size_t)nl);
+                    orc_partition_arrays(P, a0.data(), a1.data(), az.data(), pa.data(), pn.data(), pfc.data(), pcc.data(), pv.data(), pcfp.data(), pcfa.data(),
+                                         gid.data(), gfid.data(), peers.data(), sp.data(), si.data(), rp.data());
+                    owned_total += no;
+                    int ust = 0;
+                    if (orc_partition_upload(P, 0, nullptr, nullptr, nullptr, &ust) != nullptr || ust != ORC_ERR_NO_DEVICE) { orc_partition_destroy(P); orc_mesh_data_destroy(d); return 1; }
+                    orc_partition_destroy(P);
+                }
+                if (rejected) break;
+                if (owned_total != nc) { fprintf(stderr, "%s: %d ranks own %lld of %lld cells\n", path, ranks, (long long)owned_total, (long long)nc); orc_mesh_data_destroy(d); return 1; }
+            }
+    }
     int stu = 0;
     if (orc_mesh_upload(d, &stu) != nullptr || stu != ORC_ERR_NO_DEVICE) { orc_mesh_data_destroy(d); return 1; }  // goes through the (stubbed) device entry
     orc_mesh_data_destroy(d);
@@ -82,6 +118,14 @@ static int run_file(const char *path, bool expect_ok) {
 
 int main(int argc, char **argv) {
     int bad = 0;
+    {   // the mixed tet / pyramid / prism / hex generator (mesh_gen.cpp) and the reader on its output
+        const std::string path = std::string(argv[argc - 1] + (argv[argc - 1][0] == '!' ? 1 : 0)) + ".mixed.msh";
+        int64_t gc = 0, gf = 0;
+        if (orc_mixed_channel_write_msh(path.c_str(), 20, 3, 2, 0.002, 0.001, 2e-4, &gc, &gf) != ORC_OK || gc <= 0) { fprintf(stderr, "mixed generator failed\n"); bad++; }
+        else bad += run_file(path.c_str(), true);
+        if (orc_mixed_channel_write_msh(path.c_str(), 5, 3, 2, 0.002, 0.001, 2e-4, &gc, &gf) != ORC_ERR_BAD_ARGUMENT) bad++;  // nx < 20
+        remove(path.c_str());
+    }
     for (int a = 1; a < argc; ++a) {
         const bool expect_ok = argv[a][0] != '!';
         bad += run_file(argv[a] + (expect_ok ? 0 : 1), expect_ok);

@@ -294,3 +294,44 @@ def test_read_data_accepts_reference_style_lines_and_rejects_garbage(tmp_path):
     with pytest.raises(OrcError) as e:
         orc_io.read_data(str(tmp_path / "absent.csv"))
     assert e.value.status == 13 and "could not read data file" in str(e.value)
+
+
+def test_mixed_channel_generator_is_conforming_and_readable(oracle, tmp_path):
+    """orc_mixed_channel_write_msh (BASELINE config 5 workload): tetrahedra, pyramids, prisms and hexahedra in one conforming
+    mesh — every interior face has exactly two cells (the writer rejects an unpaired one), every cell is closed, the volumes
+    fill the box, triangular and quadrilateral faces sit in separate zones, and the product reader and the oracle's reader
+    build identical meshes from the file."""
+    from orc_amd import io as orc_io
+    from orc_amd.mesh import write_mixed_channel_msh
+    path = str(tmp_path / "mixed.msh")
+    nx, ny, nz = 24, 5, 4
+    nc, nf = write_mixed_channel_msh(path, nx, ny, nz)
+    d = orc_io.read_mesh(path)
+    a = d.arrays()
+    om = oracle.Mesh.read(path)
+    ao = om.arrays()
+    assert len(a["cell_volume"]) == nc == om.n_cells and len(a["face_area"]) == nf == om.n_faces
+    for k in ("face_c0", "face_c1", "face_zone", "face_area", "face_normal", "face_centroid", "cell_centroid", "cell_volume", "cell_face_ptr", "cell_faces"):
+        assert np.array_equal(np.asarray(a[k]), np.asarray(ao[k])), k
+    nfc = np.diff(a["cell_face_ptr"])
+    assert set(np.unique(nfc).tolist()) == {4, 5, 6}
+    vol = np.asarray(a["cell_volume"])
+    assert vol.min() > 0 and abs(vol.sum() - 0.002 * 0.001 * 1e-4 * nz) < 1e-13 * vol.sum()
+    c0, c1 = np.asarray(a["face_c0"]), np.asarray(a["face_c1"])
+    An = np.asarray(a["face_normal"]) * np.asarray(a["face_area"])[:, None]
+    S = np.zeros((nc, 3))
+    np.add.at(S, c0, An)
+    m = c1 >= 0
+    np.add.at(S, c1[m], -An[m])
+    assert np.abs(S).max() < 1e-20
+    names = a["zone_names"]
+    assert {"FLUID", "FLUID_TRI", "INLET", "OUTLET", "WALL", "WALL_TRI", "PERIODIC_-Z", "PERIODIC_-Z_TRI", "PERIODIC_+Z", "PERIODIC_+Z_TRI"} <= set(names)
+    # faces of a "_TRI" zone have three nodes, the others four (the reference cannot parse mixed zones, io.rs:232)
+    fz = np.asarray(a["face_zone"])
+    _, fnp, _ = d.nodes()
+    nn = np.diff(fnp)
+    for zi, name in enumerate(a["zone_names"]):
+        sel = nn[fz == zi]
+        assert len(sel) == 0 or set(np.unique(sel).tolist()) == ({3} if name.endswith("_TRI") else {4}), name
+    with pytest.raises(Exception):
+        write_mixed_channel_msh(path, 10, 3, 2)  # fewer than 20 blocks along x: the regions would collapse

@@ -1,5 +1,6 @@
-"""AddressSanitizer + UBSan over the product's host-side io.rs mirror (orc_amd/csrc/mesh_io.cpp, compiled with g++ and
-the device entry points stubbed): every reference mesh, truncated and corrupted variants, the checkpoint formats."""
+"""AddressSanitizer + UBSan over the product's host-side code (orc_amd/csrc/mesh_io.cpp, partition.cpp, mesh_gen.cpp,
+compiled with g++ and the device entry points stubbed): every reference mesh, truncated and corrupted variants, the
+checkpoint formats, the partitioner in every ordering at 1 / 2 / 5 ranks, the mixed-element generator."""
 import os
 import subprocess
 
@@ -15,7 +16,8 @@ def reader_binary(tmp_path_factory):
     cmd = ["g++", "-std=c++17", "-O1", "-g", "-ffp-contract=off", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
            "-fno-omit-frame-pointer", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include"),
            "-I" + os.path.join(ROOT, "orc_amd", "csrc"), os.path.join(ROOT, "tests", "sanitize_reader_main.cpp"),
-           os.path.join(ROOT, "orc_amd", "csrc", "mesh_io.cpp"), "-o", exe]
+           os.path.join(ROOT, "orc_amd", "csrc", "mesh_io.cpp"), os.path.join(ROOT, "orc_amd", "csrc", "partition.cpp"),
+           os.path.join(ROOT, "orc_amd", "csrc", "mesh_gen.cpp"), "-o", exe]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     return exe
