@@ -18,6 +18,7 @@
 // the reference's summation order (i ascending inside T = R A, j ascending inside T R^T), so the
 // coarse operator is bit-identical to nalgebra-sparse's.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <mutex>
 
@@ -363,6 +364,184 @@ __global__ __launch_bounds__(1024) void tail_small_k(MatView A, int *choice, int
         T->rounds += rounds;
         T->parity = s_parity;
         if (finished) T->finished = 1;
+    }
+}
+
+// ---- asynchronous tail: one wavefront follows one cascade ---------------------------------------------------------
+// What is left after the first row-level round are cascades: a row changes its partner, which frees one column and takes
+// another, which makes exactly one later row change, ... for hundreds of dependent steps (the traces show work lists
+// whose every row changes, shrinking by a few rows per round).  Lock-step rounds pay four kernel boundaries per step of
+// the LONGEST cascade; here a wavefront takes a listed row and follows its cascade on its own — evaluate, commit, repair
+// the two touched columns, continue with the first row that activates — so a step costs a chain of L2 round trips
+// instead of a round of launches.  Cascades run concurrently and may meet, hence the protocol:
+//   * shared state (choice, first-taker table, row flags) is read and written with agent-scope atomics only;
+//   * a row is owned by one wavefront at a time: flag bit 1 = running, bit 0 = queued / re-run requested.  An
+//     activation that finds the row running only sets bit 0 and the owner runs it again when it is through;
+//   * the first taker of a column is kept with a version: (version << 32 | first row).  Whoever changes a row's
+//     partner bumps the versions of the old and the new column AFTER the commit, scans the column and installs its
+//     result with an atomic max, so the scan that started after the last commit is the one that stays;
+//   * each install activates the rows whose "taken before me" status differs between the value it replaced and the
+//     one it installed; a row that committed to a column and then finds an earlier taker in its own scan re-queues
+//     itself (the store-buffering race between its commit and the earlier taker's activation pass).
+// Every loop is bounded: no wavefront ever waits for another.  The fixed point is unique, so the result does not depend
+// on the interleaving; and because the row-level rounds run once more from scratch afterwards (exact first takers
+// rebuilt, every row evaluated), a flaw here could only cost time: a round that changes nothing certifies the pairing.
+// Ordering between this wavefront's accesses to the shared state: every one of them is an agent-scope atomic that is
+// performed at the device's coherence point, so all that is needed is to wait for the previous ones to complete before
+// the next is issued (s_waitcnt).  A device-scope fence would also write back and invalidate the XCD's L2 — measured at
+// hundreds of microseconds per fence with thousands of wavefronts doing it — and there is no plain shared data to flush.
+__device__ __forceinline__ void chase_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+__device__ __forceinline__ int ld_i(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_i(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int first_taker(const unsigned long long *tb, int j) {
+    return (int)(unsigned)(__hip_atomic_load(tb + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xffffffffull);
+}
+
+__global__ void chase_convert_k(const int *__restrict__ taken_by, unsigned long long *__restrict__ tb, int *__restrict__ ver, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        tb[i] = (unsigned long long)(unsigned)taken_by[i];  // version 0
+        ver[i] = 0;
+    }
+}
+
+// group_eval_row over a whole wavefront, against the versioned table
+__device__ __forceinline__ int wave_eval_row(const MatView &A, const unsigned long long *tb, int i, int lane) {
+    const int len = A.P.row_len[i];
+    const RowWalk W(A, i);
+    double best = 1.7976931348623157e308;  // Float::MAX
+    int bk = 0x7fffffff, bj = -1;
+    for (int k = lane; k < len; k += 64) {
+        const int j = W.column(k);
+        if (j == i || j >= A.P.n) continue;
+        if (first_taker(tb, j) < i) continue;
+        const double a = W.value(A, i, k);
+        if (a < best) { best = a; bk = k; bj = j; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ob = __shfl_xor(best, off, 64);
+        const int ok = __shfl_xor(bk, off, 64);
+        const int oj = __shfl_xor(bj, off, 64);
+        if (ob < best || (ob == best && ok < bk)) { best = ob; bk = ok; bj = oj; }
+    }
+    return bj;
+}
+
+// queue row m unless it is queued already; true when the caller has to find it a place (list or continuation)
+__device__ __forceinline__ bool chase_request(int *flag, int m) { return __hip_atomic_fetch_or(flag + m, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0; }
+
+// the wavefront's rows to queue: the first becomes its continuation when it has none, the rest go to the next list
+__device__ __forceinline__ void chase_place(bool enq, int m, int lane, int &cont, int *next_list, int *next_count) {
+    unsigned long long mask = __ballot(enq);
+    if (!mask) return;
+    if (cont < 0) {
+        const int leader = __ffsll((long long)mask) - 1;
+        cont = __shfl(m, leader, 64);
+        mask &= mask - 1ull;
+        if (lane == leader) enq = false;
+        if (!mask) return;
+    }
+    const int first = __ffsll((long long)mask) - 1;
+    int base = 0;
+    if (lane == first) base = atomicAdd(next_count, __popcll(mask));
+    base = __shfl(base, first, 64);
+    if (enq) next_list[base + __popcll(mask & ((1ull << lane) - 1ull))] = m;
+}
+
+// row `i` (running, owned by this wavefront) changed its partner from or to column j
+__device__ __forceinline__ void chase_touch(const MatView &A, const int *choice, unsigned long long *tb, int *ver, int *flag, int j, int i, bool is_new,
+                                            int lane, int &cont, int *next_list, int *next_count) {
+    const int lj = A.P.row_len[j];
+    const RowWalk W(A, j);
+    unsigned v = 0;
+    if (lane == 0) v = (unsigned)__hip_atomic_fetch_add(ver + j, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    v = (unsigned)__shfl((int)v, 0, 64);
+    chase_fence();
+    int mn = 0x7fffffff;
+    for (int kk = lane; kk < lj; kk += 64) {  // rows holding column j = (symmetric pattern) the columns of row j
+        const int m = W.column(kk);
+        if (m >= A.P.n || m == j) continue;
+        if (ld_i(choice + m) == j && m < mn) mn = m;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mn = min(mn, __shfl_xor(mn, off, 64));
+    const unsigned long long packed = ((unsigned long long)v << 32) | (unsigned long long)(unsigned)mn;
+    unsigned prev_lo = 0, prev_hi = 0;
+    if (lane == 0) {
+        const unsigned long long prev = __hip_atomic_fetch_max(tb + j, packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        prev_lo = (unsigned)(prev & 0xffffffffull);
+        prev_hi = (unsigned)(prev >> 32);
+    }
+    prev_lo = (unsigned)__shfl((int)prev_lo, 0, 64);
+    prev_hi = (unsigned)__shfl((int)prev_hi, 0, 64);
+    chase_fence();
+    const int t_before = (int)prev_lo;
+    if (prev_hi < v && mn != t_before) {  // this scan is the newest: activate the rows that see column j differently now
+        const int lo = min(mn, t_before), hi = max(mn, t_before);
+        const bool taken_earlier = mn < t_before;
+        for (int k0 = 0; k0 < lj; k0 += 64) {
+            const int kk = k0 + lane;
+            const int m = kk < lj ? W.column(kk) : -1;
+            bool want = m >= 0 && m < A.P.n && m > lo && m <= hi;
+            if (want && taken_earlier) want = ld_i(choice + m) == j;  // only a row that had chosen j loses it
+            const bool enq = want && chase_request(flag, m);
+            chase_place(enq, m, lane, cont, next_list, next_count);
+        }
+    }
+    // an earlier row holds the column this row has just committed to: evaluate this row again (the owner sees bit 0
+    // when it is through with the row)
+    if (is_new && mn < i && lane == 0) __hip_atomic_fetch_or(flag + i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(kBlock) void tail_chase_k(MatView A, int *choice, unsigned long long *tb, int *ver, int *flag, TailCounters *T, int *list_a,
+                                                       int *list_b, int max_steps) {
+    const int count = T->cur;
+    if (T->finished || count == 0) return;
+    const int *cur = T->parity ? list_b : list_a;
+    int *next = T->parity ? list_a : list_b;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    int steps = 0;
+    for (int64_t idx = wave; idx < count; idx += waves) {
+        int i = cur[idx];
+        while (i >= 0) {
+            if (steps >= max_steps) {  // hand the row (still queued) to the next launch
+                if (lane == 0) next[atomicAdd(&T->next, 1)] = i;
+                break;
+            }
+            ++steps;
+            if (lane == 0) __hip_atomic_exchange(flag + i, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // queued -> running
+            chase_fence();
+            const int nv = wave_eval_row(A, tb, i, lane);
+            const int old = ld_i(choice + i);
+            int cont = -1;
+            if (nv != old) {
+                if (lane == 0) st_i(choice + i, nv);
+                chase_fence();
+                if (old >= 0) chase_touch(A, choice, tb, ver, flag, old, i, false, lane, cont, next, &T->next);
+                if (nv >= 0) chase_touch(A, choice, tb, ver, flag, nv, i, true, lane, cont, next, &T->next);
+            }
+            int was = 0;
+            if (lane == 0) was = __hip_atomic_fetch_and(flag + i, ~2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // running -> idle, or -> queued
+            was = __shfl(was, 0, 64);
+            if (was & 1) {  // somebody asked for this row while it ran
+                if (cont < 0) cont = i;
+                else if (lane == 0) next[atomicAdd(&T->next, 1)] = i;
+            }
+            i = cont;
+        }
+    }
+    if (lane == 0 && steps) atomicAdd(&T->changed, steps);  // statistics: evaluations of this launch
+}
+
+__global__ void chase_rotate_k(TailCounters *T, int *steps_total) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && !T->finished) {
+        *steps_total += T->changed;
+        T->cur = T->next;
+        T->next = 0;
+        T->changed = 0;
+        T->rounds += 1;
+        T->parity ^= 1;
     }
 }
 
@@ -954,6 +1133,16 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
     hipLaunchKernelGGL(agg_init_k, dim3(g), dim3(kBlock), 0, st, A, choice, act_a, act_b);  // also resets the slice flags
     if (warm) ORC_HIP(hipMemcpyAsync(choice, warm, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, st));
     int rounds = 0;
+    static const bool trace_t = getenv("ORC_AMG_TRACE") != nullptr;
+    double t_mark = 0.;
+    auto lap = [&](const char *what) {  // trace only: wall time of the phase that just ended (drains the stream)
+        if (!trace_t) return;
+        (void)hipStreamSynchronize(st);
+        const double now = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+        if (what) fprintf(stderr, "[amg phase n=%lld] %s %.3f ms\n", (long long)n, what, now - t_mark);
+        t_mark = now;
+    };
+    lap(nullptr);
     const bool sym = A.symmetric;
     const int all_active = sym ? 0 : 1;  // activation needs "rows holding column j" = columns of row j
     unsigned char *cur = act_a, *nxt = act_b;
@@ -982,6 +1171,7 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
         }
         if (rounds > 8 * 1000 * 1000) return set_error(ORC_ERR_BAD_ARGUMENT, "aggregation did not reach its fixed point");
     }
+    lap("bulk sweeps");
     if (sym) {
         // ---- tail phase: exact taken_by once, then row-level rounds
         int *flag, *listA, *listB, *ch_row, *ch_new, *ch_old, *ch_t_old, *ch_t_new;
@@ -1008,8 +1198,57 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
         const int kBatch = small_enabled ? big_batch : 16;  // four-kernel rounds per host round trip; a round past the fixed point is a no-op
         bool first = true, fin = false;
         TailCounters h;
+        static const int chase_enabled = getenv("ORC_AMG_CHASE") ? atoi(getenv("ORC_AMG_CHASE")) : 1;
+        static const int chase_steps = getenv("ORC_AMG_CHASE_STEPS") ? atoi(getenv("ORC_AMG_CHASE_STEPS")) : 4096;
+        static const int chase_grid = getenv("ORC_AMG_CHASE_GRID") ? atoi(getenv("ORC_AMG_CHASE_GRID")) : 2048;
+        static const bool trace = getenv("ORC_AMG_TRACE") != nullptr;
+        if (chase_enabled) {
+            // one lock-step round over every row, the cascades it leaves followed asynchronously, then the lock-step rounds
+            // again from scratch: they certify the fixed point (one round that changes nothing) or finish the job
+            const int ge = g;
+            hipLaunchKernelGGL(tail_eval_k, dim3(ge), dim3(kBlock), 0, st, A, choice, taken_by, (const int *)listA, (const int *)listB, T, flag, ch_row, ch_new);
+            hipLaunchKernelGGL(tail_commit_k, dim3(ge), dim3(kBlock), 0, st, choice, taken_by, T, ch_row, ch_new, ch_old, ch_t_old, ch_t_new);
+            hipLaunchKernelGGL(tail_update_k, dim3(ge), dim3(kBlock), 0, st, A, choice, taken_by, T, ch_row, ch_new, ch_old, ch_t_old, ch_t_new, flag, listA, listB);
+            hipLaunchKernelGGL(tail_rotate_k, dim3(1), dim3(1), 0, st, T);
+            unsigned long long *tb;
+            int *ver, *steps_total;
+            ORC_TRY(arena.alloc((size_t)n, &tb));
+            ORC_TRY(arena.alloc((size_t)n, &ver));
+            ORC_TRY(arena.alloc((size_t)64, &steps_total));
+            ORC_HIP(hipMemsetAsync(steps_total, 0, sizeof(int), st));
+            hipLaunchKernelGGL(chase_convert_k, dim3(g), dim3(kBlock), 0, st, (const int *)taken_by, tb, ver, n);
+            lap("first lock-step round");
+            int launches = 0, first_list = -1;
+            for (;;) {
+                for (int b = 0; b < 2; ++b) {
+                    hipLaunchKernelGGL(tail_chase_k, dim3(chase_grid), dim3(kBlock), 0, st, A, choice, tb, ver, flag, T, listA, listB, chase_steps);
+                    hipLaunchKernelGGL(chase_rotate_k, dim3(1), dim3(1), 0, st, T, steps_total);
+                }
+                launches += 2;
+                ORC_HIP(hipGetLastError());
+                ORC_HIP(hipMemcpyAsync(&h, T, sizeof(h), hipMemcpyDeviceToHost, st));
+                ORC_HIP(hipStreamSynchronize(st));
+                if (first_list < 0) first_list = h.cur;
+                if (h.finished || h.cur == 0 || launches >= 64) break;
+            }
+            rounds += h.rounds;
+            lap("cascades");
+            if (trace) {
+                int stot = 0;
+                ORC_HIP(hipMemcpy(&stot, steps_total, sizeof(int), hipMemcpyDeviceToHost));
+                fprintf(stderr, "[amg chase n=%lld] launches %d evaluations %d left %d finished %d\n", (long long)n, launches, stot, h.cur, h.finished);
+            }
+            fin = h.finished != 0;
+            if (!fin) {  // certification / completion: exact first takers from scratch, every row evaluated
+                hipLaunchKernelGGL(agg_reset_k, dim3(g), dim3(kBlock), 0, st, taken_by, n);
+                hipLaunchKernelGGL(agg_scatter_k, dim3(g), dim3(kBlock), 0, st, choice, taken_by, n);
+                hipLaunchKernelGGL(tail_seed_k, dim3(1), dim3(1), 0, st, T, (int)n);
+            }
+        }
+        int cert_batches = 0;
         while (!fin) {
-            for (int b = 0; b < kBatch; ++b) {
+            const int batch = chase_enabled && cert_batches == 0 ? 1 : kBatch;  // after the cascades one round is expected to certify
+            for (int b = 0; b < batch; ++b) {
                 static const int tail_grid = getenv("ORC_AMG_TAIL_GRID") ? atoi(getenv("ORC_AMG_TAIL_GRID")) : 1024;
                 const int ge = first ? g : tail_grid;
                 hipLaunchKernelGGL(tail_eval_k, dim3(ge), dim3(kBlock), 0, st, A, choice, taken_by, (const int *)listA, (const int *)listB, T, flag, ch_row, ch_new);
@@ -1025,8 +1264,11 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
             ORC_HIP(hipMemcpyAsync(&h, T, sizeof(h), hipMemcpyDeviceToHost, st));
             ORC_HIP(hipStreamSynchronize(st));
             fin = h.finished != 0;
+            ++cert_batches;
             if (h.rounds > 8 * 1000 * 1000) return set_error(ORC_ERR_BAD_ARGUMENT, "aggregation did not reach its fixed point");
         }
+        lap("lock-step rounds");
+        if (trace && chase_enabled) fprintf(stderr, "[amg certify n=%lld] lock-step rounds %d\n", (long long)n, h.rounds);
         rounds += h.rounds;
     }
     ORC_HIP(hipMemsetAsync(chooser, 0xff, sizeof(int) * (size_t)n, st));
