@@ -404,105 +404,137 @@ __global__ void chase_convert_k(const int *__restrict__ taken_by, unsigned long 
     }
 }
 
-// group_eval_row over a whole wavefront, against the versioned table
-__device__ __forceinline__ int wave_eval_row(const MatView &A, const unsigned long long *tb, int i, int lane) {
-    const int len = A.P.row_len[i];
-    const RowWalk W(A, i);
-    double best = 1.7976931348623157e308;  // Float::MAX
-    int bk = 0x7fffffff, bj = -1;
-    for (int k = lane; k < len; k += 64) {
-        const int j = W.column(k);
-        if (j == i || j >= A.P.n) continue;
-        if (first_taker(tb, j) < i) continue;
-        const double a = W.value(A, i, k);
-        if (a < best) { best = a; bk = k; bj = j; }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const double ob = __shfl_xor(best, off, 64);
-        const int ok = __shfl_xor(bk, off, 64);
-        const int oj = __shfl_xor(bj, off, 64);
-        if (ob < best || (ob == best && ok < bk)) { best = ob; bk = ok; bj = oj; }
-    }
-    return bj;
-}
-
 // queue row m unless it is queued already; true when the caller has to find it a place (list or continuation)
 __device__ __forceinline__ bool chase_request(int *flag, int m) { return __hip_atomic_fetch_or(flag + m, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0; }
 
-// the wavefront's rows to queue: the first becomes its continuation when it has none, the rest go to the next list
-__device__ __forceinline__ void chase_place(bool enq, int m, int lane, int &cont, int *next_list, int *next_count) {
-    unsigned long long mask = __ballot(enq);
+// A cascade is followed by a group of G lanes (G = 16, 32 or 64, by the level's row length): short rows leave most of a
+// wavefront idle, and what limits the early rounds is the number of cascades in flight.  Control flow is uniform inside
+// a group; the groups of a wavefront run the same code on different rows and diverge only where their cascades do.
+template <int G>
+__device__ __forceinline__ unsigned long long group_ballot(bool p) {
+    const unsigned long long m = __ballot(p);
+    if (G == 64) return m;
+    const int shift = (threadIdx.x & 63) & ~(G - 1);
+    return (m >> shift) & ((1ull << G) - 1ull);
+}
+
+// the group's rows to queue: the first becomes its continuation when it has none, the rest go to the next list
+template <int G>
+__device__ __forceinline__ void chase_place(bool enq, int m, int gl, int &cont, int *next_list, int *next_count) {
+    unsigned long long mask = group_ballot<G>(enq);
     if (!mask) return;
     if (cont < 0) {
         const int leader = __ffsll((long long)mask) - 1;
-        cont = __shfl(m, leader, 64);
+        cont = __shfl(m, leader, G);
         mask &= mask - 1ull;
-        if (lane == leader) enq = false;
+        if (gl == leader) enq = false;
         if (!mask) return;
     }
     const int first = __ffsll((long long)mask) - 1;
     int base = 0;
-    if (lane == first) base = atomicAdd(next_count, __popcll(mask));
-    base = __shfl(base, first, 64);
-    if (enq) next_list[base + __popcll(mask & ((1ull << lane) - 1ull))] = m;
+    if (gl == first) base = atomicAdd(next_count, __popcll(mask));
+    base = __shfl(base, first, G);
+    if (enq) next_list[base + __popcll(mask & ((1ull << gl) - 1ull))] = m;
 }
 
-// row `i` (running, owned by this wavefront) changed its partner from or to column j
-__device__ __forceinline__ void chase_touch(const MatView &A, const int *choice, unsigned long long *tb, int *ver, int *flag, int j, int i, bool is_new,
-                                            int lane, int &cont, int *next_list, int *next_count) {
-    const int lj = A.P.row_len[j];
-    const RowWalk W(A, j);
-    unsigned v = 0;
-    if (lane == 0) v = (unsigned)__hip_atomic_fetch_add(ver + j, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-    v = (unsigned)__shfl((int)v, 0, 64);
-    chase_fence();
-    int mn = 0x7fffffff;
-    for (int kk = lane; kk < lj; kk += 64) {  // rows holding column j = (symmetric pattern) the columns of row j
-        const int m = W.column(kk);
-        if (m >= A.P.n || m == j) continue;
-        if (ld_i(choice + m) == j && m < mn) mn = m;
+// Row i (running, owned by this wavefront) moved from column jj[0] to column jj[1] (-1: none).  Both columns are repaired
+// together, phase by phase, so that their memory round trips overlap — a cascade's speed is the number of dependent
+// round trips per step: versions + row geometry, column lists, the takers' choices, the two installs, the activations.
+template <int G>
+__device__ __forceinline__ void chase_touch2(const MatView &A, const int *choice, unsigned long long *tb, int *ver, int *flag, const int (&jj)[2], int i,
+                                             int lane, int &cont, int *next_list, int *next_count) {
+    const int n = (int)A.P.n;
+    int lj[2] = {0, 0}, m0[2] = {-1, -1}, c0[2] = {-2, -2}, mn[2] = {0x7fffffff, 0x7fffffff};
+    unsigned v[2] = {0u, 0u};
+    const int32_t *colp[2] = {nullptr, nullptr};
+    int64_t cbase[2] = {0, 0}, cstride[2] = {1, 1};
+    // ---- versions (after the commit) and row geometry
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        if (jj[t] < 0) continue;
+        if (lane == 0) v[t] = (unsigned)__hip_atomic_fetch_add(ver + jj[t], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        lj[t] = A.P.row_len[jj[t]];
+        const RowWalk W(A, jj[t]);
+        colp[t] = W.col; cbase[t] = W.base; cstride[t] = W.stride;
+    }
+    // ---- the rows holding each column (symmetric pattern: the columns of row j); first G entries kept in registers
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+        if (jj[t] >= 0 && lane < lj[t]) m0[t] = colp[t][cbase[t] + (int64_t)lane * cstride[t]];
+    chase_fence();  // the version bumps are performed before any taker's choice is read
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+        if (m0[t] >= 0 && m0[t] < n && m0[t] != jj[t]) c0[t] = ld_i(choice + m0[t]);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        if (jj[t] < 0) continue;
+        if (c0[t] == jj[t]) mn[t] = m0[t];
+        for (int kk = G + lane; kk < lj[t]; kk += G) {  // rows longer than the group
+            const int m = colp[t][cbase[t] + (int64_t)kk * cstride[t]];
+            if (m >= n || m == jj[t]) continue;
+            if (ld_i(choice + m) == jj[t] && m < mn[t]) mn[t] = m;
+        }
+#pragma unroll
+        for (int off = G / 2; off > 0; off >>= 1) mn[t] = min(mn[t], __shfl_xor(mn[t], off, G));
+    }
+    // ---- install (newest version wins)
+    unsigned prev_lo[2] = {0u, 0u}, prev_hi[2] = {0u, 0u};
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        if (jj[t] < 0) continue;
+        v[t] = (unsigned)__shfl((int)v[t], 0, G);
+        if (lane == 0) {
+            const unsigned long long packed = ((unsigned long long)v[t] << 32) | (unsigned long long)(unsigned)mn[t];
+            const unsigned long long prev = __hip_atomic_fetch_max(tb + jj[t], packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            prev_lo[t] = (unsigned)(prev & 0xffffffffull);
+            prev_hi[t] = (unsigned)(prev >> 32);
+        }
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mn = min(mn, __shfl_xor(mn, off, 64));
-    const unsigned long long packed = ((unsigned long long)v << 32) | (unsigned long long)(unsigned)mn;
-    unsigned prev_lo = 0, prev_hi = 0;
-    if (lane == 0) {
-        const unsigned long long prev = __hip_atomic_fetch_max(tb + j, packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        prev_lo = (unsigned)(prev & 0xffffffffull);
-        prev_hi = (unsigned)(prev >> 32);
+    for (int t = 0; t < 2; ++t) {
+        prev_lo[t] = (unsigned)__shfl((int)prev_lo[t], 0, G);
+        prev_hi[t] = (unsigned)__shfl((int)prev_hi[t], 0, G);
     }
-    prev_lo = (unsigned)__shfl((int)prev_lo, 0, 64);
-    prev_hi = (unsigned)__shfl((int)prev_hi, 0, 64);
-    chase_fence();
-    const int t_before = (int)prev_lo;
-    if (prev_hi < v && mn != t_before) {  // this scan is the newest: activate the rows that see column j differently now
-        const int lo = min(mn, t_before), hi = max(mn, t_before);
-        const bool taken_earlier = mn < t_before;
-        for (int k0 = 0; k0 < lj; k0 += 64) {
-            const int kk = k0 + lane;
-            const int m = kk < lj ? W.column(kk) : -1;
-            bool want = m >= 0 && m < A.P.n && m > lo && m <= hi;
-            if (want && taken_earlier) want = ld_i(choice + m) == j;  // only a row that had chosen j loses it
-            const bool enq = want && chase_request(flag, m);
-            chase_place(enq, m, lane, cont, next_list, next_count);
+    chase_fence();  // installs before activations
+    // ---- activate the rows that see a column differently now
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        if (jj[t] < 0) continue;
+        const int t_before = (int)prev_lo[t];
+        if (prev_hi[t] < v[t] && mn[t] != t_before) {  // this scan is the newest one
+            const int lo = min(mn[t], t_before), hi = max(mn[t], t_before);
+            const bool taken_earlier = mn[t] < t_before;
+            for (int k0 = 0; k0 < lj[t]; k0 += G) {
+                const int kk = k0 + lane;
+                int m = -1, cm = -2;
+                if (k0 == 0) { m = m0[t]; cm = c0[t]; }
+                else if (kk < lj[t]) m = colp[t][cbase[t] + (int64_t)kk * cstride[t]];
+                bool want = m >= 0 && m < n && m > lo && m <= hi;
+                if (want && taken_earlier) {  // only a row that had chosen j loses it (read after this row's commit)
+                    if (k0 != 0) cm = ld_i(choice + m);
+                    want = cm == jj[t];
+                }
+                const bool enq = want && chase_request(flag, m);
+                chase_place<G>(enq, m, lane, cont, next_list, next_count);
+            }
         }
     }
     // an earlier row holds the column this row has just committed to: evaluate this row again (the owner sees bit 0
     // when it is through with the row)
-    if (is_new && mn < i && lane == 0) __hip_atomic_fetch_or(flag + i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (jj[1] >= 0 && mn[1] < i && lane == 0) __hip_atomic_fetch_or(flag + i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+template <int G>
 __global__ __launch_bounds__(kBlock) void tail_chase_k(MatView A, int *choice, unsigned long long *tb, int *ver, int *flag, TailCounters *T, int *list_a,
                                                        int *list_b, int max_steps) {
     const int count = T->cur;
     if (T->finished || count == 0) return;
     const int *cur = T->parity ? list_b : list_a;
     int *next = T->parity ? list_a : list_b;
-    const int lane = threadIdx.x & 63;
-    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int lane = threadIdx.x & (G - 1);  // lane inside the group
+    const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G, groups = ((int64_t)gridDim.x * blockDim.x) / G;
     int steps = 0;
-    for (int64_t idx = wave; idx < count; idx += waves) {
+    for (int64_t idx = group; idx < count; idx += groups) {
         int i = cur[idx];
         while (i >= 0) {
             if (steps >= max_steps) {  // hand the row (still queued) to the next launch
@@ -510,20 +542,43 @@ __global__ __launch_bounds__(kBlock) void tail_chase_k(MatView A, int *choice, u
                 break;
             }
             ++steps;
-            if (lane == 0) __hip_atomic_exchange(flag + i, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // queued -> running
-            chase_fence();
-            const int nv = wave_eval_row(A, tb, i, lane);
-            const int old = ld_i(choice + i);
+            // queued -> running.  A request that lands before this store is served by the evaluation below (its install
+            // precedes it); one that lands after finds the row running and is seen when the row is through.
+            if (lane == 0) st_i(flag + i, 2);
+            const int old = ld_i(choice + i);  // only the owner writes it
+            // ---- evaluate (group_eval_row over the wavefront, against the versioned table)
+            const int len = A.P.row_len[i];
+            const RowWalk W(A, i);
+            double best = 1.7976931348623157e308;  // Float::MAX
+            int bk = 0x7fffffff, bj = -1;
+            for (int k0 = 0; k0 < len; k0 += G) {
+                const int k = k0 + lane;
+                int j = -1;
+                double a = 0.;
+                if (k < len) { j = W.column(k); a = W.value(A, i, k); }
+                if (k0 == 0) chase_fence();  // the flag store is performed before the table is read
+                if (j < 0 || j == i || j >= A.P.n) continue;
+                if (first_taker(tb, j) < i) continue;
+                if (a < best) { best = a; bk = k; bj = j; }
+            }
+#pragma unroll
+            for (int off = G / 2; off > 0; off >>= 1) {
+                const double ob = __shfl_xor(best, off, G);
+                const int ok = __shfl_xor(bk, off, G);
+                const int oj = __shfl_xor(bj, off, G);
+                if (ob < best || (ob == best && ok < bk)) { best = ob; bk = ok; bj = oj; }
+            }
+            const int nv = bj;
             int cont = -1;
             if (nv != old) {
                 if (lane == 0) st_i(choice + i, nv);
-                chase_fence();
-                if (old >= 0) chase_touch(A, choice, tb, ver, flag, old, i, false, lane, cont, next, &T->next);
-                if (nv >= 0) chase_touch(A, choice, tb, ver, flag, nv, i, true, lane, cont, next, &T->next);
+                chase_fence();  // commit before the version bumps
+                const int jj[2] = {old, nv};
+                chase_touch2<G>(A, choice, tb, ver, flag, jj, i, lane, cont, next, &T->next);
             }
             int was = 0;
             if (lane == 0) was = __hip_atomic_fetch_and(flag + i, ~2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // running -> idle, or -> queued
-            was = __shfl(was, 0, 64);
+            was = __shfl(was, 0, G);
             if (was & 1) {  // somebody asked for this row while it ran
                 if (cont < 0) cont = i;
                 else if (lane == 0) next[atomicAdd(&T->next, 1)] = i;
@@ -1218,10 +1273,19 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
             ORC_HIP(hipMemsetAsync(steps_total, 0, sizeof(int), st));
             hipLaunchKernelGGL(chase_convert_k, dim3(g), dim3(kBlock), 0, st, (const int *)taken_by, tb, ver, n);
             lap("first lock-step round");
+            // lanes per cascade: the narrowest group that covers a typical row in one pass
+            static const int group_env = getenv("ORC_AMG_CHASE_GROUP") ? atoi(getenv("ORC_AMG_CHASE_GROUP")) : 0;
+            int64_t stored = 0;  // padded entries: an upper bound of the mean row length is all that is needed
+            ORC_HIP(hipMemcpyAsync(&stored, A.P.slice_ptr + A.P.n_slices, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+            ORC_HIP(hipStreamSynchronize(st));
+            const double avg_len = n > 0 ? (double)stored / (double)n : 0.;
+            const int group = group_env ? group_env : (avg_len <= 14. ? 16 : (avg_len <= 28. ? 32 : 64));
             int launches = 0, first_list = -1;
             for (;;) {
                 for (int b = 0; b < 2; ++b) {
-                    hipLaunchKernelGGL(tail_chase_k, dim3(chase_grid), dim3(kBlock), 0, st, A, choice, tb, ver, flag, T, listA, listB, chase_steps);
+                    if (group == 16) hipLaunchKernelGGL(tail_chase_k<16>, dim3(chase_grid), dim3(kBlock), 0, st, A, choice, tb, ver, flag, T, listA, listB, chase_steps);
+                    else if (group == 32) hipLaunchKernelGGL(tail_chase_k<32>, dim3(chase_grid), dim3(kBlock), 0, st, A, choice, tb, ver, flag, T, listA, listB, chase_steps);
+                    else hipLaunchKernelGGL(tail_chase_k<64>, dim3(chase_grid), dim3(kBlock), 0, st, A, choice, tb, ver, flag, T, listA, listB, chase_steps);
                     hipLaunchKernelGGL(chase_rotate_k, dim3(1), dim3(1), 0, st, T, steps_total);
                 }
                 launches += 2;
