@@ -18,6 +18,7 @@
 // the reference's summation order (i ascending inside T = R A, j ascending inside T R^T), so the
 // coarse operator is bit-identical to nalgebra-sparse's.
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <cmath>
 #include <mutex>
@@ -874,6 +875,204 @@ __global__ __launch_bounds__(64) void galerkin_wave_k(MatView A, const int *__re
     }
 }
 
+// ---- the same product without sorting --------------------------------------------------------------------------------
+// The candidates of T = (R A)[I,:] are <= 4 fine rows whose columns ascend, so T is a MERGE: every candidate finds its
+// place by binary searches in the other lists (equal columns keep the order of the fine rows, i ascending, which is the
+// reference's order of accumulation).  And (T R^T)[I,J] = sum_j T_j R_Jj is a sum over the <= 4 fine indices of row J
+// of R (restriction_row(J), ascending j — again the reference's order): once the distinct J are known each output lane
+// looks its <= 4 terms up in T.  The distinct J need no sort either: a fine column j reaches J = j >> 1 (when j has a
+// partner) and J' = chooser[j] >> 1 (when it was chosen), and whether an earlier T entry reaches the same coarse column is
+// decided by O(1) look-ups (the sibling 2J+1 / the sibling's partner).  The survivors are ranked by counting.  Compared
+// with two bitonic sorts per coarse row (dozens of LDS passes with a barrier each) this is a handful of passes, and the
+// lists need half the LDS.  Bit-identical output (same products, same order of every sum).
+__device__ __forceinline__ int lds_lower_bound(const int *p, int len, int key) {
+    int lo = 0, hi = len;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (p[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+__device__ __forceinline__ int lds_upper_bound(const int *p, int len, int key) {
+    int lo = 0, hi = len;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (p[mid] <= key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// exclusive prefix sum of one int per lane across a group of G lanes
+template <int G>
+__device__ __forceinline__ int group_excl_scan(int v, int &total) {
+    const int gl = threadIdx.x & (G - 1);
+    int x = v;
+#pragma unroll
+    for (int off = 1; off < G; off <<= 1) {
+        const int y = __shfl_up(x, off, G);
+        if (gl >= off) x += y;
+    }
+    total = __shfl(x, G - 1, G);
+    return x - v;
+}
+
+// G lanes per coarse row (64 / G rows per wavefront): the passes of a narrow row (<= 32 candidates on the first coarse
+// level) fill half a wavefront, and the kernel is bound by instruction issue, not by memory.
+template <int G>
+__global__ __launch_bounds__(64) void galerkin_merge_k(MatView A, const int *__restrict__ choice, const int *__restrict__ chooser, int64_t n_coarse,
+                                                       int cap /* power of two >= 2 * candidates */, int *__restrict__ row_len_c,
+                                                       const long long *__restrict__ slice_base, const int *__restrict__ intra_off, int *__restrict__ s_col,
+                                                       double *__restrict__ s_val, const int *__restrict__ list, const int *__restrict__ list_count) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int kRows = 64 / G;  // coarse rows in flight per wavefront
+    const int h = cap >> 1;
+    const int lane = threadIdx.x & (G - 1), grp = threadIdx.x / G;
+    double *src_val = reinterpret_cast<double *>(smem + (size_t)grp * (size_t)cap * 16);  // candidates in generation order, later T's values
+    double *m_val = src_val + h;                          // merged candidates
+    int *src_col = reinterpret_cast<int *>(m_val + h);    // ... later T's columns
+    int *m_col = src_col + h;
+    int *U = m_col + h;  // [cap] distinct coarse columns, unsorted
+    const int n_fine = (int)A.P.n;
+    const int64_t total_rows = list ? (int64_t)*list_count : n_coarse;
+    for (int64_t it0 = (int64_t)blockIdx.x * kRows; it0 < total_rows; it0 += (int64_t)gridDim.x * kRows) {
+        const int64_t it = it0 + grp;
+        const bool active = it < total_rows;  // the barriers below are reached by every group the same number of times
+        const int64_t I = active ? (list ? (int64_t)list[it] : it) : 0;
+        RRow R;
+        R.n = 0;
+        if (active) R = restriction_row(choice, I, A.P.n);
+        // ---- 1. candidates, list after list (ghost columns dropped: coarse levels are per rank)
+        int b1 = 0, b2 = 0, b3 = 0, b4 = 0;
+        {
+            int base = 0;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                if (a < R.n) {
+                    const int i = R.idx[a];
+                    const double w = R.w[a];
+                    const int len = A.P.row_len[i];
+                    const int64_t rb = A.P.slice_ptr[i >> 6] + (i & 63);
+                    for (int k0 = 0; k0 < len; k0 += G) {
+                        const int k = k0 + lane;
+                        int c = -1;
+                        int64_t pos = 0;
+                        if (k < len) { pos = rb + (int64_t)k * 64; c = A.P.col[pos]; }
+                        const int valid = (c >= 0 && c < n_fine) ? 1 : 0;
+                        int tot;
+                        const int slot = base + group_excl_scan<G>(valid, tot);
+                        if (valid) { src_col[slot] = c; src_val[slot] = w * view_value(A, i, pos); }
+                        base += tot;
+                    }
+                }
+                if (a == 0) b1 = base;
+                if (a == 1) b2 = base;
+                if (a == 2) b3 = base;
+                if (a == 3) b4 = base;
+            }
+        }
+        const int cnt = b4;
+        __syncthreads();
+        // ---- 2. merge: rank = own position + entries of earlier lists with column <= c + entries of later lists with column < c
+        for (int e = lane; e < cnt; e += G) {
+            const int a = (e >= b1) + (e >= b2) + (e >= b3);
+            const int c = src_col[e];
+            const int own_base = a == 0 ? 0 : (a == 1 ? b1 : (a == 2 ? b2 : b3));
+            int rank = e - own_base;
+            if (a != 0 && b1 > 0) rank += lds_upper_bound(src_col, b1, c);
+            if (a != 1 && b2 > b1) rank += a > 1 ? lds_upper_bound(src_col + b1, b2 - b1, c) : lds_lower_bound(src_col + b1, b2 - b1, c);
+            if (a != 2 && b3 > b2) rank += a > 2 ? lds_upper_bound(src_col + b2, b3 - b2, c) : lds_lower_bound(src_col + b2, b3 - b2, c);
+            if (a != 3 && b4 > b3) rank += lds_lower_bound(src_col + b3, b4 - b3, c);
+            m_col[rank] = c;
+            m_val[rank] = src_val[e];
+        }
+        __syncthreads();
+        // ---- 3. runs of equal j -> T (sorted by j) into src_col / src_val
+        int cntT = 0;
+        for (int b0 = 0; b0 < cnt; b0 += G) {
+            const int e = b0 + lane;
+            int head = 0;
+            if (e < cnt) head = (e == 0) || (m_col[e] != m_col[e - 1]);
+            int tot;
+            const int slot = cntT + group_excl_scan<G>(head, tot);
+            if (head) {
+                const int j = m_col[e];
+                double acc = 0. + m_val[e];
+                for (int q = e + 1; q < cnt && m_col[q] == j; ++q) acc += m_val[q];
+                src_col[slot] = j;
+                src_val[slot] = acc;
+            }
+            cntT += tot;
+        }
+        __syncthreads();
+        const int *tj = src_col;
+        const double *tv = src_val;
+        // ---- 4. the distinct coarse columns, first occurrence only
+        int nU = 0;
+        for (int b0 = 0; b0 < cntT; b0 += G) {
+            const int e = b0 + lane;
+            int k0 = -1, k1 = -1;
+            if (e < cntT) {
+                const int j = tj[e];
+                const int cj = choice[j], mj = chooser[j];
+                if (cj >= 0) {  // J = j >> 1; its other fine row 2J comes first when it is here too
+                    const bool dup = (j & 1) && e > 0 && tj[e - 1] == j - 1 && choice[j - 1] >= 0;
+                    if (!dup) k0 = j >> 1;
+                }
+                if (mj >= 0) {  // J' = chooser[j] >> 1
+                    const int Jp = mj >> 1;
+                    bool drop = cj >= 0 && Jp == (j >> 1);
+                    if (!drop) {  // reached through its own fine rows 2J', 2J'+1 (with a partner) by some T entry?
+                        const int p = lds_lower_bound(tj, cntT, 2 * Jp);
+                        const bool has_even = p < cntT && tj[p] == 2 * Jp;
+                        if (has_even && choice[2 * Jp] >= 0) drop = true;
+                        else {
+                            const int q = has_even ? p + 1 : p;
+                            if (q < cntT && tj[q] == 2 * Jp + 1 && choice[2 * Jp + 1] >= 0) drop = true;
+                        }
+                    }
+                    if (!drop) {  // the sibling of chooser[j] chose an earlier T entry: that one keeps J'
+                        const int sib = mj ^ 1;
+                        if (sib < n_fine) {
+                            const int js = choice[sib];
+                            if (js >= 0 && js < j) {
+                                const int p = lds_lower_bound(tj, cntT, js);
+                                if (p < cntT && tj[p] == js) drop = true;
+                            }
+                        }
+                    }
+                    if (!drop) k1 = Jp;
+                }
+            }
+            int tot;
+            int slot = nU + group_excl_scan<G>((k0 >= 0 ? 1 : 0) + (k1 >= 0 ? 1 : 0), tot);
+            if (k0 >= 0) U[slot++] = k0;
+            if (k1 >= 0) U[slot] = k1;
+            nU += tot;
+        }
+        __syncthreads();
+        // ---- 5. every distinct J: position by counting, value from the <= 4 fine indices of row J of R (ascending)
+        const long long off = active ? slice_base[I >> 6] + intra_off[I] : 0;
+        for (int e = lane; e < nU; e += G) {
+            const int u = U[e];
+            int rank = 0;
+            for (int q = 0; q < nU; ++q) rank += U[q] < u ? 1 : 0;
+            const RRow RJ = restriction_row(choice, u, A.P.n);
+            double acc = 0.;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                if (a < RJ.n) {
+                    const int p = lds_lower_bound(tj, cntT, RJ.idx[a]);
+                    if (p < cntT && tj[p] == RJ.idx[a]) acc += tv[p] * RJ.w[a];
+                }
+            }
+            s_col[off + rank] = u;
+            s_val[off + rank] = acc;
+        }
+        if (active && lane == 0) row_len_c[I] = nU;
+        __syncthreads();
+    }
+}
+
 // scratch rows -> SELL-64 (columns, values, diagonal offsets, padding)
 __global__ void galerkin_pack_k(SellDev Pc, const long long *__restrict__ slice_base, const int *__restrict__ intra_off, const int *__restrict__ s_col,
                                 const double *__restrict__ s_val,
@@ -906,7 +1105,7 @@ __global__ void galerkin_pack_k(SellDev Pc, const long long *__restrict__ slice_
 constexpr int kGalerkinTiers = 7;  // LDS list capacities 64 << t, t = 0..6 (2 KB .. 128 KB per wavefront)
 __global__ __launch_bounds__(64) void galerkin_bound_k(SellDev P, const int *__restrict__ choice, int64_t n_coarse, int *__restrict__ out_max,
                                                        unsigned long long *__restrict__ out_sum, int *__restrict__ intra_off,
-                                                       long long *__restrict__ slice_tot, int *__restrict__ tier_count, int *__restrict__ tier_list) {
+                                                       long long *__restrict__ slice_tot, int *__restrict__ tier_count, int *__restrict__ tier_list, int min_tier) {
     const int lane = threadIdx.x;
     const int64_t n_slices = (n_coarse + 63) / 64;
     int mx = 0;
@@ -929,7 +1128,7 @@ __global__ __launch_bounds__(64) void galerkin_bound_k(SellDev P, const int *__r
         // the row's list never exceeds 2c entries: it goes to the narrowest tier that holds them (no overflow passes)
         int tier = -1;
         if (I < n_coarse) {
-            tier = 1;  // 128 slots (4 KB) is the smallest list: 16 wavefronts per CU already saturate the narrow rows
+            tier = min_tier;  // sorting kernel: 128 slots (4 KB) at least, 16 wavefronts per CU already saturate the narrow rows
             while (tier < kGalerkinTiers - 1 && (64 << tier) < 2 * c) ++tier;
         }
         for (int t = 0; t < kGalerkinTiers; ++t) {
@@ -973,67 +1172,56 @@ __global__ __launch_bounds__(1024) void scan_i64_k(const long long *__restrict__
     }
 }
 
-// slice widths -> slice_ptr (single workgroup scan; n_slices is n/64)
-__global__ __launch_bounds__(1024) void slice_ptr_k(const int *__restrict__ row_len, int64_t n, int n_slices, int64_t *__restrict__ slice_ptr) {
-    __shared__ long long carry;
-    __shared__ long long buf[1024];
-    if (threadIdx.x == 0) { carry = 0; slice_ptr[0] = 0; }
+// slice widths -> slice_ptr and packed sizes -> pk_ptr.
+// One wavefront per slice reduces its 64 row lengths (SELL width * 64 and the packed size rounded up to 16 elements =
+// 128 bytes), then ONE workgroup scans both tables (a single workgroup reading all n row lengths itself took 0.9 + 1.4 ms
+// per level at 5 M rows).
+__global__ __launch_bounds__(kBlock) void slice_sizes_k(const int *__restrict__ row_len, int64_t n, int n_slices, int64_t *__restrict__ w_sell,
+                                                        int64_t *__restrict__ w_pk) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t s = wave; s < n_slices; s += waves) {
+        const int64_t r = s * 64 + lane;
+        const int len = r < n ? row_len[r] : 0;
+        int mx = len, sum = len;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            mx = max(mx, __shfl_xor(mx, off, 64));
+            sum += __shfl_xor(sum, off, 64);
+        }
+        if (lane == 0) { w_sell[s] = (int64_t)mx * 64; w_pk[s] = ((int64_t)sum + 15) & ~(int64_t)15; }
+    }
+}
+// exclusive scans of two tables at once, totals in out[n]; wave shuffles inside a 1024-element tile, one LDS hop across waves
+__global__ __launch_bounds__(1024) void scan2_i64_k(const int64_t *__restrict__ in_a, const int64_t *__restrict__ in_b, int n, int64_t *__restrict__ out_a,
+                                                    int64_t *__restrict__ out_b) {
+    __shared__ long long wave_tot[2][16];
+    __shared__ long long carry[2];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x < 2) carry[threadIdx.x] = 0;
     __syncthreads();
-    for (int base = 0; base < n_slices; base += 1024) {
-        const int s = base + threadIdx.x;
-        long long w = 0;
-        if (s < n_slices) {
-            const int64_t lo = (int64_t)s * 64, hi = lo + 64 < n ? lo + 64 : n;
-            int mx = 0;
-            for (int64_t r = lo; r < hi; ++r) mx = max(mx, row_len[r]);
-            w = (long long)mx * 64;
+    for (int base = 0; base < n; base += 1024) {
+        const int e = base + threadIdx.x;
+        const long long va = e < n ? (long long)in_a[e] : 0, vb = e < n ? (long long)in_b[e] : 0;
+        long long xa = va, xb = vb;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const long long ya = __shfl_up(xa, off, 64), yb = __shfl_up(xb, off, 64);
+            if (lane >= off) { xa += ya; xb += yb; }
         }
-        buf[threadIdx.x] = w;
+        if (lane == 63) { wave_tot[0][w] = xa; wave_tot[1][w] = xb; }
         __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
-            long long v = threadIdx.x >= off ? buf[threadIdx.x - off] : 0;
-            __syncthreads();
-            buf[threadIdx.x] += v;
-            __syncthreads();
-        }
-        if (s < n_slices) slice_ptr[s + 1] = carry + buf[threadIdx.x];
+        long long pa = carry[0], pb = carry[1];
+        for (int q = 0; q < w; ++q) { pa += wave_tot[0][q]; pb += wave_tot[1][q]; }
+        if (e < n) { out_a[e] = (int64_t)(pa + xa - va); out_b[e] = (int64_t)(pb + xb - vb); }
         __syncthreads();
-        if (threadIdx.x == 1023) carry += buf[1023];
+        if (threadIdx.x == 1023) { carry[0] = pa + xa; carry[1] = pb + xb; }
         __syncthreads();
     }
+    if (threadIdx.x == 0) { out_a[n] = (int64_t)carry[0]; out_b[n] = (int64_t)carry[1]; }
 }
 
 // ---- packed mirror of the coarse operator (PackedDev, linalg.hpp): what the level's ~200 products stream
-// slice sizes (sum of the row lengths, rounded up to 16 elements = 128 bytes) -> pk_ptr (single workgroup scan)
-__global__ __launch_bounds__(1024) void pk_ptr_k(const int *__restrict__ row_len, int64_t n, int n_slices, int64_t *__restrict__ pk_ptr) {
-    __shared__ long long carry;
-    __shared__ long long buf[1024];
-    if (threadIdx.x == 0) { carry = 0; pk_ptr[0] = 0; }
-    __syncthreads();
-    for (int base = 0; base < n_slices; base += 1024) {
-        const int s = base + threadIdx.x;
-        long long w = 0;
-        if (s < n_slices) {
-            const int64_t lo = (int64_t)s * 64, hi = lo + 64 < n ? lo + 64 : n;
-            long long sum = 0;
-            for (int64_t r = lo; r < hi; ++r) sum += row_len[r];
-            w = (sum + 15) & ~15ll;
-        }
-        buf[threadIdx.x] = w;
-        __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
-            long long v = threadIdx.x >= off ? buf[threadIdx.x - off] : 0;
-            __syncthreads();
-            buf[threadIdx.x] += v;
-            __syncthreads();
-        }
-        if (s < n_slices) pk_ptr[s + 1] = carry + buf[threadIdx.x];
-        __syncthreads();
-        if (threadIdx.x == 1023) carry += buf[1023];
-        __syncthreads();
-    }
-}
-
 // scratch rows -> packed image: one wavefront per slice, depth by depth; the entries of the active lanes land back to back
 __global__ __launch_bounds__(kBlock) void galerkin_pack_packed_k(SellDev Pc, const int64_t *__restrict__ pk_ptr, const long long *__restrict__ slice_base,
                                                                  const int *__restrict__ intra_off, const int *__restrict__ s_col,
@@ -1351,6 +1539,16 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
     int64_t *slice_ptr;
     const int n_slices = (int)((nc + 63) / 64);
     const size_t ncs = (size_t)std::max<int64_t>(nc, 1);
+    static const bool trace_t = getenv("ORC_AMG_TRACE") != nullptr;
+    double t_mark = 0.;
+    auto lap = [&](const char *what) {  // trace only: wall time of the phase that just ended (drains the stream)
+        if (!trace_t) return;
+        (void)hipStreamSynchronize(st);
+        const double now = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+        if (what) fprintf(stderr, "[amg phase n=%lld] %s %.3f ms\n", (long long)n, what, now - t_mark);
+        t_mark = now;
+    };
+    lap(nullptr);
     ORC_TRY(arena.alloc(ncs, &row_len));
     ORC_TRY(arena.alloc(ncs, &diag));
     ORC_TRY(arena.alloc(ncs, &intra_off));
@@ -1361,12 +1559,27 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
     ORC_TRY(arena.alloc((size_t)2, &counters));
     ORC_HIP(hipMemsetAsync(flags, 0, 4 * sizeof(int), st));
     ORC_HIP(hipMemsetAsync(counters, 0, 2 * sizeof(unsigned long long), st));
+    static const bool use_sort = getenv("ORC_GALERKIN_SORT") != nullptr && atoi(getenv("ORC_GALERKIN_SORT")) != 0;
+    // lanes per coarse row by LDS tier (list capacity 64 << t); ORC_GALERKIN_GROUPS="g0,g1,..." overrides
+    static const std::array<int, kGalerkinTiers> tier_group = [] {
+        std::array<int, kGalerkinTiers> g = {16, 16, 32, 64, 64, 64, 64};  // measured at 10.24 M fine rows (levels of 7 / 15 / 34 entries per row)
+        if (const char *e = getenv("ORC_GALERKIN_GROUPS")) {
+            int t = 0;
+            for (const char *q = e; *q && t < kGalerkinTiers; ++t) {
+                const int v = atoi(q);
+                if (v == 16 || v == 32 || v == 64) g[t] = v;
+                while (*q && *q != ',') ++q;
+                if (*q == ',') ++q;
+            }
+        }
+        return g;
+    }();
     int *tier_count, *tier_list;
     ORC_TRY(arena.alloc((size_t)kGalerkinTiers + 1, &tier_count));
     ORC_TRY(arena.alloc((size_t)kGalerkinTiers * ncs, &tier_list));
     ORC_HIP(hipMemsetAsync(tier_count, 0, (kGalerkinTiers + 1) * sizeof(int), st));
     hipLaunchKernelGGL(galerkin_bound_k, dim3((unsigned)std::min<int64_t>(n_slices, 8192)), dim3(64), 0, st, A.P, choice, nc, flags, counters + 1, intra_off,
-                       slice_tot, tier_count, tier_list);
+                       slice_tot, tier_count, tier_list, use_sort ? 1 : 0);
     hipLaunchKernelGGL(scan_i64_k, dim3(1), dim3(1024), 0, st, slice_tot, (int64_t)n_slices, slice_base);
     int hflags[4];
     unsigned long long hcount[2];
@@ -1381,13 +1594,29 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
     double *s_val;
     ORC_TRY(arena.alloc((size_t)scratch_cap, &s_col));
     ORC_TRY(arena.alloc((size_t)scratch_cap, &s_val));
+    lap("galerkin bounds");
     static std::once_flag attr_once;  // several lane threads reach this concurrently
     std::call_once(attr_once, [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&galerkin_wave_k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&galerkin_merge_k<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     // LDS tiers (32 B per list slot): every row was assigned to the narrowest list that is guaranteed to hold it
     if ((size_t)2 * max_cand > (size_t)(64 << (kGalerkinTiers - 1))) return set_error(ORC_ERR_BAD_ARGUMENT, "Galerkin row too long for LDS (%d candidates)", max_cand);
-    for (int t = 0; t < kGalerkinTiers; ++t) {
+    for (int t = 0; t < kGalerkinTiers && !use_sort; ++t) {
+        if (htier[t] == 0) continue;
+        const int cap = 64 << t;
+        const int G = tier_group[t];  // narrow rows: two or four coarse rows per wavefront
+        const int rows_per_wave = 64 / G;
+        const size_t smem = (size_t)cap * 16 * (size_t)rows_per_wave;
+        static const int merge_waves = getenv("ORC_GALERKIN_WAVES") ? atoi(getenv("ORC_GALERKIN_WAVES")) : 16;
+        const int waves_per_cu = (int)std::max<size_t>(1, std::min<size_t>((size_t)merge_waves, (size_t)(150 * 1024) / smem));
+        const int g = (int)std::min<int64_t>(((int64_t)htier[t] + rows_per_wave - 1) / rows_per_wave, (int64_t)256 * waves_per_cu);
+        const int *tl = tier_list + (int64_t)t * nc, *tc = tier_count + t;
+        if (G == 16) hipLaunchKernelGGL(galerkin_merge_k<16>, dim3(g), dim3(64), smem, st, A, choice, chooser, nc, cap, row_len, slice_base, intra_off, s_col, s_val, tl, tc);
+        else if (G == 32) hipLaunchKernelGGL(galerkin_merge_k<32>, dim3(g), dim3(64), smem, st, A, choice, chooser, nc, cap, row_len, slice_base, intra_off, s_col, s_val, tl, tc);
+        else hipLaunchKernelGGL(galerkin_merge_k<64>, dim3(g), dim3(64), smem, st, A, choice, chooser, nc, cap, row_len, slice_base, intra_off, s_col, s_val, tl, tc);
+    }
+    for (int t = 0; t < kGalerkinTiers && use_sort; ++t) {
         if (htier[t] == 0) continue;
         const int cap = 64 << t;
         const size_t smem = (size_t)cap * 32;
@@ -1396,10 +1625,13 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
         hipLaunchKernelGGL(galerkin_wave_k, dim3(g), dim3(64), smem, st, A, choice, chooser, nc, cap, row_len, slice_base, intra_off, s_col, s_val,
                            flags + 1, (const int *)(tier_list + (int64_t)t * nc), (const int *)(tier_count + t), (int *)nullptr, (int *)nullptr);
     }
-    hipLaunchKernelGGL(slice_ptr_k, dim3(1), dim3(1024), 0, st, row_len, nc, n_slices, slice_ptr);
-    int64_t *pk_ptr;
+    lap("galerkin product");
+    int64_t *pk_ptr, *w_sell, *w_pk;
     ORC_TRY(arena.alloc((size_t)n_slices + 1, &pk_ptr));
-    hipLaunchKernelGGL(pk_ptr_k, dim3(1), dim3(1024), 0, st, row_len, nc, n_slices, pk_ptr);
+    ORC_TRY(arena.alloc((size_t)n_slices + 1, &w_sell));
+    ORC_TRY(arena.alloc((size_t)n_slices + 1, &w_pk));
+    hipLaunchKernelGGL(slice_sizes_k, dim3((unsigned)std::min<int64_t>(((int64_t)n_slices + 3) / 4, 4096)), dim3(kBlock), 0, st, row_len, nc, n_slices, w_sell, w_pk);
+    hipLaunchKernelGGL(scan2_i64_k, dim3(1), dim3(1024), 0, st, (const int64_t *)w_sell, (const int64_t *)w_pk, n_slices, slice_ptr, pk_ptr);
     ORC_HIP(hipGetLastError());
     int64_t padded = 0, packed_total = 0;
     ORC_HIP(hipMemcpyAsync(&packed_total, pk_ptr + n_slices, sizeof(int64_t), hipMemcpyDeviceToHost, st));
@@ -1416,6 +1648,7 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
     Pc.n = nc; Pc.ncols = nc; Pc.n_slices = n_slices; Pc.ragged = padded < 24 * nc ? 2 : 1; Pc.slice_ptr = slice_ptr; Pc.row_len = row_len; Pc.col = col; Pc.diag_pos = diag;
     hipLaunchKernelGGL(galerkin_pack_k, dim3(grid_for(nc)), dim3(kBlock), 0, st, Pc, slice_base, intra_off, s_col, s_val, col, val, diag);
     ORC_HIP(hipGetLastError());
+    lap("galerkin pack");
     L.P = Pc; L.val = val; L.n = nc; L.padded = padded;
     L.pk = PackedDev();
     L.xw = XWinDev();
@@ -1445,6 +1678,7 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
         ORC_HIP(hipGetLastError());
         L.xw.wcol = wcol; L.xw.wsize = wsize; L.xw.lidx = lidx;
     }
+    lap("galerkin mirrors");
     return ORC_OK;
 }
 
