@@ -1073,29 +1073,68 @@ __global__ __launch_bounds__(64) void galerkin_merge_k(MatView A, const int *__r
     }
 }
 
-// scratch rows -> SELL-64 (columns, values, diagonal offsets, padding)
-__global__ void galerkin_pack_k(SellDev Pc, const long long *__restrict__ slice_base, const int *__restrict__ intra_off, const int *__restrict__ s_col,
-                                const double *__restrict__ s_val,
-                                int *__restrict__ col_c, double *__restrict__ val_c, int *__restrict__ diag_c) {
-    for (int64_t I = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; I < Pc.n; I += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t base = Pc.slice_ptr[I >> 6] + (I & 63);
-        const int width = (int)((Pc.slice_ptr[(I >> 6) + 1] - Pc.slice_ptr[I >> 6]) >> 6);
-        const int len = Pc.row_len[I];
-        const long long off = slice_base[I >> 6] + intra_off[I];
+// scratch rows -> SELL-64 (columns, values, diagonal offsets, padding) and, when asked for, the packed mirror, in one
+// pass.  The scratch rows are contiguous per ROW, the images are interleaved per SLICE: a thread copying its own row reads
+// 64 different cache lines per instruction (the texture path serialises them: 3 ms per image at 5 M rows).  Here one
+// wavefront moves one slice through an LDS tile of 16 depths x 64 rows: four rows at a time are read with 16 consecutive
+// lanes each (a handful of lines per instruction), the tile is read back depth by depth with lane = row, and both images
+// are written with full-width stores.
+constexpr int kPackDepth = 16;
+__global__ __launch_bounds__(64) void galerkin_pack_fused_k(SellDev Pc, const long long *__restrict__ slice_base, const int *__restrict__ intra_off,
+                                                            const int *__restrict__ s_col, const double *__restrict__ s_val, int *__restrict__ col_c,
+                                                            double *__restrict__ val_c, int *__restrict__ diag_c, const int64_t *__restrict__ pk_ptr,
+                                                            int *__restrict__ pk_col, double *__restrict__ pk_val) {
+    __shared__ int t_col[kPackDepth * 65];
+    __shared__ double t_val[kPackDepth * 65];
+    const int lane = threadIdx.x;
+    const int kk = lane & (kPackDepth - 1), rr = lane / kPackDepth;  // gather phase: depth inside the tile, row inside the group of 4
+    for (int64_t slice = blockIdx.x; slice < Pc.n_slices; slice += gridDim.x) {
+        const int64_t I = slice * 64 + lane;
+        const bool live = I < Pc.n;
+        const int len = live ? Pc.row_len[I] : 0;
+        const long long src = live ? slice_base[slice] + intra_off[I] : 0;
+        const int src_lo = (int)(unsigned)(src & 0xffffffffll), src_hi = (int)(src >> 32);
+        const int64_t base = Pc.slice_ptr[slice];
+        const int width = (int)((Pc.slice_ptr[slice + 1] - base) >> 6);
+        int64_t pk_off = pk_ptr ? pk_ptr[slice] : 0;
         int d = -1;
-        for (int q = 0; q < width; ++q) {
-            const int64_t pos = base + (int64_t)q * 64;
-            if (q < len) {
-                const int J = s_col[off + q];
-                col_c[pos] = J;
-                val_c[pos] = s_val[off + q];
-                if (J == I) d = (int)pos;
-            } else {
-                col_c[pos] = (int)I;
-                val_c[pos] = 0.;
+        for (int kc = 0; kc < width; kc += kPackDepth) {
+            // ---- gather: rows 4 rb + rr, depths kc + kk
+#pragma unroll 4
+            for (int rb = 0; rb < 64 / (64 / kPackDepth); ++rb) {
+                const int row = rb * (64 / kPackDepth) + rr;
+                const int rlen = __shfl(len, row, 64);
+                const long long rsrc = ((long long)__shfl(src_hi, row, 64) << 32) | (long long)(unsigned)__shfl(src_lo, row, 64);
+                const int k = kc + kk;
+                if (k < rlen) {
+                    t_col[kk * 65 + row] = s_col[rsrc + k];
+                    t_val[kk * 65 + row] = s_val[rsrc + k];
+                }
             }
+            __syncthreads();
+            // ---- scatter: depth by depth, lane = row
+            const int kend = min(kPackDepth, width - kc);
+            for (int q = 0; q < kend; ++q) {
+                const int k = kc + q;
+                const bool in = k < len;
+                const int c = in ? t_col[q * 65 + lane] : (int)I;
+                const double v = in ? t_val[q * 65 + lane] : 0.;
+                const int64_t pos = base + (int64_t)k * 64 + lane;
+                if (live) {
+                    col_c[pos] = c;
+                    val_c[pos] = v;
+                    if (in && c == (int)I) d = (int)pos;
+                }
+                if (pk_ptr) {
+                    const unsigned long long m = __ballot(in);
+                    const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                    if (in) { pk_col[pk_off + rank] = c; pk_val[pk_off + rank] = v; }
+                    pk_off += __popcll(m);
+                }
+            }
+            __syncthreads();
         }
-        diag_c[I] = d;
+        if (live) diag_c[I] = d;
     }
 }
 
@@ -1222,32 +1261,6 @@ __global__ __launch_bounds__(1024) void scan2_i64_k(const int64_t *__restrict__ 
 }
 
 // ---- packed mirror of the coarse operator (PackedDev, linalg.hpp): what the level's ~200 products stream
-// scratch rows -> packed image: one wavefront per slice, depth by depth; the entries of the active lanes land back to back
-__global__ __launch_bounds__(kBlock) void galerkin_pack_packed_k(SellDev Pc, const int64_t *__restrict__ pk_ptr, const long long *__restrict__ slice_base,
-                                                                 const int *__restrict__ intra_off, const int *__restrict__ s_col,
-                                                                 const double *__restrict__ s_val, int *__restrict__ pk_col, double *__restrict__ pk_val) {
-    const int lane = threadIdx.x & 63;
-    const int waves = blockDim.x >> 6;
-    for (int64_t slice = (int64_t)blockIdx.x * waves + (threadIdx.x >> 6); slice < Pc.n_slices; slice += (int64_t)gridDim.x * waves) {
-        const int64_t I = slice * 64 + lane;
-        const bool live = I < Pc.n;
-        const int len = live ? Pc.row_len[I] : 0;
-        const long long src = live ? slice_base[slice] + intra_off[I] : 0;
-        const int width = (int)((Pc.slice_ptr[slice + 1] - Pc.slice_ptr[slice]) >> 6);
-        int64_t off = pk_ptr[slice];
-        for (int q = 0; q < width; ++q) {
-            const bool in = q < len;
-            const unsigned long long m = __ballot(in);
-            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-            if (in) {
-                pk_col[off + rank] = s_col[src + q];
-                pk_val[off + rank] = s_val[src + q];
-            }
-            off += __popcll(m);
-        }
-    }
-}
-
 // ---- LDS x windows of the packed mirror (XWinDev, linalg.hpp): per block of 256 rows the ascending list of distinct
 // columns and, per packed entry, the 16-bit position of its column in that list.  One workgroup per block: the columns
 // set bits in an LDS bitmap over the block's column span, a prefix of the word population counts turns a bit into its
@@ -1646,7 +1659,19 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
     ORC_TRY(arena.alloc((size_t)std::max<int64_t>(padded, 1), &val));
     SellDev Pc;
     Pc.n = nc; Pc.ncols = nc; Pc.n_slices = n_slices; Pc.ragged = padded < 24 * nc ? 2 : 1; Pc.slice_ptr = slice_ptr; Pc.row_len = row_len; Pc.col = col; Pc.diag_pos = diag;
-    hipLaunchKernelGGL(galerkin_pack_k, dim3(grid_for(nc)), dim3(kBlock), 0, st, Pc, slice_base, intra_off, s_col, s_val, col, val, diag);
+    // Packed mirror + LDS x windows for the levels whose rows are long enough for a window to be re-used (measured at
+    // 10.24 M fine rows: 33 entries per row +2 %, 70 entries per row +17 % against the padded product; 15 entries per row
+    // -10 %, so that level keeps the padded image).  ORC_SPMV_XWIN_MIN_NNZ < 0 switches the mirror off.
+    static const int xwin_min = getenv("ORC_SPMV_XWIN_MIN_NNZ") ? atoi(getenv("ORC_SPMV_XWIN_MIN_NNZ")) : 24;
+    const bool mirror = xwin_min >= 0 && packed_total > 0 && packed_total >= (int64_t)xwin_min * nc;
+    int *pk_col = nullptr;
+    double *pk_val = nullptr;
+    if (mirror) {
+        ORC_TRY(arena.alloc((size_t)packed_total, &pk_col));
+        ORC_TRY(arena.alloc((size_t)packed_total, &pk_val));
+    }
+    hipLaunchKernelGGL(galerkin_pack_fused_k, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(n_slices, 256 * 12))), dim3(64), 0, st, Pc, slice_base, intra_off,
+                       s_col, s_val, col, val, diag, mirror ? (const int64_t *)pk_ptr : (const int64_t *)nullptr, pk_col, pk_val);
     ORC_HIP(hipGetLastError());
     lap("galerkin pack");
     L.P = Pc; L.val = val; L.n = nc; L.padded = padded;
@@ -1655,18 +1680,7 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
     L.rows = RowsDev();
     static const bool rows_enabled = !(getenv("ORC_AMG_ROWS_MIRROR") && atoi(getenv("ORC_AMG_ROWS_MIRROR")) == 0);
     if (rows_enabled) { L.rows.slice_base = slice_base; L.rows.intra_off = intra_off; L.rows.col = s_col; L.rows.val = s_val; }
-    // Packed mirror + LDS x windows for the levels whose rows are long enough for a window to be re-used (measured at
-    // 10.24 M fine rows: 33 entries per row +2 %, 70 entries per row +17 % against the padded product; 15 entries per row
-    // -10 %, so that level keeps the padded image).  ORC_SPMV_XWIN_MIN_NNZ < 0 switches the mirror off.
-    static const int xwin_min = getenv("ORC_SPMV_XWIN_MIN_NNZ") ? atoi(getenv("ORC_SPMV_XWIN_MIN_NNZ")) : 24;
-    if (xwin_min >= 0 && packed_total > 0 && packed_total >= (int64_t)xwin_min * nc) {
-        int *pk_col;
-        double *pk_val;
-        ORC_TRY(arena.alloc((size_t)packed_total, &pk_col));
-        ORC_TRY(arena.alloc((size_t)packed_total, &pk_val));
-        const int gp = (int)std::min<int64_t>(((int64_t)n_slices + 3) / 4, kMaxGrid);
-        hipLaunchKernelGGL(galerkin_pack_packed_k, dim3(std::max(gp, 1)), dim3(kBlock), 0, st, Pc, pk_ptr, slice_base, intra_off, s_col, s_val, pk_col, pk_val);
-        ORC_HIP(hipGetLastError());
+    if (mirror) {
         L.pk.ptr = pk_ptr; L.pk.col = pk_col; L.pk.val = pk_val;
         const int64_t n_blocks = ((int64_t)n_slices + 3) / 4;
         int *wcol, *wsize;
