@@ -287,7 +287,7 @@ def main():
                 "hbm_used_gb": round(hbm_used_gb, 1),
             },
             "roofline": {
-                "kernel": "spmv_k<EpiStore, kSpmvPlain> (CSR/SELL-64 SpMV inside BiCGSTAB, a_u of the momentum system)",
+                "kernel": "spmv_uniform_k<EpiStore, false> (SELL-64 SpMV inside BiCGSTAB, a_u of the momentum system)",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
