@@ -269,6 +269,9 @@ int orc_bench_amg_levels(OrcSolver *s, int reps, int64_t *rows, int64_t *nnz, in
  * 2 = padded with predicated padding, 3 = packed where a mirror exists, 4/5 = packed/padded WITHOUT the x gathers —
  * wrong results, times the matrix stream alone). */
 int orc_debug_set_spmv_variant(int variant);
+/* Test hook: how many level-0 products of partitioned operators this thread has run in the overlapped form (interior rows
+ * on a second stream beside the halo exchange, rows along the cuts after it) since orc_init. */
+long long orc_debug_halo_overlaps(void);
 /* kernel-level timers accumulated inside orc_solver_iterate when enabled: name/ms pairs */
 int orc_profile_enable(int on);
 int orc_profile_report(char *buf, int64_t buf_len);

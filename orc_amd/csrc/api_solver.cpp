@@ -77,6 +77,25 @@ OrcMesh *orc_mesh_create_partitioned(int64_t n_owned, int64_t n_cells, int64_t n
                 H.recv_off.push_back(recv_ptr[q]); H.recv_cnt.push_back(recv_ptr[q + 1] - recv_ptr[q]);
             }
             if (st == ORC_OK) st = H.send_idx.upload(idx.data(), idx.size());
+            if (st == ORC_OK) {  // the longest run of 64-row slices whose rows have no ghost neighbour
+                const int64_t n_slices = (n_owned + 63) / 64;
+                std::vector<unsigned char> touches((size_t)n_slices, 0);
+                for (int64_t f = 0; f < n_faces; ++f) {
+                    const int64_t a = face_c0[f], b = face_c1[f];
+                    if (b < 0) continue;
+                    if (a < n_owned && b >= n_owned) touches[(size_t)(a >> 6)] = 1;
+                    if (b < n_owned && a >= n_owned) touches[(size_t)(b >> 6)] = 1;
+                }
+                int64_t best_lo = 0, best_len = 0, run_lo = 0;
+                for (int64_t sl = 0; sl <= n_slices; ++sl) {
+                    if (sl == n_slices || touches[(size_t)sl]) {
+                        if (sl - run_lo > best_len) { best_len = sl - run_lo; best_lo = run_lo; }
+                        run_lo = sl + 1;
+                    }
+                }
+                H.interior_lo = (int32_t)best_lo;
+                H.interior_hi = (int32_t)(best_lo + best_len);
+            }
         }
         if (st != ORC_OK) { delete m; m = nullptr; }
     }

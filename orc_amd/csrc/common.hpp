@@ -28,6 +28,7 @@ struct Ctx {
     bool breakdown_guard = true;  // OrcSettings.breakdown_guard of the running solve
     int reduction_order = 0;      // OrcReductionOrder of the running solve: 0 = wave trees, 1 = the reference's (nalgebra) association
     int spmv_variant = 0;         // orc_debug_set_spmv_variant (measurement only)
+    long long halo_overlaps = 0;  // level-0 products that ran beside their halo exchange (orc_debug_halo_overlaps)
     int *guard_events = nullptr;  // device counter: BiCGSTAB solves in which the breakdown guard fired (orc_breakdown_guard_events)
     // multi-GPU (comm.cpp)
     int rank = 0, world = 1;

@@ -20,6 +20,11 @@ struct HaloPlan {
     DevBuf<double> send_buf;   // [k * n_send]
     DevBuf<double> recv_buf;   // [k * n_ghost] staging for multi-field exchanges
     std::vector<double> h_send, h_recv;  // debug transport
+    // Slices [interior_lo, interior_hi) of the mesh pattern hold no row with a ghost column (the longest such run: after a
+    // slab cut or a contiguous-block partition the rows along the cuts sit at the ends of the owned range).  A level-0
+    // product runs them on `aux_stream` while the exchange travels on the library stream.
+    int32_t interior_lo = 0, interior_hi = 0;
+    void *aux_stream = nullptr, *ev_ready = nullptr, *ev_done = nullptr;  // hipStream_t / hipEvent_t, created on first use
     bool active() const { return !peers.empty(); }
     // exchange the ghost entries of k vectors (each n_own + n_ghost long) in one grouped launch
     int exchange(double *const *xs, int k);

@@ -272,6 +272,44 @@ static int launch_spmv(const MatView &A, const double *x, const Epi &epi, double
         if (gb >= 8) gb = (gb / 8) * 8;
         g = (int)std::max<int64_t>(gb, 1);
     }
+    static const bool ragged_on = !(getenv("ORC_SPMV_RAGGED") && atoi(getenv("ORC_SPMV_RAGGED")) == 0);
+    const char *ov_env = A.halo ? getenv("ORC_HALO_OVERLAP") : nullptr;  // read per product: tests compare the two forms in one process
+    const bool overlap_on = !(ov_env && atoi(ov_env) == 0);
+    // Partitioned level-0 operator: the rows without a ghost column (a contiguous run of slices, HaloPlan::interior_*) are
+    // multiplied on a second stream while the exchange travels; the rows along the cuts follow it on the library stream.
+    HaloPlan *H = A.halo;
+    const bool uniform_kernel = variant == 0 && !A.pk.ptr && !(ragged_on && A.P.ragged == 1);
+    if (H && overlap_on && uniform_kernel && A.slice_hi < 0 && ctx().world > 1 && g >= 64 &&
+        (int64_t)(H->interior_hi - H->interior_lo) * 2 >= (int64_t)A.P.n_slices) {
+        const int g_b = std::max(8, (g / 8 / 8) * 8), g_i = std::max(8, ((g - 2 * g_b) / 8) * 8);
+        const int total = g_i + 2 * g_b;
+        if (grid_out) *grid_out = total;
+        if (!H->aux_stream) {
+            hipStream_t st2;
+            hipEvent_t e1, e2;
+            ORC_HIP(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
+            ORC_HIP(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+            ORC_HIP(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+            H->aux_stream = st2; H->ev_ready = e1; H->ev_done = e2;
+        }
+        hipStream_t lib = ctx().stream, aux = (hipStream_t)H->aux_stream;
+        ORC_HIP(hipEventRecord((hipEvent_t)H->ev_ready, lib));  // x and whatever the epilogue reads are complete
+        ORC_HIP(hipStreamWaitEvent(aux, (hipEvent_t)H->ev_ready, 0));
+        MatView V = A;
+        V.part_stride = total;
+        V.slice_lo = H->interior_lo; V.slice_hi = H->interior_hi; V.part_base = 0;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_uniform_k<Epi, false>), dim3(g_i), dim3(kBlock), 0, aux, V, x, epi, partials, skip_flags);
+        ORC_HIP(hipEventRecord((hipEvent_t)H->ev_done, aux));
+        ORC_TRY(H->exchange(const_cast<double *>(x)));  // C1 on the library stream (every RCCL call stays there)
+        V.slice_lo = 0; V.slice_hi = H->interior_lo; V.part_base = g_i;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_uniform_k<Epi, false>), dim3(g_b), dim3(kBlock), 0, lib, V, x, epi, partials, skip_flags);
+        V.slice_lo = H->interior_hi; V.slice_hi = A.P.n_slices; V.part_base = g_i + g_b;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_uniform_k<Epi, false>), dim3(g_b), dim3(kBlock), 0, lib, V, x, epi, partials, skip_flags);
+        ORC_HIP(hipStreamWaitEvent(lib, (hipEvent_t)H->ev_done, 0));
+        ORC_HIP(hipGetLastError());
+        ctx().halo_overlaps += 1;
+        return ORC_OK;
+    }
     if (grid_out) *grid_out = g;
     if (A.P.n == 0) return ORC_OK;
     if (A.halo) ORC_TRY(A.halo->exchange(const_cast<double *>(x)));  // C1: refresh the ghost entries of x

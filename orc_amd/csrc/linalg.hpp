@@ -76,6 +76,10 @@ struct MatView {
     bool persistent_pattern = false;  // the pattern outlives the solve (mesh pattern): derived data such as a colouring may be cached
     HaloPlan *halo = nullptr;  // partitioned level-0 operator: x's ghost entries are refreshed before every product,
                                // reductions are summed over ranks; coarse AMG levels are per-rank (halo == nullptr)
+    // A product restricted to the slices [slice_lo, slice_hi) (slice_hi < 0: all of them) whose partial sums go to
+    // partials[q * part_stride + part_base + blockIdx.x] (part_stride 0: the grid size): the pieces of a product that
+    // overlaps its halo exchange (launch_spmv) are folded together by one reduce_partials.
+    int32_t slice_lo = 0, slice_hi = -1, part_stride = 0, part_base = 0;
 };
 
 // Owning pattern (built on the host from CSR, e.g. the mesh pattern or a user matrix).

@@ -17,20 +17,20 @@ __device__ __forceinline__ double view_value(const MatView &A, int64_t row, int6
 // of being fetched by all eight.  Pure speed: any placement gives the same result.
 struct SliceWalk {
     int64_t begin, end, step;
-    __device__ __forceinline__ SliceWalk(int32_t n_slices) {
+    __device__ __forceinline__ SliceWalk(int32_t n_slices, int32_t first = 0) {  // slices [first, n_slices)
         const int waves = blockDim.x >> 6;
         const int wave = threadIdx.x >> 6;
         if ((gridDim.x & 7) == 0 && gridDim.x >= 8) {
             const int xcd = blockIdx.x & 7, bl = blockIdx.x >> 3, nb = gridDim.x >> 3;
-            const int64_t spx = ((int64_t)n_slices + 7) / 8;
-            const int64_t lo = (int64_t)xcd * spx;
+            const int64_t spx = ((int64_t)(n_slices - first) + 7) / 8;
+            const int64_t lo = (int64_t)first + (int64_t)xcd * spx;
             int64_t hi = lo + spx;
             if (hi > n_slices) hi = n_slices;
             begin = lo + (int64_t)bl * waves + wave;
             end = hi;
             step = (int64_t)nb * waves;
         } else {
-            begin = (int64_t)blockIdx.x * waves + wave;
+            begin = (int64_t)first + (int64_t)blockIdx.x * waves + wave;
             end = n_slices;
             step = (int64_t)gridDim.x * waves;
         }
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(kBlock) void spmv_uniform_k(MatView A, const double
     if (skip_flags && (skip_flags[0] != 0. || skip_flags[1] != 0.)) return;
     const int lane = threadIdx.x & 63;
     double r0 = 0., r1 = 0.;
-    SliceWalk w(A.P.n_slices);
+    SliceWalk w(A.slice_hi >= 0 ? A.slice_hi : A.P.n_slices, A.slice_lo);
     for (int64_t slice = w.begin; slice < w.end; slice += w.step) {
         const int64_t row = slice * 64 + lane;
         const int64_t base = A.P.slice_ptr[slice];
@@ -185,13 +185,14 @@ __global__ __launch_bounds__(kBlock) void spmv_uniform_k(MatView A, const double
         }
         if (live) epi.apply(row, acc, r0, r1);
     }
+    const int pstride = A.part_stride > 0 ? A.part_stride : (int)gridDim.x;
     if (Epi::kReductions > 0) {
         double t = block_sum(r0, lds);
-        if (threadIdx.x == 0) partials[blockIdx.x] = t;
+        if (threadIdx.x == 0) partials[A.part_base + blockIdx.x] = t;
     }
     if (Epi::kReductions > 1) {
         double t = block_sum(r1, lds);
-        if (threadIdx.x == 0) partials[gridDim.x + blockIdx.x] = t;
+        if (threadIdx.x == 0) partials[pstride + A.part_base + blockIdx.x] = t;
     }
 }
 

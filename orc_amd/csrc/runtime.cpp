@@ -184,6 +184,8 @@ int orc_debug_set_spmv_variant(int variant) {
     return ORC_OK;
 }
 
+long long orc_debug_halo_overlaps(void) { return orc::ctx().halo_overlaps; }
+
 int orc_profile_enable(int on) {
     orc::ctx().profile = on != 0;
     return ORC_OK;

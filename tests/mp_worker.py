@@ -110,6 +110,15 @@ def main():
             print("MP_WORKER_OK" if t.item() == 1.0 else "MP_WORKER_FAIL", flush=True)
         dist.destroy_process_group()
         return
+    if mode == "gpu_overlap":
+        ok = gpu_overlap_checks(rank, world)
+        t = torch.tensor([1.0 if ok else 0.0])
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        dist.barrier()
+        if rank == 0:
+            print("MP_WORKER_OK" if t.item() == 1.0 else "MP_WORKER_FAIL", flush=True)
+        dist.destroy_process_group()
+        return
     if mode == "cpu_general":
         ok = general_partition_checks(rank, world)
         t = torch.tensor([1.0 if ok else 0.0])
@@ -218,6 +227,69 @@ def gpu_general_checks(rank, world):
             ok = ok and good
     parallel.finalize()
     return ok
+
+
+def gpu_overlap_checks(rank, world):
+    """Slabs large enough for the overlapped level-0 product (interior slices on a second stream beside the halo exchange,
+    the slices along the cut after it): BiCGSTAB and the Multigrid arm against the single-rank run, and the hook that says
+    the overlapped form really ran."""
+    import ctypes
+    import orc_amd
+    from orc_amd._lib import lib
+    from orc_amd.mesh import Mesh
+    from orc_amd.settings import NumericalSettings
+    from orc_amd.solver import Solver
+    orc_amd.init(0)
+    parallel.init_host_transport(dist, rank, world)
+    nx, ny, nzl = 40, 26, 16  # 16640 owned cells = 260 slices per rank, 17 of them along a cut
+    a, halo, gids = parallel.slab_arrays(nx, ny, nzl, rank, world)
+    ag = hex_channel(nx, ny, nzl * world)
+    set_channel_bcs(a)
+    set_channel_bcs(ag)
+    ug = global_fields(ag)
+    n_own = halo["n_owned"]
+    L = lib()
+    L.orc_debug_halo_overlaps.restype = ctypes.c_longlong
+    good_all = True
+    # against the single-rank run the iterates differ by association (rows along the cut add their ghost column last) and,
+    # for Multigrid, by the per-rank coarse levels; against the SAME partitioned run without the overlap only the layout of
+    # the partial sums differs
+    # (the reference's BiCGSTAB amplifies a last-bit difference of rho = sum(r) quickly — tests/test_oracle_sensitivity.py —
+    # so the sharp comparison is the one-iteration run: a wrong or stale row would show at O(1) there)
+    for name, kw, its, tol, tol_same in (("bicgstab-1", dict(momentum=5, solver_type=3, iterations=1), 1, 1e-12, 1e-13),
+                                         ("multigrid-1", dict(momentum=1, solver_type=2, iterations=1), 1, 10.0, 1e-11),  # one smoother iteration: the per-rank hierarchy is a different method
+                                         ("bicgstab", dict(momentum=5, solver_type=3, iterations=8), 2, 1e-7, 1e-7),
+                                         ("multigrid", dict(momentum=1, solver_type=2, iterations=20), 2, 0.5, 0.05)):
+        s = NumericalSettings.default(**kw)
+        runs = {}
+        for form in ("overlapped", "plain"):
+            if form == "plain":
+                os.environ["ORC_HALO_OVERLAP"] = "0"
+            try:
+                before = L.orc_debug_halo_overlaps()
+                pm = parallel.PartitionedMesh(a, halo)
+                sol = Solver(pm, s, 1000.0, 1e-3)
+                sol.set_fields(*[f[gids] for f in ug])
+                st = sol.iterate(its, raise_on_error=False)
+                runs[form] = (st, sol.get_fields(), L.orc_debug_halo_overlaps() - before)
+            finally:
+                os.environ.pop("ORC_HALO_OVERLAP", None)
+        st, loc, overlapped = runs["overlapped"]
+        st_p, loc_p, overlapped_p = runs["plain"]
+        gm = Mesh(ag)
+        ref = Solver(gm, s, 1000.0, 1e-3)
+        ref.set_fields(*ug)
+        st_ref = ref.iterate(its, raise_on_error=False)
+        glob = ref.get_fields()
+        err = max(np.linalg.norm(l[:n_own] - g[gids[:n_own]]) / max(np.linalg.norm(g), 1e-300) for l, g in zip(loc, glob))
+        same = max(np.linalg.norm(l[:n_own] - q[:n_own]) / max(np.linalg.norm(q[:n_own]), 1e-300) for l, q in zip(loc, loc_p))
+        good = (st == st_p == st_ref == 0) and err <= tol and same <= tol_same and overlapped > 0 and overlapped_p == 0 and all(np.isfinite(f).all() for f in loc)
+        if rank == 0:
+            print("  %-10s status %d/%d/%d  overlapped products %d (plain run %d)  vs plain partitioned run %.3e  vs single rank %.3e  %s"
+                  % (name, st, st_p, st_ref, overlapped, overlapped_p, same, err, "ok" if good else "FAIL"), flush=True)
+        good_all = good_all and good
+    parallel.finalize()
+    return good_all
 
 
 def gpu_checks(rank, world, a, halo, gids, ag):

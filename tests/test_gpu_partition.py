@@ -20,6 +20,15 @@ def test_general_partitioner_two_ranks_match_single_rank(gpu):
     assert "MP_WORKER_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-4000:]
 
 
+def test_overlapped_level0_product_two_ranks(gpu):
+    """Slabs of 260 slices per rank: the level-0 products run their interior slices beside the halo exchange; fields against
+    the same partitioned run without the overlap (1e-11 / 1e-8: only the layout of the partial sums differs), against the
+    single-rank run, and the overlap counter > 0."""
+    r = launch(2, "gpu_overlap", timeout=900)
+    print(r.stdout[-1500:])
+    assert "MP_WORKER_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-4000:]
+
+
 def test_rccl_selftest_single_rank(gpu):
     """The RCCL branch of HaloPlan::exchange / all-reduce / status agreement on one GPU: a single-rank communicator
     with rank 0 as its own neighbour.  (Two real ranks need two GPUs: the driver's scaling run.)"""
