@@ -1109,6 +1109,8 @@ static int solve_field_on(SolverState &s, DevBuf<double> &a, DevBuf<double> &b, 
     A.halo = s.mesh->halo.active() ? &s.mesh->halo : nullptr;
     A.persistent_pattern = true;
     const OrcSettings &t = s.settings;
+    if (arena.empty()) ORC_TRY(arena.reset());  // nothing of the previous solve is alive: a fragmented reservation is folded into one chunk
+    if (side_arena && side_arena->empty()) ORC_TRY(side_arena->reset());
     ctx().breakdown_guard = t.breakdown_guard != 0;
     ctx().reduction_order = t.reduction_order;
     stats.cache = &s.amg_cache[eq];
@@ -1162,7 +1164,7 @@ static int prepare_p_hierarchy(SolverState &s) {
     A.symmetric = m.pat.symmetric;
     A.halo = m.halo.active() ? &m.halo : nullptr;  // level 1 pairs owned rows only; nothing is exchanged
     A.persistent_pattern = true;
-    s.hier_arena.release(Arena::Mark{0, 0});
+    ORC_TRY(s.hier_arena.reset());
     ORC_TRY(multigrid_prepare_dev(A, s.settings.preconditioner, s.hier_arena, s.p_hierarchy));
     ORC_HIP(hipStreamSynchronize(st));
     return ORC_OK;
@@ -1438,6 +1440,7 @@ int solver_iterate(SolverState &s, uint64_t iterations, double *report) {
     const int64_t n = s.n;
     for (uint64_t it = 0; it < iterations; ++it) {
         double peclet[3] = {0., 0., 0.};
+        if (s.arena.empty()) ORC_TRY(s.arena.reset());  // between iterations nothing in the solver's own arena is alive
         if (H.active()) { double *f[4] = {s.u.p, s.v.p, s.w.p, s.p.p}; ORC_TRY(H.exchange(f, 4)); }
         ORC_TRY(k_gradients(s, tvd));
         if (H.active()) { double *g3[3] = {s.gp.p, s.gp.p + n, s.gp.p + 2 * n}; ORC_TRY(H.exchange(g3, 3)); }

@@ -73,6 +73,8 @@ __global__ void halo_pack_k(const double *__restrict__ x, const int32_t *__restr
 }
 
 // C1: neighbour halo exchange of k fields.
+bool comm_host_transport_active() { return g_host_ex != nullptr; }
+
 int HaloPlan::exchange(double *const *xs, int k) {
     Ctx &c = ctx();
     if (!active() || c.world <= 1) return ORC_OK;

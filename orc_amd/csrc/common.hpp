@@ -110,6 +110,12 @@ class Arena {
     struct Mark { size_t chunk, off; };
     Mark mark() const { return {cur_, off_}; }
     void release(Mark m) { cur_ = m.chunk; off_ = m.off; }
+    // Everything the arena holds is dead (no stream reads it any more): unwind to empty and, when the reservation has
+    // become fragmented (several chunks, or far more than was ever in use at once), replace it by ONE chunk of the
+    // high-water size.  hipFree synchronises the device, so this happens in the first iterations only: once one chunk
+    // holds a whole iteration nothing is freed or allocated again.
+    int reset();
+    bool empty() const { return cur_ == 0 && off_ == 0; }
     int alloc_bytes(size_t bytes, void **out);
     template <class T>
     int alloc(size_t count, T **out) { return alloc_bytes(count * sizeof(T), (void **)out); }
@@ -119,6 +125,7 @@ class Arena {
     struct Chunk { char *p; size_t size; };
     std::vector<Chunk> chunks_;
     size_t cur_ = 0, off_ = 0;
+    size_t high_ = 0;  // most bytes in use at once, counting the skipped tails of earlier chunks as used
 };
 
 // Unwinds an arena to where it stood when the scope was entered, on EVERY exit path (ORC_TRY / ORC_HIP return early).

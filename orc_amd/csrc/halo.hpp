@@ -37,5 +37,6 @@ int comm_allreduce_max(double *dev, int n);
 // collective: max over ranks of a host-side OrcStatus (no-op on a single rank).
 int comm_global_status(int status);
 void comm_set_host_transport(HostExchangeFn ex, HostAllreduceFn ar, void *user);
+bool comm_host_transport_active();  // the debug transport blocks the calling thread inside exchange()
 
 }  // namespace orc

@@ -298,9 +298,13 @@ static int launch_spmv(const MatView &A, const double *x, const Epi &epi, double
         MatView V = A;
         V.part_stride = total;
         V.slice_lo = H->interior_lo; V.slice_hi = H->interior_hi; V.part_base = 0;
+        // RCCL: the exchange is queued first, so that its kernels are resident before the interior product fills the CUs.
+        // The debug transport blocks this thread inside exchange(): there the interior product is launched first.
+        const bool exchange_first = !comm_host_transport_active();
+        if (exchange_first) ORC_TRY(H->exchange(const_cast<double *>(x)));  // C1 on the library stream (every RCCL call stays there)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_uniform_k<Epi, false>), dim3(g_i), dim3(kBlock), 0, aux, V, x, epi, partials, skip_flags);
         ORC_HIP(hipEventRecord((hipEvent_t)H->ev_done, aux));
-        ORC_TRY(H->exchange(const_cast<double *>(x)));  // C1 on the library stream (every RCCL call stays there)
+        if (!exchange_first) ORC_TRY(H->exchange(const_cast<double *>(x)));
         V.slice_lo = 0; V.slice_hi = H->interior_lo; V.part_base = g_i;
         hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_uniform_k<Epi, false>), dim3(g_b), dim3(kBlock), 0, lib, V, x, epi, partials, skip_flags);
         V.slice_lo = H->interior_hi; V.slice_hi = A.P.n_slices; V.part_base = g_i + g_b;

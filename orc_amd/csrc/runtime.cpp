@@ -32,14 +32,34 @@ int ensure_init() {
 }
 
 Arena::~Arena() {
+    static const bool trace = getenv("ORC_ARENA_TRACE") != nullptr;
+    if (trace && !chunks_.empty())
+        fprintf(stderr, "[orc arena %p] %zu chunk(s), reserved %.2f GB, high water %.2f GB\n", (void *)this, chunks_.size(), (double)reserved() / 1e9, (double)high_ / 1e9);
     for (auto &c : chunks_)
         if (c.p) (void)hipFree(c.p);
 }
 
-size_t Arena::reserved() const {
-    size_t t = 0;
-    for (auto &c : chunks_) t += c.size;
-    return t;
+int Arena::reset() {
+    cur_ = 0;
+    off_ = 0;
+    static const bool compact = !(getenv("ORC_ARENA_COMPACT") && atoi(getenv("ORC_ARENA_COMPACT")) == 0);
+    const size_t used = high_;  // the cycle that just ended
+    high_ = 0;
+    if (!compact || chunks_.empty() || used == 0) return ORC_OK;
+    const size_t want = used + used / 16 + ((size_t)16 << 20);  // what the cycle needed, plus slack for the next one's drift
+    // one chunk that is not grossly oversized stays (hysteresis: cycles of slightly different sizes must not free and
+    // allocate every time — hipFree synchronises the device)
+    if (chunks_.size() == 1 && chunks_[0].size <= want + want / 2) return ORC_OK;
+    static const bool trace = getenv("ORC_ARENA_TRACE") != nullptr;
+    if (trace) fprintf(stderr, "[orc arena %p] compacting %zu chunk(s), reserved %.2f GB -> %.2f GB\n", (void *)this, chunks_.size(), (double)reserved() / 1e9, (double)want / 1e9);
+    for (auto &c : chunks_)
+        if (c.p) (void)hipFree(c.p);
+    chunks_.clear();
+    Chunk c{nullptr, want};
+    hipError_t e = hipMalloc((void **)&c.p, want);
+    if (e != hipSuccess) return set_error(ORC_ERR_HIP, "arena hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    chunks_.push_back(c);
+    return ORC_OK;
 }
 
 int Arena::alloc_bytes(size_t bytes, void **out) {
@@ -51,6 +71,9 @@ int Arena::alloc_bytes(size_t bytes, void **out) {
             if (off_ + bytes <= c.size) {
                 *out = c.p + off_;
                 off_ += bytes;
+                size_t used = off_;
+                for (size_t q = 0; q < cur_; ++q) used += chunks_[q].size;
+                if (used > high_) high_ = used;
                 return ORC_OK;
             }
             // current chunk exhausted: move on (the tail stays unused until release())
