@@ -62,6 +62,12 @@ int Arena::reset() {
     return ORC_OK;
 }
 
+size_t Arena::reserved() const {
+    size_t t = 0;
+    for (auto &c : chunks_) t += c.size;
+    return t;
+}
+
 int Arena::alloc_bytes(size_t bytes, void **out) {
     bytes = (bytes + 255) & ~(size_t)255;
     if (bytes == 0) bytes = 256;
