@@ -304,7 +304,13 @@ static int launch_spmv(const MatView &A, const double *x, const Epi &epi, double
         if (exchange_first) ORC_TRY(H->exchange(const_cast<double *>(x)));  // C1 on the library stream (every RCCL call stays there)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_uniform_k<Epi, false>), dim3(g_i), dim3(kBlock), 0, aux, V, x, epi, partials, skip_flags);
         ORC_HIP(hipEventRecord((hipEvent_t)H->ev_done, aux));
-        if (!exchange_first) ORC_TRY(H->exchange(const_cast<double *>(x)));
+        if (!exchange_first) {
+            const int ex = H->exchange(const_cast<double *>(x));
+            if (ex != ORC_OK) {  // the interior product is in flight: the library stream must not run ahead of it
+                (void)hipStreamWaitEvent(lib, (hipEvent_t)H->ev_done, 0);
+                return ex;
+            }
+        }
         V.slice_lo = 0; V.slice_hi = H->interior_lo; V.part_base = g_i;
         hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_uniform_k<Epi, false>), dim3(g_b), dim3(kBlock), 0, lib, V, x, epi, partials, skip_flags);
         V.slice_lo = H->interior_hi; V.slice_hi = A.P.n_slices; V.part_base = g_i + g_b;
