@@ -1454,9 +1454,12 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
         const int kBatch = small_enabled ? big_batch : 16;  // four-kernel rounds per host round trip; a round past the fixed point is a no-op
         bool first = true, fin = false;
         TailCounters h;
-        static const int chase_enabled = getenv("ORC_AMG_CHASE") ? atoi(getenv("ORC_AMG_CHASE")) : 1;
-        static const int chase_steps = getenv("ORC_AMG_CHASE_STEPS") ? atoi(getenv("ORC_AMG_CHASE_STEPS")) : 4096;
-        static const int chase_grid = getenv("ORC_AMG_CHASE_GRID") ? atoi(getenv("ORC_AMG_CHASE_GRID")) : 2048;
+        // (read per call, not cached: the tests run one process through the lock-step-only form, a starved cascade phase
+        // that hands over to the lock-step rounds unfinished, and the default)
+        const int chase_enabled = getenv("ORC_AMG_CHASE") ? atoi(getenv("ORC_AMG_CHASE")) : 1;
+        const int chase_steps = getenv("ORC_AMG_CHASE_STEPS") ? atoi(getenv("ORC_AMG_CHASE_STEPS")) : 4096;
+        const int chase_grid = getenv("ORC_AMG_CHASE_GRID") ? atoi(getenv("ORC_AMG_CHASE_GRID")) : 2048;
+        const int chase_launches = getenv("ORC_AMG_CHASE_LAUNCHES") ? atoi(getenv("ORC_AMG_CHASE_LAUNCHES")) : 64;
         static const bool trace = getenv("ORC_AMG_TRACE") != nullptr;
         if (chase_enabled) {
             // one lock-step round over every row, the cascades it leaves followed asynchronously, then the lock-step rounds
@@ -1475,7 +1478,7 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
             hipLaunchKernelGGL(chase_convert_k, dim3(g), dim3(kBlock), 0, st, (const int *)taken_by, tb, ver, n);
             lap("first lock-step round");
             // lanes per cascade: the narrowest group that covers a typical row in one pass
-            static const int group_env = getenv("ORC_AMG_CHASE_GROUP") ? atoi(getenv("ORC_AMG_CHASE_GROUP")) : 0;
+            const int group_env = getenv("ORC_AMG_CHASE_GROUP") ? atoi(getenv("ORC_AMG_CHASE_GROUP")) : 0;
             int64_t stored = 0;  // padded entries: an upper bound of the mean row length is all that is needed
             ORC_HIP(hipMemcpyAsync(&stored, A.P.slice_ptr + A.P.n_slices, sizeof(int64_t), hipMemcpyDeviceToHost, st));
             ORC_HIP(hipStreamSynchronize(st));
@@ -1494,7 +1497,7 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
                 ORC_HIP(hipMemcpyAsync(&h, T, sizeof(h), hipMemcpyDeviceToHost, st));
                 ORC_HIP(hipStreamSynchronize(st));
                 if (first_list < 0) first_list = h.cur;
-                if (h.finished || h.cur == 0 || launches >= 64) break;
+                if (h.finished || h.cur == 0 || launches >= chase_launches) break;
             }
             rounds += h.rounds;
             lap("cascades");
@@ -1572,9 +1575,9 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
     ORC_TRY(arena.alloc((size_t)2, &counters));
     ORC_HIP(hipMemsetAsync(flags, 0, 4 * sizeof(int), st));
     ORC_HIP(hipMemsetAsync(counters, 0, 2 * sizeof(unsigned long long), st));
-    static const bool use_sort = getenv("ORC_GALERKIN_SORT") != nullptr && atoi(getenv("ORC_GALERKIN_SORT")) != 0;
+    const bool use_sort = getenv("ORC_GALERKIN_SORT") != nullptr && atoi(getenv("ORC_GALERKIN_SORT")) != 0;  // per call: tests compare the forms
     // lanes per coarse row by LDS tier (list capacity 64 << t); ORC_GALERKIN_GROUPS="g0,g1,..." overrides
-    static const std::array<int, kGalerkinTiers> tier_group = [] {
+    const std::array<int, kGalerkinTiers> tier_group = [] {
         std::array<int, kGalerkinTiers> g = {16, 16, 32, 64, 64, 64, 64};  // measured at 10.24 M fine rows (levels of 7 / 15 / 34 entries per row)
         if (const char *e = getenv("ORC_GALERKIN_GROUPS")) {
             int t = 0;

@@ -50,6 +50,32 @@ def test_aggregation_and_galerkin_bit_exact(gpu, oracle, shape):
     assert rounds >= 1
 
 
+@pytest.mark.parametrize("env", [{"ORC_AMG_CHASE": "0"}, {"ORC_AMG_CHASE_STEPS": "2", "ORC_AMG_CHASE_LAUNCHES": "2"},
+                                 {"ORC_AMG_CHASE_GROUP": "16"}, {"ORC_AMG_CHASE_GROUP": "64", "ORC_AMG_CHASE_GRID": "8"},
+                                 {"ORC_GALERKIN_SORT": "1"}, {"ORC_GALERKIN_GROUPS": "64,64,64,64"}, {"ORC_GALERKIN_GROUPS": "16,16,16,32"}])
+def test_set_up_forms_agree(gpu, monkeypatch, env):
+    """Every form of the set-up lands on the same pairing and the same coarse operator, bit for bit: lock-step rounds only;
+    a cascade phase cut off after two steps and two launches (the lock-step rounds finish the job); cascades followed by
+    16- and by 64-lane groups on a tiny grid; the Galerkin product by sorting and by merging with every group size."""
+    from orc_amd.linear_algebra import amg_coarsen
+    results = []
+    for form in ({}, env):
+        for k, v in form.items():
+            monkeypatch.setenv(k, v)
+        per_shape = []
+        for shape in ((33, 9, 4), (64, 40, 3), (40, 40, 12)):
+            partner, ac, rounds = amg_coarsen(fv_like_matrix(*shape))
+            _, ac2, _ = amg_coarsen(ac)  # a coarse level's rows (15 - 30 entries) through the set-up as well
+            per_shape.append((partner, ac, ac2))
+        results.append(per_shape)
+        for k in form:
+            monkeypatch.delenv(k)
+    for (p0, a0, b0), (p1, a1, b1) in zip(*results):
+        assert np.array_equal(p0, p1)
+        for x, y in ((a0, a1), (b0, b1)):
+            assert np.array_equal(x.indptr, y.indptr) and np.array_equal(x.indices, y.indices) and np.array_equal(x.data, y.data)
+
+
 def test_aggregation_dependency_chain(gpu, oracle):
     """1-D chain with monotone coefficients: every row's choice depends on its predecessor's, i.e. the
     longest possible dependency chain (n/2 rounds)."""
