@@ -210,6 +210,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # device memory in use by the timed run (before the measurement legs below build a hierarchy of their own)
+    import ctypes
+    free_b, total_b = ctypes.c_int64(0), ctypes.c_int64(0)
+    orc_amd._lib.check(orc_amd._lib.lib().orc_device_memory(ctypes.byref(free_b), ctypes.byref(total_b)))
+    hbm_used_gb = (total_b.value - free_b.value) / 1e9
+
     # dominant kernel: CSR(SELL-64) SpMV inside BiCGSTAB, timed live with HIP events on the library stream
     spmv_ms, _ = solver.bench_spmv(args.spmv_reps)
     n_local = getattr(mesh, "n_owned", mesh.n_cells)  # rows of this rank's matrices
@@ -234,10 +240,6 @@ def main():
                 for L in levels:
                     fh.write("%d,%d,%d,%d,%.4f,%.2f,%.0f,%.1f,%.4f\n" % (L["level"], L["rows"], L["nnz"], L["padded"], L["padded"] / max(L["nnz"], 1),
                                                                         L["us_per_product"], L["algorithmic_bytes"], L["GBs"], L["frac_of_peak"]))
-    import ctypes
-    free_b, total_b = ctypes.c_int64(0), ctypes.c_int64(0)
-    orc_amd._lib.check(orc_amd._lib.lib().orc_device_memory(ctypes.byref(free_b), ctypes.byref(total_b)))
-    hbm_used_gb = (total_b.value - free_b.value) / 1e9
     key = (args.nx, args.ny, args.nz, args.momentum, args.solver)
     workload_name = ("BASELINE configs[3]" if key == (400, 160, 160, "umist", "multigrid")
                      else "BASELINE configs[2]" if key == (512, 2016, 1, "quick", "bicgstab_gs") else "custom")
