@@ -441,22 +441,38 @@ __device__ __forceinline__ void chase_place(bool enq, int m, int gl, int &cont, 
 // Row i (running, owned by this wavefront) moved from column jj[0] to column jj[1] (-1: none).  Both columns are repaired
 // together, phase by phase, so that their memory round trips overlap — a cascade's speed is the number of dependent
 // round trips per step: versions + row geometry, column lists, the takers' choices, the two installs, the activations.
+// The geometry of the two rows (length, where their entries start) does not depend on the commit, so the caller loads it
+// BEFORE the commit and its round trip rides with the commit's; the version bumps then travel with the column lists.
+struct ChaseGeom {
+    int lj[2];
+    const int32_t *colp[2];
+    int64_t cbase[2], cstride[2];
+    __device__ __forceinline__ ChaseGeom(const MatView &A, const int (&jj)[2]) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            lj[t] = 0; colp[t] = nullptr; cbase[t] = 0; cstride[t] = 1;
+            if (jj[t] < 0) continue;
+            lj[t] = A.P.row_len[jj[t]];
+            const RowWalk W(A, jj[t]);
+            colp[t] = W.col; cbase[t] = W.base; cstride[t] = W.stride;
+        }
+    }
+};
+
 template <int G>
 __device__ __forceinline__ void chase_touch2(const MatView &A, const int *choice, unsigned long long *tb, int *ver, int *flag, const int (&jj)[2], int i,
-                                             int lane, int &cont, int *next_list, int *next_count) {
+                                             const ChaseGeom &geo, int lane, int &cont, int *next_list, int *next_count, int &was) {
     const int n = (int)A.P.n;
-    int lj[2] = {0, 0}, m0[2] = {-1, -1}, c0[2] = {-2, -2}, mn[2] = {0x7fffffff, 0x7fffffff};
+    int m0[2] = {-1, -1}, c0[2] = {-2, -2}, mn[2] = {0x7fffffff, 0x7fffffff};
     unsigned v[2] = {0u, 0u};
-    const int32_t *colp[2] = {nullptr, nullptr};
-    int64_t cbase[2] = {0, 0}, cstride[2] = {1, 1};
-    // ---- versions (after the commit) and row geometry
+    const int (&lj)[2] = geo.lj;
+    const int32_t *const (&colp)[2] = geo.colp;
+    const int64_t (&cbase)[2] = geo.cbase, (&cstride)[2] = geo.cstride;
+    // ---- versions (after the commit)
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         if (jj[t] < 0) continue;
         if (lane == 0) v[t] = (unsigned)__hip_atomic_fetch_add(ver + jj[t], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-        lj[t] = A.P.row_len[jj[t]];
-        const RowWalk W(A, jj[t]);
-        colp[t] = W.col; cbase[t] = W.base; cstride[t] = W.stride;
     }
     // ---- the rows holding each column (symmetric pattern: the columns of row j); first G entries kept in registers
 #pragma unroll
@@ -497,6 +513,13 @@ __device__ __forceinline__ void chase_touch2(const MatView &A, const int *choice
         prev_hi[t] = (unsigned)__shfl((int)prev_hi[t], 0, G);
     }
     chase_fence();  // installs before activations
+    // an earlier row holds the column this row has just committed to: evaluate this row again.  Then the row is released
+    // (running -> idle, or -> queued when somebody, or the line above, asked for it): the answer travels with the
+    // activations below, which concern other rows only.
+    if (lane == 0) {
+        if (jj[1] >= 0 && mn[1] < i) __hip_atomic_fetch_or(flag + i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        was = __hip_atomic_fetch_and(flag + i, ~2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     // ---- activate the rows that see a column differently now
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -520,9 +543,6 @@ __device__ __forceinline__ void chase_touch2(const MatView &A, const int *choice
             }
         }
     }
-    // an earlier row holds the column this row has just committed to: evaluate this row again (the owner sees bit 0
-    // when it is through with the row)
-    if (jj[1] >= 0 && mn[1] < i && lane == 0) __hip_atomic_fetch_or(flag + i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <int G>
@@ -570,15 +590,16 @@ __global__ __launch_bounds__(kBlock) void tail_chase_k(MatView A, int *choice, u
                 if (ob < best || (ob == best && ok < bk)) { best = ob; bk = ok; bj = oj; }
             }
             const int nv = bj;
-            int cont = -1;
+            int cont = -1, was = 0;
             if (nv != old) {
+                const int jj[2] = {old, nv};
+                const ChaseGeom geo(A, jj);  // in flight together with the commit
                 if (lane == 0) st_i(choice + i, nv);
                 chase_fence();  // commit before the version bumps
-                const int jj[2] = {old, nv};
-                chase_touch2<G>(A, choice, tb, ver, flag, jj, i, lane, cont, next, &T->next);
+                chase_touch2<G>(A, choice, tb, ver, flag, jj, i, geo, lane, cont, next, &T->next, was);
+            } else if (lane == 0) {
+                was = __hip_atomic_fetch_and(flag + i, ~2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // running -> idle, or -> queued
             }
-            int was = 0;
-            if (lane == 0) was = __hip_atomic_fetch_and(flag + i, ~2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // running -> idle, or -> queued
             was = __shfl(was, 0, G);
             if (was & 1) {  // somebody asked for this row while it ran
                 if (cont < 0) cont = i;
