@@ -75,6 +75,12 @@ __global__ void halo_pack_k(const double *__restrict__ x, const int32_t *__restr
 // C1: neighbour halo exchange of k fields.
 bool comm_host_transport_active() { return g_host_ex != nullptr; }
 
+HaloPlan::~HaloPlan() {
+    if (ev_ready) (void)hipEventDestroy((hipEvent_t)ev_ready);
+    if (ev_done) (void)hipEventDestroy((hipEvent_t)ev_done);
+    if (aux_stream) (void)hipStreamDestroy((hipStream_t)aux_stream);
+}
+
 int HaloPlan::exchange(double *const *xs, int k) {
     Ctx &c = ctx();
     if (!active() || c.world <= 1) return ORC_OK;

@@ -25,6 +25,10 @@ struct HaloPlan {
     // product runs them on `aux_stream` while the exchange travels on the library stream.
     int32_t interior_lo = 0, interior_hi = 0;
     void *aux_stream = nullptr, *ev_ready = nullptr, *ev_done = nullptr;  // hipStream_t / hipEvent_t, created on first use
+    ~HaloPlan();  // comm.cpp: the second stream and its events
+    HaloPlan() = default;
+    HaloPlan(const HaloPlan &) = delete;
+    HaloPlan &operator=(const HaloPlan &) = delete;
     bool active() const { return !peers.empty(); }
     // exchange the ghost entries of k vectors (each n_own + n_ghost long) in one grouped launch
     int exchange(double *const *xs, int k);
