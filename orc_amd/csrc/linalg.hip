@@ -38,6 +38,37 @@ int reduce_partials(const double *partials, int count, int nq, double *out, bool
     return ORC_OK;
 }
 
+// The same fold done by EVERY workgroup of the kernel that consumes the sum (256 threads): four passes over
+// reduce_partials_k's 16 virtual wavefronts, so the association — and therefore every bit — is that of the one-workgroup
+// kernel.  A BiCGSTAB iteration has three such sums; as separate one-workgroup launches they sit between the big kernels
+// of their stream and, when other streams fill the chip, wait for a slot each time (84 us on average in the concurrent
+// schedule against 4.8 us alone).  Returns the sum to every thread.
+__device__ __forceinline__ double fold_partials_block(const double *__restrict__ partials, int count, double *lds16 /* 16 doubles */) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;  // blockDim.x == 256
+    double a[4], b[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {  // virtual thread vt of 1024 adds partials[vt] and partials[vt + 1024] (count <= 2048)
+        const int vt = (w + 4 * p) * 64 + lane;
+        a[p] = vt < count ? partials[vt] : 0.;
+        b[p] = vt + 1024 < count ? partials[vt + 1024] : 0.;
+    }
+    __syncthreads();  // lds16 may still be read from a previous fold
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int vt = (w + 4 * p) * 64 + lane;
+        double v = 0.;
+        if (vt < count) v += a[p];
+        if (vt + 1024 < count) v += b[p];
+        v = wave_sum(v);
+        if (lane == 0) lds16[w + 4 * p] = v;
+    }
+    __syncthreads();
+    double r = 0.;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r += lds16[i];
+    return r;
+}
+
 // ------------------------------------------------------------------ reference-order reductions (verification mode)
 // OrcSettings.reduction_order = ORC_REDUCTION_REFERENCE: every dot product / norm of the solvers is evaluated in the
 // association of nalgebra 0.32.4's `dotx` (base/blas.rs): eight running accumulators
@@ -398,21 +429,37 @@ __device__ __forceinline__ bool bicg_frozen(const double *__restrict__ scal, int
 __device__ __forceinline__ bool finite_nonzero(double v) { return v != 0. && isfinite(v); }
 
 // s = r - alpha*nu, alpha = rho / (r_hat_0 . nu)                     (:257, :259)
-__global__ void bicg_s_k(double *__restrict__ scal, int rho_idx, const double *__restrict__ r, const double *__restrict__ nu,
-                         double *__restrict__ s, int64_t n, int guard) {
+// fold (null: scal[S_SUM_NU] is there already): the product's partial sums of nu, folded by every workgroup here
+__global__ __launch_bounds__(kBlock) void bicg_s_k(double *__restrict__ scal, int rho_idx, const double *__restrict__ r, const double *__restrict__ nu,
+                                                   double *__restrict__ s, int64_t n, int guard, const double *__restrict__ fold, int fold_count) {
+    __shared__ double lds16[16];
     if (bicg_frozen(scal, guard)) return;
-    const double alpha = scal[rho_idx] / scal[S_SUM_NU];
-    if (guard && !(finite_nonzero(scal[rho_idx]) && finite_nonzero(scal[S_SUM_NU]) && isfinite(alpha))) {
+    // 16-byte accesses: two consecutive elements per lane (arena vectors are 256-byte aligned).  The first pair of every
+    // thread is requested BEFORE the fold, so that its round trip and the fold's overlap.
+    const int64_t n2 = n >> 1, stride = (int64_t)gridDim.x * blockDim.x;
+    const double2 *r2 = reinterpret_cast<const double2 *>(r), *nu2 = reinterpret_cast<const double2 *>(nu);
+    double2 *s2 = reinterpret_cast<double2 *>(s);
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double2 a = make_double2(0., 0.), b = make_double2(0., 0.);
+    if (i < n2) { a = r2[i]; b = nu2[i]; }
+    double sum_nu;
+    if (fold) {
+        sum_nu = fold_partials_block(fold, fold_count, lds16);
+        if (blockIdx.x == 0 && threadIdx.x == 0) scal[S_SUM_NU] = sum_nu;  // the later kernels of the iteration read it
+    } else {
+        sum_nu = scal[S_SUM_NU];
+    }
+    const double alpha = scal[rho_idx] / sum_nu;
+    if (guard && !(finite_nonzero(scal[rho_idx]) && finite_nonzero(sum_nu) && isfinite(alpha))) {
         if (blockIdx.x == 0 && threadIdx.x == 0) scal[S_FROZEN] = 1.;
         return;
     }
-    // 16-byte accesses: two consecutive elements per lane (arena vectors are 256-byte aligned)
-    const int64_t n2 = n >> 1;
-    const double2 *r2 = reinterpret_cast<const double2 *>(r), *nu2 = reinterpret_cast<const double2 *>(nu);
-    double2 *s2 = reinterpret_cast<double2 *>(s);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (int64_t)gridDim.x * blockDim.x) {
-        const double2 a = r2[i], b = nu2[i];
+    while (i < n2) {
+        const int64_t nx = i + stride;
+        double2 an = make_double2(0., 0.), bn = make_double2(0., 0.);
+        if (nx < n2) { an = r2[nx]; bn = nu2[nx]; }
         s2[i] = make_double2(a.x - alpha * b.x, a.y - alpha * b.y);
+        a = an; b = bn; i = nx;
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) s[n - 1] = r[n - 1] - alpha * nu[n - 1];
 }
@@ -420,12 +467,28 @@ __global__ void bicg_s_k(double *__restrict__ scal, int rho_idx, const double *_
 __global__ __launch_bounds__(kBlock) void bicg_xr_k(double *__restrict__ scal, int rho_idx, double *__restrict__ x,
                                                     const double *__restrict__ p, const double *__restrict__ s,
                                                     const double *__restrict__ t, double *__restrict__ r, int64_t n,
-                                                    double *__restrict__ partials, int guard) {
+                                                    double *__restrict__ partials, int guard, const double *__restrict__ fold, int fold_count) {
     __shared__ double lds[8];
+    __shared__ double lds16[16];
     if (guard && scal[S_FROZEN] != 0.) return;
+    // the first pairs of every thread are requested before the folds (their round trips overlap)
+    const int64_t n2 = n >> 1, stride = (int64_t)gridDim.x * blockDim.x;
+    double2 *x2 = reinterpret_cast<double2 *>(x), *r2 = reinterpret_cast<double2 *>(r);
+    const double2 *p2 = reinterpret_cast<const double2 *>(p), *s2 = reinterpret_cast<const double2 *>(s), *t2 = reinterpret_cast<const double2 *>(t);
+    const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double2 xv = make_double2(0., 0.), pv = xv, sv = xv, tv = xv;
+    if (i0 < n2) { xv = x2[i0]; pv = p2[i0]; sv = s2[i0]; tv = t2[i0]; }
+    double ts, tt;
+    if (fold) {  // t.s and t.t from the product's two partial arrays (fold != partials: this kernel writes its own sums)
+        ts = fold_partials_block(fold, fold_count, lds16);
+        tt = fold_partials_block(fold + fold_count, fold_count, lds16);
+        if (blockIdx.x == 0 && threadIdx.x == 0) { scal[S_TS] = ts; scal[S_TT] = tt; }
+    } else {
+        ts = scal[S_TS]; tt = scal[S_TT];
+    }
     const double alpha = scal[rho_idx] / scal[S_SUM_NU];
-    double omega = scal[S_TS] / scal[S_TT];
-    const bool bad = guard && !(finite_nonzero(scal[S_TT]) && isfinite(omega));
+    double omega = ts / tt;
+    const bool bad = guard && !(finite_nonzero(tt) && isfinite(omega));
     double acc = 0.;
     if (bad) {
         // t = A s vanished (s is already the zero residual) or overflowed: take x = h, r = s and stop
@@ -437,17 +500,18 @@ __global__ __launch_bounds__(kBlock) void bicg_xr_k(double *__restrict__ scal, i
         }
         if (blockIdx.x == 0 && threadIdx.x == 0) scal[S_FROZEN2] = 1.;
     } else {
-        const int64_t n2 = n >> 1;
-        double2 *x2 = reinterpret_cast<double2 *>(x), *r2 = reinterpret_cast<double2 *>(r);
-        const double2 *p2 = reinterpret_cast<const double2 *>(p), *s2 = reinterpret_cast<const double2 *>(s), *t2 = reinterpret_cast<const double2 *>(t);
-        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (int64_t)gridDim.x * blockDim.x) {
-            const double2 xv = x2[i], pv = p2[i], sv = s2[i], tv = t2[i];
+        int64_t i = i0;
+        while (i < n2) {
+            const int64_t nx = i + stride;
+            double2 xn = make_double2(0., 0.), pn = xn, sn = xn, tn = xn;
+            if (nx < n2) { xn = x2[nx]; pn = p2[nx]; sn = s2[nx]; tn = t2[nx]; }
             const double h0 = xv.x + alpha * pv.x, h1 = xv.y + alpha * pv.y;
             x2[i] = make_double2(h0 + omega * sv.x, h1 + omega * sv.y);
             const double q0 = sv.x - omega * tv.x, q1 = sv.y - omega * tv.y;
             r2[i] = make_double2(q0, q1);
             acc += q0;
             acc += q1;
+            xv = xn; pv = pn; sv = sn; tv = tn; i = nx;
         }
         if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
             const int64_t i = n - 1;
@@ -463,10 +527,25 @@ __global__ __launch_bounds__(kBlock) void bicg_xr_k(double *__restrict__ scal, i
     if (threadIdx.x == 0) partials[blockIdx.x] = tsum;
 }
 // beta = rho/rho_prev * alpha/omega ; p = r + beta (p - omega nu)       (:266-267)
-__global__ void bicg_p_k(double *__restrict__ scal, int rho_prev_idx, int rho_idx, const double *__restrict__ r,
-                         const double *__restrict__ nu, double *__restrict__ p, int64_t n, int guard) {
+__global__ __launch_bounds__(kBlock) void bicg_p_k(double *__restrict__ scal, int rho_prev_idx, int rho_idx, const double *__restrict__ r,
+                                                   const double *__restrict__ nu, double *__restrict__ p, int64_t n, int guard,
+                                                   const double *__restrict__ fold, int fold_count) {
+    __shared__ double lds16[16];
     if (bicg_frozen(scal, guard)) return;
-    const double rho_prev = scal[rho_prev_idx], rho = scal[rho_idx];
+    const int64_t n2 = n >> 1, stride = (int64_t)gridDim.x * blockDim.x;
+    double2 *p2 = reinterpret_cast<double2 *>(p);
+    const double2 *r2 = reinterpret_cast<const double2 *>(r), *nu2 = reinterpret_cast<const double2 *>(nu);
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double2 rv = make_double2(0., 0.), pv = rv, nv = rv;
+    if (i < n2) { rv = r2[i]; pv = p2[i]; nv = nu2[i]; }  // requested before the fold
+    double rho;
+    if (fold) {  // rho = sum(r) from bicg_xr_k's partial sums
+        rho = fold_partials_block(fold, fold_count, lds16);
+        if (blockIdx.x == 0 && threadIdx.x == 0) scal[rho_idx] = rho;
+    } else {
+        rho = scal[rho_idx];
+    }
+    const double rho_prev = scal[rho_prev_idx];
     const double alpha = rho_prev / scal[S_SUM_NU];
     const double omega = scal[S_TS] / scal[S_TT];
     const double beta = rho / rho_prev * alpha / omega;
@@ -474,12 +553,12 @@ __global__ void bicg_p_k(double *__restrict__ scal, int rho_prev_idx, int rho_id
         if (blockIdx.x == 0 && threadIdx.x == 0) scal[S_FROZEN] = 1.;
         return;
     }
-    const int64_t n2 = n >> 1;
-    double2 *p2 = reinterpret_cast<double2 *>(p);
-    const double2 *r2 = reinterpret_cast<const double2 *>(r), *nu2 = reinterpret_cast<const double2 *>(nu);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (int64_t)gridDim.x * blockDim.x) {
-        const double2 rv = r2[i], pv = p2[i], nv = nu2[i];
+    while (i < n2) {
+        const int64_t nx = i + stride;
+        double2 rn = make_double2(0., 0.), pn = rn, nn = rn;
+        if (nx < n2) { rn = r2[nx]; pn = p2[nx]; nn = nu2[nx]; }
         p2[i] = make_double2(rv.x + beta * (pv.x - omega * nv.x), rv.y + beta * (pv.y - omega * nv.y));
+        rv = rn; pv = pn; nv = nn; i = nx;
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) p[n - 1] = r[n - 1] + beta * (p[n - 1] - omega * nu[n - 1]);
 }
@@ -491,7 +570,7 @@ __global__ void guard_event_k(const double *__restrict__ scal, int *__restrict__
 }
 
 struct BicgWork {
-    double *r, *p, *nu, *s, *t, *partials, *scal;
+    double *r, *p, *nu, *s, *t, *partials, *partials2, *scal;  // partials2: bicg_xr_k's sums while it still folds the product's
 };
 
 static int bicg_alloc(Arena &arena, int64_t n, BicgWork &w) {  // n = vector length incl. ghost entries
@@ -502,6 +581,7 @@ static int bicg_alloc(Arena &arena, int64_t n, BicgWork &w) {  // n = vector len
     ORC_TRY(arena.alloc(nn, &w.s));
     ORC_TRY(arena.alloc(nn, &w.t));
     ORC_TRY(arena.alloc((size_t)2 * kMaxPartials, &w.partials));
+    ORC_TRY(arena.alloc((size_t)kMaxPartials, &w.partials2));
     ORC_TRY(arena.alloc((size_t)S_COUNT, &w.scal));
     ORC_HIP(hipMemsetAsync(w.scal, 0, S_COUNT * sizeof(double), ctx().stream));
     return ORC_OK;
@@ -514,19 +594,27 @@ static int bicg_iteration(const MatView &A, double *x, const BicgWork &w, uint64
     const double *skip = guard ? w.scal + S_FROZEN : nullptr;  // frozen solves skip their SpMVs too
     int g = 0;
     const bool ref = reference_order(A);  // dot products in nalgebra's association (verification mode)
+    // Single GPU, tree reductions: the three sums of the iteration are folded by the kernels that consume them (every
+    // workgroup folds, workgroup 0 stores the scalar for the later kernels) instead of by one-workgroup launches in between.
+    static const bool fuse_env = !(getenv("ORC_BICG_FUSED_SUMS") && atoi(getenv("ORC_BICG_FUSED_SUMS")) == 0);
+    const bool fused = fuse_env && !ref && A.halo == nullptr;
     ORC_TRY(launch_spmv(A, w.p, EpiStoreSum{w.nu}, w.partials, &g, skip));     // nu = A p, sum(nu)
     if (ref) ORC_TRY(dot_reference(nullptr, w.nu, n, w.scal + S_SUM_NU, skip));            // r_hat_0 . nu  (:257)
-    else ORC_TRY(reduce_partials(w.partials, g, 1, w.scal + S_SUM_NU, A.halo != nullptr));
-    hipLaunchKernelGGL(bicg_s_k, dim3(vg), dim3(kBlock), 0, ctx().stream, w.scal, S_RHO0 + cur, w.r, w.nu, w.s, n, guard);
+    else if (!fused) ORC_TRY(reduce_partials(w.partials, g, 1, w.scal + S_SUM_NU, A.halo != nullptr));
+    hipLaunchKernelGGL(bicg_s_k, dim3(vg), dim3(kBlock), 0, ctx().stream, w.scal, S_RHO0 + cur, w.r, w.nu, w.s, n, guard,
+                       fused ? (const double *)w.partials : (const double *)nullptr, g);
     ORC_TRY(launch_spmv(A, w.s, EpiTs{w.s, w.t}, w.partials, &g, skip));       // t = A s, t.s, t.t
     if (ref) {
         ORC_TRY(dot_reference(w.t, w.s, n, w.scal + S_TS, skip));                          // t . s, t . t  (:261)
         ORC_TRY(dot_reference(w.t, w.t, n, w.scal + S_TT, skip));
-    } else ORC_TRY(reduce_partials(w.partials, g, 2, w.scal + S_TS, A.halo != nullptr));
-    hipLaunchKernelGGL(bicg_xr_k, dim3(vg), dim3(kBlock), 0, ctx().stream, w.scal, S_RHO0 + cur, x, w.p, w.s, w.t, w.r, n, w.partials, guard);
+    } else if (!fused) ORC_TRY(reduce_partials(w.partials, g, 2, w.scal + S_TS, A.halo != nullptr));
+    double *xr_partials = fused ? w.partials2 : w.partials;
+    hipLaunchKernelGGL(bicg_xr_k, dim3(vg), dim3(kBlock), 0, ctx().stream, w.scal, S_RHO0 + cur, x, w.p, w.s, w.t, w.r, n, xr_partials, guard,
+                       fused ? (const double *)w.partials : (const double *)nullptr, g);
     if (ref) ORC_TRY(dot_reference(nullptr, w.r, n, w.scal + S_RHO0 + nxt, skip));  // rho = r_hat_0 . r  (:265)
-    else ORC_TRY(reduce_partials(w.partials, vg, 1, w.scal + S_RHO0 + nxt, A.halo != nullptr));  // rho = r_hat_0 . r
-    hipLaunchKernelGGL(bicg_p_k, dim3(vg), dim3(kBlock), 0, ctx().stream, w.scal, S_RHO0 + cur, S_RHO0 + nxt, w.r, w.nu, w.p, n, guard);
+    else if (!fused) ORC_TRY(reduce_partials(w.partials, vg, 1, w.scal + S_RHO0 + nxt, A.halo != nullptr));  // rho = r_hat_0 . r
+    hipLaunchKernelGGL(bicg_p_k, dim3(vg), dim3(kBlock), 0, ctx().stream, w.scal, S_RHO0 + cur, S_RHO0 + nxt, w.r, w.nu, w.p, n, guard,
+                       fused ? (const double *)w.partials2 : (const double *)nullptr, vg);
     ORC_HIP(hipGetLastError());
     return ORC_OK;
 }
