@@ -1393,7 +1393,63 @@ struct CoarseLevel {
     int rounds = 0;
 };
 
-static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, int *rounds_out, const int *warm = nullptr) {
+// Is `choice` the fixed point?  Every row is evaluated against the exact first-taker table of `choice` itself; a state in
+// which no row would choose differently is the sequential greedy pairing (the fixed point is unique).  Thread per row:
+// coalesced reads of the interleaved image.  Counts the rows that would change.
+__global__ void agg_verify_k(MatView A, const int *__restrict__ choice, const int *__restrict__ taken_by, AggCounters *C) {
+    int bad = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < A.P.n; i += (int64_t)gridDim.x * blockDim.x)
+        if (agg_eval_row(A, taken_by, i, true) != choice[i]) ++bad;
+    if (bad) atomicAdd(&C->changed, bad);  // rare: a verified pairing has none
+}
+
+SiblingPairing::~SiblingPairing() {
+    for (auto &e : ready)
+        if (e) (void)hipEventDestroy(e);
+}
+void SiblingPairing::begin(bool leader_will_run) {
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto &p : published) p = false;
+    leader_done = !leader_will_run;
+}
+int SiblingPairing::publish(int level, const int *choice, int64_t rows, hipStream_t stream) {
+    if (level < 0 || level >= kLevels) return ORC_OK;
+    int st = ORC_OK;
+    if (buf[level].n < (size_t)std::max<int64_t>(rows, 1)) st = buf[level].alloc((size_t)std::max<int64_t>(rows, 1));
+    if (st == ORC_OK && !ready[level] && hipEventCreateWithFlags(&ready[level], hipEventDisableTiming) != hipSuccess) st = set_error(ORC_ERR_HIP, "hipEventCreate failed");
+    if (st == ORC_OK && rows > 0 && hipMemcpyAsync(buf[level].p, choice, sizeof(int) * (size_t)rows, hipMemcpyDeviceToDevice, stream) != hipSuccess)
+        st = set_error(ORC_ERR_HIP, "hipMemcpyAsync failed");
+    if (st == ORC_OK && hipEventRecord(ready[level], stream) != hipSuccess) st = set_error(ORC_ERR_HIP, "hipEventRecord failed");
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (st == ORC_OK) { n[level] = rows; published[level] = true; }
+        else leader_done = true;  // nobody waits for a level that will not come
+    }
+    cv.notify_all();
+    return st;
+}
+const int *SiblingPairing::wait(int level, int64_t rows, hipStream_t stream) {
+    if (level < 0 || level >= kLevels) return nullptr;
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [&] { return published[level] || leader_done; });
+    if (!published[level] || n[level] != rows) return nullptr;
+    if (hipStreamWaitEvent(stream, ready[level], 0) != hipSuccess) return nullptr;
+    return buf[level].p;
+}
+void SiblingPairing::finish() {
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        leader_done = true;
+    }
+    cv.notify_all();
+}
+
+// warm: a starting state for the fixed-point iteration (any state is valid).  warm_kind 1: last iteration's pairing of the
+// same equation (ORC_AMG_WARM, off); 2: a sibling system's pairing of THIS iteration, taken if it IS this matrix's fixed
+// point (agg_verify_k: one pass, nothing to iterate) and dropped otherwise — measured: a sibling's pairing that is off in
+// a few per cent of the rows is a worse start than the slice sweep's state (the cascades from it multiply instead of
+// running out: 60 M evaluations against 4 M), so there is no middle way.
+static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, int *rounds_out, const int *warm = nullptr, int warm_kind = 1) {
     const int64_t n = A.P.n;
     const int g = grid_for(n);
     const int gs = grid_for(A.P.n_slices, 64);  // one thread per slice, 64-thread workgroups spread the slices over the CUs
@@ -1407,6 +1463,27 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
     ORC_TRY(arena.alloc((size_t)64, &snap));
     hipStream_t st = ctx().stream;
     ORC_HIP(hipMemsetAsync(C, 0, sizeof(AggCounters), st));
+    if (warm && warm_kind == 2 && n > 0) {  // a sibling's pairing: this matrix's too?
+        AggCounters hc;
+        ORC_HIP(hipMemcpyAsync(choice, warm, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(agg_reset_k, dim3(g), dim3(kBlock), 0, st, taken_by, n);
+        hipLaunchKernelGGL(agg_scatter_k, dim3(g), dim3(kBlock), 0, st, (const int *)choice, taken_by, n);
+        hipLaunchKernelGGL(agg_verify_k, dim3(g), dim3(kBlock), 0, st, A, (const int *)choice, (const int *)taken_by, C);
+        ORC_HIP(hipGetLastError());
+        ORC_HIP(hipMemcpyAsync(&hc, C, sizeof(hc), hipMemcpyDeviceToHost, st));
+        ORC_HIP(hipStreamSynchronize(st));
+        static const bool trace_v = getenv("ORC_AMG_TRACE") != nullptr;
+        if (trace_v) fprintf(stderr, "[amg sibling n=%lld] rows that would change: %d\n", (long long)n, hc.changed);
+        if (hc.changed == 0) {
+            ORC_HIP(hipMemsetAsync(chooser, 0xff, sizeof(int) * (size_t)n, st));
+            hipLaunchKernelGGL(chooser_k, dim3(g), dim3(kBlock), 0, st, (const int *)choice, chooser, n);
+            ORC_HIP(hipGetLastError());
+            if (rounds_out) *rounds_out = 1;
+            return ORC_OK;
+        }
+        ORC_HIP(hipMemsetAsync(C, 0, sizeof(AggCounters), st));
+        warm = nullptr;  // not this matrix's pairing: from scratch
+    }
     hipLaunchKernelGGL(agg_init_k, dim3(g), dim3(kBlock), 0, st, A, choice, act_a, act_b);  // also resets the slice flags
     if (warm) ORC_HIP(hipMemcpyAsync(choice, warm, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, st));
     int rounds = 0;
@@ -1791,7 +1868,17 @@ static int multigrid_solve_dev(const MatView &A, const double *r, uint64_t level
         const int *warm = nullptr;
         static const bool warm_enabled = getenv("ORC_AMG_WARM") != nullptr && atoi(getenv("ORC_AMG_WARM")) != 0;
         if (warm_enabled && cache && level < 8 && cache->size[level] == n) warm = cache->choice[level].p;
-        ORC_TRY(aggregate(A, arena, choice, chooser, &L.rounds, warm));  // :80 (scratch is released with the level)
+        int warm_kind = 1;
+        SiblingPairing *sib = stats ? stats->sibling : nullptr;
+        if (sib && stats->sibling_role == 2 && level == 1) {  // the fine level only: there the systems share their pattern
+            if (const int *w = sib->wait((int)level, n, st)) { warm = w; warm_kind = 2; }
+        }
+        const int agg_st = aggregate(A, arena, choice, chooser, &L.rounds, warm, warm_kind);  // :80 (scratch is released with the level)
+        if (sib && stats->sibling_role == 1 && level == 1) {
+            if (agg_st == ORC_OK) ORC_TRY(sib->publish((int)level, choice, n, st));
+            sib->finish();  // nothing more will be published
+        }
+        ORC_TRY(agg_st);
         if (cache && level < 8) {
             if (cache->size[level] != n) { ORC_TRY(cache->choice[level].alloc((size_t)std::max<int64_t>(n, 1))); cache->size[level] = n; }
             ORC_HIP(hipMemcpyAsync(cache->choice[level].p, choice, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, st));
@@ -1850,7 +1937,7 @@ static int multigrid_solve_dev(const MatView &A, const double *r, uint64_t level
 
 // The set-up half of the Multigrid arm on its own: levels 1..3 of the hierarchy for `A_in` seen through the arm's
 // preconditioner (linear_algebra.rs:159-166 then :80, :84 per level, recursion rule of :109).
-int multigrid_prepare_dev(const MatView &A_in, int preconditioner, Arena &arena, AmgHierarchy &H) {
+int multigrid_prepare_dev(const MatView &A_in, int preconditioner, Arena &arena, AmgHierarchy &H, SiblingPairing *sibling, int sibling_role) {
     H = AmgHierarchy();
     const int64_t n = A_in.P.n;
     H.n_fine = n;
@@ -1873,7 +1960,14 @@ int multigrid_prepare_dev(const MatView &A_in, int preconditioner, Arena &arena,
         ORC_TRY(arena.alloc((size_t)std::max<int64_t>(nf, 1), &h.choice));
         ORC_TRY(arena.alloc((size_t)std::max<int64_t>(nf, 1), &h.chooser));
         CoarseLevel L;
-        ORC_TRY(aggregate(A, arena, h.choice, h.chooser, &L.rounds));
+        const int *warm = nullptr;
+        if (sibling && sibling_role == 2 && level == 1) warm = sibling->wait((int)level, nf, ctx().stream);
+        const int agg_st = aggregate(A, arena, h.choice, h.chooser, &L.rounds, warm, 2);
+        if (sibling && sibling_role == 1 && level == 1) {
+            if (agg_st == ORC_OK) ORC_TRY(sibling->publish((int)level, h.choice, nf, ctx().stream));
+            sibling->finish();
+        }
+        ORC_TRY(agg_st);
         ORC_TRY(galerkin(A, h.choice, h.chooser, arena, L));
         h.P = L.P; h.val = L.val; h.pk = L.pk; h.xw = L.xw; h.rows = L.rows; h.n = L.n; h.padded = L.padded; h.rounds = L.rounds;
         H.n_levels = (int)level;

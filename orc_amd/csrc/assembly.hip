@@ -938,6 +938,7 @@ int solver_init(SolverState &s, OrcMesh *m, const OrcSettings *settings, double 
     s.concurrent_momentum = !(getenv("ORC_CONCURRENT_MOMENTUM") && atoi(getenv("ORC_CONCURRENT_MOMENTUM")) == 0);
     s.two_stream_multigrid = !(getenv("ORC_TWO_STREAM_MULTIGRID") && atoi(getenv("ORC_TWO_STREAM_MULTIGRID")) == 0);
     s.early_p_hierarchy = !(getenv("ORC_EARLY_P_HIERARCHY") && atoi(getenv("ORC_EARLY_P_HIERARCHY")) == 0);
+    s.sibling_pairing = !(getenv("ORC_AMG_SIBLING") && atoi(getenv("ORC_AMG_SIBLING")) == 0);
     ORC_TRY(validate_settings(s.settings));
     const size_t n = (size_t)s.n, pad = (size_t)std::max<int64_t>(m->pat.padded, 1), F = (size_t)m->n_faces;
     DevBuf<double> *nvec[] = {&s.u, &s.v, &s.w, &s.p, &s.p_prime, &s.b_u_di, &s.b_v_di, &s.b_w_di, &s.b_u, &s.b_v, &s.b_w, &s.b_p, &s.du, &s.dv, &s.dw};
@@ -1115,6 +1116,9 @@ static int solve_field_on(SolverState &s, DevBuf<double> &a, DevBuf<double> &b, 
     ctx().reduction_order = t.reduction_order;
     stats.cache = &s.amg_cache[eq];
     stats.side = nullptr;
+    // the momentum systems share their pairing's starting state (the caller has opened the exchange: SiblingPairing::begin)
+    stats.sibling = (s.sibling_pairing && eq < 3) ? &s.sibling : nullptr;
+    stats.sibling_role = eq == 0 ? 1 : 2;
     stats.hierarchy = prepared ? prepared : ((eq == 3 && s.p_hierarchy.n_levels > 0) ? &s.p_hierarchy : nullptr);
     if (side && s.two_stream_multigrid && t.solver_type == ORC_SOLVER_MULTIGRID) {
         if (!side->stream) {
@@ -1410,8 +1414,10 @@ static int solve_momentum_concurrently(SolverState &s, bool setup_first, Prepare
         } else {
             st[k] = solve_field_on(s, *mats[k], *rhs[k], *sol[k], k, L.arena, L.stats, &L.side, &L.side_arena);
         }
+        if (k == 0) s.sibling.finish();  // whatever happened to u: v and w must not wait for a level that will not come
         if (hipStreamSynchronize(local[k].stream) != hipSuccess && st[k] == ORC_OK) st[k] = set_error(ORC_ERR_HIP, "stream synchronisation failed in a solve thread");
     };
+    s.sibling.begin(!setup_first);  // with the hierarchies prepared ahead nobody aggregates inside the solves
     run_lanes(work);
     s.stats = s.lanes[0].stats;
     for (int k = 0; k < 3; ++k)
@@ -1467,7 +1473,10 @@ int solver_iterate(SolverState &s, uint64_t iterations, double *report) {
         } else if (lanes_partitioned) {
             ORC_TRY(solve_momentum_partitioned(s));                     // the same with every RCCL call on the library stream
         } else {
-            ORC_TRY(solve_field(s, s.a_u, s.b_u, s.u, 0));              // :99-110
+            s.sibling.begin(true);
+            const int st_u = solve_field(s, s.a_u, s.b_u, s.u, 0);      // :99-110
+            s.sibling.finish();
+            ORC_TRY(st_u);
             if (dbg) debug_field(s, "u", s.u);
             ORC_TRY(solve_field(s, s.a_v, s.b_v, s.v, 1));              // :112-123
             if (dbg) debug_field(s, "v", s.v);

@@ -73,6 +73,7 @@ struct SolverState {
     Arena arena;
     SolveStats stats;
     AmgCache amg_cache[4];  // u, v, w, p' (warm start of the per-solve hierarchy set-up)
+    SiblingPairing sibling;  // u's pairing of this iteration as the starting state of v's and w's (linalg.hpp)
     // The u, v and w systems of an iteration are independent (solver.rs:99-136 solves them one after the other, none
     // reads another's result): each gets its own stream, arena and host thread, so the latency-bound set-up rounds of
     // one hierarchy overlap the bandwidth-bound products of another.  Same kernels, same order per system: same bits.
@@ -92,6 +93,7 @@ struct SolverState {
     Arena hier_arena;
     hipStream_t prep_stream = nullptr;
     bool early_p_hierarchy = true;
+    bool sibling_pairing = true;  // v and w take u's fine-level pairing when it verifies as theirs (ORC_AMG_SIBLING=0: off)
     SolveSide side;       // the same for the solves on the library stream (p', or all four when the lanes are off)
     Arena side_arena;
     bool two_stream_multigrid = true;

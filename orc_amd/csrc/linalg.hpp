@@ -1,5 +1,7 @@
 // linalg.hpp — device sparse matrix format and the iterative solvers (K1-K8 of SURVEY §2.1).
 #pragma once
+#include <condition_variable>
+#include <mutex>
 #include "common.hpp"
 #include "halo.hpp"
 
@@ -139,8 +141,32 @@ struct AmgHierarchy {
     int64_t n_fine = 0;
 };
 
+// The u, v and w momentum systems of one SIMPLE iteration share their pattern and differ in a few coefficients (the TVD
+// limiter per component), and their greedy pairings come out the same for all but a handful of rows (measured: 100.00 %
+// on level 0, 99.9 % on level 1 of the 400 x 40 x 40 channel).  The pairing is a unique fixed point that the device reaches
+// from ANY starting state and certifies, so the first system to finish a level (the leader, u) publishes its pairing and
+// the others start from it instead of from the unconstrained arg-min: their first lock-step round then finds almost
+// nothing to change.  Nothing is carried from one SIMPLE iteration to the next.
+struct SiblingPairing {
+    static constexpr int kLevels = 8;
+    DevBuf<int> buf[kLevels];          // the leader's pairing per level (a copy: the leader's own array is arena memory)
+    int64_t n[kLevels] = {0};
+    hipEvent_t ready[kLevels] = {nullptr};
+    bool published[kLevels] = {false};
+    bool leader_done = true;           // no leader at work: followers do not wait
+    std::mutex mu;
+    std::condition_variable cv;
+    ~SiblingPairing();
+    void begin(bool leader_will_run);  // before the systems of an iteration start
+    int publish(int level, const int *choice, int64_t rows, hipStream_t stream);  // leader, after its aggregation of `level`
+    const int *wait(int level, int64_t rows, hipStream_t stream);                 // follower; null = start from scratch
+    void finish();                     // leader, on every exit from its solve
+};
+
 struct SolveStats {
     AmgCache *cache = nullptr;  // optional, owned by the caller (one per equation)
+    SiblingPairing *sibling = nullptr;  // optional, owned by the caller (shared by the momentum systems of an iteration)
+    int sibling_role = 0;               // 1 = leader (publishes), 2 = follower (starts from the leader's pairing)
     SolveSide *side = nullptr;  // optional, owned by the caller
     const AmgHierarchy *hierarchy = nullptr;  // optional: a hierarchy prepared for exactly this matrix
     int64_t jacobi_sweeps = 0;
@@ -159,7 +185,8 @@ int iterative_solve_dev(const MatView &A, const double *b, double *x, uint64_t i
 
 // Builds the hierarchy the Multigrid arm of iterative_solve_dev(A, ..., preconditioner) would build for itself (same
 // kernels, same results); all of its memory comes from `arena` and stays valid until the caller releases it.
-int multigrid_prepare_dev(const MatView &A, int preconditioner, Arena &arena, AmgHierarchy &H);
+int multigrid_prepare_dev(const MatView &A, int preconditioner, Arena &arena, AmgHierarchy &H, SiblingPairing *sibling = nullptr,
+                          int sibling_role = 0);
 // dinv[i] = 1 / A(i,i) through the view (the Jacobi preconditioner's p_inv, linear_algebra.rs:159-166)
 int diag_inverse_dev(const MatView &A, double *dinv);
 // out = 0 + s * b  (p_inv * b, linear_algebra.rs:165)
