@@ -133,10 +133,11 @@ struct TailCounters {
     int parity;    // which of the two work lists is the current one (the other collects the next round's rows)
     int first;     // first round: every row is evaluated, no list
     int finished;  // a round without a change has been seen: the fixed point is certified
+    int fetch;     // cascades: next unclaimed entry of the current list (groups claim rows as they become free)
 };
 
 __global__ void tail_seed_k(TailCounters *T, int n) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) { T->cur = n; T->changed = 0; T->next = 0; T->rounds = 0; T->parity = 1; T->first = 1; T->finished = 0; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { T->cur = n; T->changed = 0; T->next = 0; T->rounds = 0; T->parity = 1; T->first = 1; T->finished = 0; T->fetch = 0; }
 }
 
 // One atomicAdd per wavefront instead of one per lane: the lanes that want a slot are counted with a ballot, the
@@ -292,6 +293,7 @@ __global__ void tail_rotate_k(TailCounters *T) {
         T->rounds += 1;
         T->parity ^= 1;
         T->first = 0;
+        T->fetch = 0;
     }
 }
 
@@ -553,9 +555,12 @@ __global__ __launch_bounds__(kBlock) void tail_chase_k(MatView A, int *choice, u
     const int *cur = T->parity ? list_b : list_a;
     int *next = T->parity ? list_a : list_b;
     const int lane = threadIdx.x & (G - 1);  // lane inside the group
-    const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G, groups = ((int64_t)gridDim.x * blockDim.x) / G;
     int steps = 0;
-    for (int64_t idx = group; idx < count; idx += groups) {
+    while (steps < max_steps) {  // rows are claimed one at a time: a group that is through with a short cascade takes the next
+        int idx = 0;             // (rows nobody claims before the budgets run out are carried over by chase_carry_k)
+        if (lane == 0) idx = atomicAdd(&T->fetch, 1);
+        idx = __shfl(idx, 0, G);
+        if (idx >= count) break;
         int i = cur[idx];
         while (i >= 0) {
             if (steps >= max_steps) {  // hand the row (still queued) to the next launch
@@ -611,6 +616,15 @@ __global__ __launch_bounds__(kBlock) void tail_chase_k(MatView A, int *choice, u
     if (lane == 0 && steps) atomicAdd(&T->changed, steps);  // statistics: evaluations of this launch
 }
 
+// rows of the current list that no group claimed (every budget ran out first) move to the next list
+__global__ void chase_carry_k(TailCounters *T, const int *list_a, const int *list_b, int *out_a, int *out_b) {
+    if (T->finished) return;
+    const int count = T->cur, from = min(T->fetch, count);
+    const int *cur = T->parity ? list_b : list_a;
+    int *next = T->parity ? out_a : out_b;
+    for (int idx = from + blockIdx.x * blockDim.x + threadIdx.x; idx < count; idx += gridDim.x * blockDim.x) next[atomicAdd(&T->next, 1)] = cur[idx];
+}
+
 __global__ void chase_rotate_k(TailCounters *T, int *steps_total) {
     if (blockIdx.x == 0 && threadIdx.x == 0 && !T->finished) {
         *steps_total += T->changed;
@@ -619,6 +633,7 @@ __global__ void chase_rotate_k(TailCounters *T, int *steps_total) {
         T->changed = 0;
         T->rounds += 1;
         T->parity ^= 1;
+        T->fetch = 0;
     }
 }
 
@@ -1555,9 +1570,13 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
         // (read per call, not cached: the tests run one process through the lock-step-only form, a starved cascade phase
         // that hands over to the lock-step rounds unfinished, and the default)
         const int chase_enabled = getenv("ORC_AMG_CHASE") ? atoi(getenv("ORC_AMG_CHASE")) : 1;
-        const int chase_steps = getenv("ORC_AMG_CHASE_STEPS") ? atoi(getenv("ORC_AMG_CHASE_STEPS")) : 4096;
+        // steps per wavefront and launch: a wavefront that is through with them hands its rows to the next launch, which
+        // spreads them over the whole chip again (unbounded: a few wavefronts with long cascades work alone — 477 ms of
+        // cascades per 3.25 iterations against 321 ms at 96; 16: 525 ms, launches dominate)
+        const int chase_steps = getenv("ORC_AMG_CHASE_STEPS") ? atoi(getenv("ORC_AMG_CHASE_STEPS")) : 96;
         const int chase_grid = getenv("ORC_AMG_CHASE_GRID") ? atoi(getenv("ORC_AMG_CHASE_GRID")) : 2048;
-        const int chase_launches = getenv("ORC_AMG_CHASE_LAUNCHES") ? atoi(getenv("ORC_AMG_CHASE_LAUNCHES")) : 64;
+        const int chase_launches = getenv("ORC_AMG_CHASE_LAUNCHES") ? atoi(getenv("ORC_AMG_CHASE_LAUNCHES")) : 1024;
+        const int chase_batch = getenv("ORC_AMG_CHASE_BATCH") ? std::max(1, atoi(getenv("ORC_AMG_CHASE_BATCH"))) : 2;  // launches per host read
         static const bool trace = getenv("ORC_AMG_TRACE") != nullptr;
         if (chase_enabled) {
             // one lock-step round over every row, the cascades it leaves followed asynchronously, then the lock-step rounds
@@ -1584,13 +1603,14 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
             const int group = group_env ? group_env : (avg_len <= 14. ? 16 : (avg_len <= 28. ? 32 : 64));
             int launches = 0, first_list = -1;
             for (;;) {
-                for (int b = 0; b < 2; ++b) {
+                for (int b = 0; b < chase_batch; ++b) {
                     if (group == 16) hipLaunchKernelGGL(tail_chase_k<16>, dim3(chase_grid), dim3(kBlock), 0, st, A, choice, tb, ver, flag, T, listA, listB, chase_steps);
                     else if (group == 32) hipLaunchKernelGGL(tail_chase_k<32>, dim3(chase_grid), dim3(kBlock), 0, st, A, choice, tb, ver, flag, T, listA, listB, chase_steps);
                     else hipLaunchKernelGGL(tail_chase_k<64>, dim3(chase_grid), dim3(kBlock), 0, st, A, choice, tb, ver, flag, T, listA, listB, chase_steps);
+                    hipLaunchKernelGGL(chase_carry_k, dim3(64), dim3(kBlock), 0, st, T, (const int *)listA, (const int *)listB, listA, listB);
                     hipLaunchKernelGGL(chase_rotate_k, dim3(1), dim3(1), 0, st, T, steps_total);
                 }
-                launches += 2;
+                launches += chase_batch;
                 ORC_HIP(hipGetLastError());
                 ORC_HIP(hipMemcpyAsync(&h, T, sizeof(h), hipMemcpyDeviceToHost, st));
                 ORC_HIP(hipStreamSynchronize(st));
