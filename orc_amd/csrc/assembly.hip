@@ -1089,10 +1089,14 @@ int k_apply_correction(SolverState &s, double *sums_host) {
 // lane (measured: about the same), 2 = this scheme (default).  1.34 -> 1.24 s per iteration.
 enum { kSetupStream = 0, kSolveStream = 100 };
 static int create_stream(hipStream_t *out, int role, int lane) {
-    static const int prio_mode = getenv("ORC_STREAM_PRIORITIES") ? atoi(getenv("ORC_STREAM_PRIORITIES")) : 2;
+    // 3 (default): solve streams above set-up streams — since the round-2 set-up rework the solves are the critical path of
+    // the momentum phase (measured: 0.863-0.879 s per iteration against 0.903-0.909 s with 2, the round-1 setting that
+    // favoured the then latency-bound set-up, and 0.926-0.957 s without priorities); 1: by lane; 0: none
+    static const int prio_mode = getenv("ORC_STREAM_PRIORITIES") ? atoi(getenv("ORC_STREAM_PRIORITIES")) : 3;
     int least = 0, greatest = 0;
     if (prio_mode != 0 && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) {
         int klass = prio_mode == 1 ? lane : (role == kSolveStream ? 2 : 0);
+        if (prio_mode == 3) klass = role == kSolveStream ? 0 : 2;  // the other way round: products first
         const int prio = klass == 0 ? greatest : (klass == 2 ? least : (least + greatest) / 2);
         ORC_HIP(hipStreamCreateWithPriority(out, hipStreamNonBlocking, prio));
         return ORC_OK;
