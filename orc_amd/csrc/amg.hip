@@ -1612,10 +1612,17 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
                 }
                 launches += chase_batch;
                 ORC_HIP(hipGetLastError());
+                int evaluated = 0;
                 ORC_HIP(hipMemcpyAsync(&h, T, sizeof(h), hipMemcpyDeviceToHost, st));
+                ORC_HIP(hipMemcpyAsync(&evaluated, steps_total, sizeof(int), hipMemcpyDeviceToHost, st));
                 ORC_HIP(hipStreamSynchronize(st));
                 if (first_list < 0) first_list = h.cur;
                 if (h.finished || h.cur == 0 || launches >= chase_launches) break;
+                // Cascades that multiply instead of running out (seen from a state that is complete but not this matrix's:
+                // displaced rows displace later ones and the chains run through each other's rows again and again) are
+                // left to the lock-step rounds, whose order keeps every row to one decision per round: give up once the
+                // evaluations exceed four per row (the channel's levels need 0.4 to 1.5).
+                if ((int64_t)evaluated > 4 * n + 4096) break;
             }
             rounds += h.rounds;
             lap("cascades");
