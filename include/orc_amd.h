@@ -296,6 +296,14 @@ int orc_hex_channel_write_msh(const char *path, int64_t nx, int64_t ny, int64_t 
  * INLET, OUTLET, WALL, PERIODIC_-Z, PERIODIC_+Z and their "_TRI" twins, boundary zones of type 3 (wall). */
 int orc_mixed_channel_write_msh(const char *path, int64_t nx, int64_t ny, int64_t nz, double lx, double ly, double lz,
                                 int64_t *n_cells, int64_t *n_faces);
+/* The same with a region of POLYHEDRAL cells between x = lx/20 and lx/4 (BASELINE config 5: "tet/hex/poly"): blocks
+ * alternate between a hexahedron and six pyramids about the block centre, and every pyramid is agglomerated into the
+ * hexahedron behind its base — rhombic dodecahedra of 12 planar quadrilateral faces (13 matrix entries per row), with
+ * partial cells and left-over pyramids along the region's sides.  Polyhedral CELLS written through triangular and
+ * quadrilateral face sections: the subset of TGRID the reference's reader parses correctly (io.rs:232-233 misreads the
+ * per-line node count of face_type 0 / 5 sections), no two cells sharing more than one face (discretization.rs:312-322). */
+int orc_poly_channel_write_msh(const char *path, int64_t nx, int64_t ny, int64_t nz, double lx, double ly, double lz,
+                               int64_t *n_cells, int64_t *n_faces);
 
 /* ---------- multi-GPU (one process per GPU, RCCL over xGMI) ---------- */
 #define ORC_COMM_ID_BYTES 128

@@ -12,6 +12,7 @@
 #include <cinttypes>
 #include <cmath>
 #include <cstdio>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/orc_amd.h"
@@ -234,6 +235,7 @@ struct FaceRec {
     int64_t nodes[4];
     int64_t cell;
     int nn;
+    bool agglomerated;  // face of a cell that was put together from several blocks' pieces (polyhedral region)
 };
 
 struct MixedBuilder {
@@ -251,8 +253,9 @@ struct MixedBuilder {
         cell_cnt.push_back(0);
         return n_cells++;
     }
-    void face(int64_t cell, std::initializer_list<int64_t> ns) {
+    void face(int64_t cell, std::initializer_list<int64_t> ns, bool agglomerated = false) {
         FaceRec r;
+        r.agglomerated = agglomerated;
         r.nn = (int)ns.size();
         int q = 0;
         for (int64_t v : ns) { r.nodes[q] = v; r.key[q] = v; ++q; }
@@ -279,23 +282,58 @@ struct MixedBuilder {
     }
 };
 
-enum BlockKind { kHexBlock, kPrismBlock, kTetBlock, kTransitionBlock };
+enum BlockKind { kHexBlock, kPrismBlock, kTetBlock, kTransitionBlock, kPolyBlock };
+
+// Polyhedral region (`polyhedra` != 0; BASELINE config 5: "tet/hex/poly").  True polygonal face sections (face_type 5) are
+// out of reach — the reference's reader takes "tokens - 2" as the node count of every face line (io.rs:232) — but a
+// polyhedral CELL only needs many faces, and those may be triangles and quadrilaterals.  The blocks of the region alternate
+// like a checkerboard between a hexahedron and six pyramids about the block centre; every pyramid is AGGLOMERATED into the
+// hexahedron behind its base.  The cell that results is a rhombic dodecahedron: the pyramid sides of the two blocks that
+// meet along a block edge are coplanar and separate the same two cells, so they are written as ONE planar rhombus
+// (edge end, block centre, edge end, block centre) — 12 quadrilateral faces, 14 vertices, 13 matrix entries per row.
+// A pyramid whose base looks out of the region (or at the wall) stays a pyramid, and next to it the cells keep single
+// triangular faces, so that no two cells ever share more than one face (one matrix entry per interior face,
+// discretization.rs:312-322).
+int write_mixed_channel(const char *path, int64_t nx, int64_t ny, int64_t nz, double lx, double ly, double lz, int polyhedra,
+                        int64_t *n_cells_out, int64_t *n_faces_out);
 
 }  // namespace
 
 extern "C" int orc_mixed_channel_write_msh(const char *path, int64_t nx, int64_t ny, int64_t nz, double lx, double ly, double lz,
                                            int64_t *n_cells_out, int64_t *n_faces_out) {
+    return write_mixed_channel(path, nx, ny, nz, lx, ly, lz, 0, n_cells_out, n_faces_out);
+}
+
+extern "C" int orc_poly_channel_write_msh(const char *path, int64_t nx, int64_t ny, int64_t nz, double lx, double ly, double lz,
+                                          int64_t *n_cells_out, int64_t *n_faces_out) {
+    return write_mixed_channel(path, nx, ny, nz, lx, ly, lz, 1, n_cells_out, n_faces_out);
+}
+
+namespace {
+
+int write_mixed_channel(const char *path, int64_t nx, int64_t ny, int64_t nz, double lx, double ly, double lz, int polyhedra,
+                        int64_t *n_cells_out, int64_t *n_faces_out) {
     if (!path || nx < 20 || ny < 1 || nz < 1) return ORC_ERR_BAD_ARGUMENT;
     MixedBuilder B;
     B.nx = nx; B.ny = ny; B.nz = nz; B.lx = lx; B.ly = ly; B.lz = lz;
     B.grid_nodes = (nx + 1) * (ny + 1) * (nz + 1);
+    const int64_t iq0 = nx / 20 + 1, iq1 = nx / 4;                // polyhedra (hexahedra either side)
     const int64_t ip0 = nx * 3 / 10, ip1 = nx * 45 / 100;         // prism columns
     const int64_t it0 = nx / 2 + 1, it1 = nx * 85 / 100;          // Kuhn tetrahedra, one transition block either side
     auto kind = [&](int64_t i) {
+        if (polyhedra && i >= iq0 && i < iq1) return kPolyBlock;
         if (i >= ip0 && i < ip1) return kPrismBlock;
         if (i >= it0 && i < it1) return kTetBlock;
         if (i == it0 - 1 || i == it1) return kTransitionBlock;
         return kHexBlock;
+    };
+    // cell of the hexahedron block (i, j, k) of the polyhedral region, created on first use (a pyramid block may come first)
+    std::vector<int64_t> poly_cell;
+    if (polyhedra) poly_cell.assign((size_t)((iq1 - iq0) * ny * nz), -1);
+    auto poly_hex_cell = [&](int64_t i, int64_t j, int64_t k) {
+        int64_t &c = poly_cell[(size_t)((i - iq0) + (iq1 - iq0) * (j + ny * k))];
+        if (c < 0) c = B.new_cell();
+        return c;
     };
     B.coords.reserve((size_t)B.grid_nodes + (size_t)(2 * ny * nz));
     for (int64_t k = 0; k <= nz; ++k)
@@ -313,6 +351,26 @@ extern "C" int orc_mixed_channel_write_msh(const char *path, int64_t nx, int64_t
                     B.face(c, {v[0], v[1], v[3], v[2]}); B.face(c, {v[4], v[5], v[7], v[6]});
                     B.face(c, {v[0], v[1], v[5], v[4]}); B.face(c, {v[2], v[3], v[7], v[6]});
                     B.face(c, {v[0], v[2], v[6], v[4]}); B.face(c, {v[1], v[3], v[7], v[5]});
+                } else if (kd == kPolyBlock && ((i + j + k) & 1) == 0) {  // the hexahedron its neighbours' pyramids are merged into
+                    const int64_t c = poly_hex_cell(i, j, k);
+                    B.face(c, {v[0], v[1], v[3], v[2]}, true); B.face(c, {v[4], v[5], v[7], v[6]}, true);
+                    B.face(c, {v[0], v[1], v[5], v[4]}, true); B.face(c, {v[2], v[3], v[7], v[6]}, true);
+                    B.face(c, {v[0], v[2], v[6], v[4]}, true); B.face(c, {v[1], v[3], v[7], v[5]}, true);
+                } else if (kd == kPolyBlock) {  // six pyramids about the centre, each handed to the hexahedron behind its base
+                    const int64_t p = (int64_t)B.coords.size();
+                    V3 s = {0., 0., 0.};
+                    for (int c = 0; c < 8; ++c) s = add(s, B.coords[(size_t)v[c]]);
+                    B.coords.push_back({s.x / 8., s.y / 8., s.z / 8.});
+                    const int64_t quads[6][4] = {{v[0], v[2], v[6], v[4]}, {v[1], v[3], v[7], v[5]}, {v[0], v[1], v[5], v[4]},
+                                                 {v[2], v[3], v[7], v[6]}, {v[0], v[1], v[3], v[2]}, {v[4], v[5], v[7], v[6]}};
+                    const int64_t di[6] = {-1, 1, 0, 0, 0, 0}, dj[6] = {0, 0, -1, 1, 0, 0}, dk[6] = {0, 0, 0, 0, -1, 1};
+                    for (int q = 0; q < 6; ++q) {
+                        const int64_t ni = i + di[q], nj = j + dj[q], nk = k + dk[q];
+                        const bool merge = ni >= iq0 && ni < iq1 && nj >= 0 && nj < ny && nk >= 0 && nk < nz;
+                        const int64_t c = merge ? poly_hex_cell(ni, nj, nk) : B.new_cell();
+                        B.face(c, {quads[q][0], quads[q][1], quads[q][2], quads[q][3]}, true);  // inside a merged cell: dropped below
+                        for (int e = 0; e < 4; ++e) B.face(c, {quads[q][e], quads[q][(e + 1) & 3], p}, true);
+                    }
                 } else if (kd == kPrismBlock) {  // two prisms along the diagonal v0 - v3 of the base
                     const int64_t tri[2][3] = {{0, 1, 3}, {0, 3, 2}};
                     for (int t = 0; t < 2; ++t) {
@@ -354,15 +412,8 @@ extern "C" int orc_mixed_channel_write_msh(const char *path, int64_t nx, int64_t
                                   "PERIODIC_-Z", "PERIODIC_-Z_TRI", "WALL", "WALL_TRI"};
     std::vector<OutFace> zones[12];
     const double eps = 1e-12 * std::max(lx, std::max(ly, lz));
-    for (size_t r = 0; r < B.recs.size();) {
-        const FaceRec &a = B.recs[r];
-        const bool paired = r + 1 < B.recs.size() && B.recs[r + 1].nn == a.nn && std::equal(a.key, a.key + 4, B.recs[r + 1].key);
-        OutFace o;
-        o.nn = a.nn;
-        o.c0 = a.cell;
-        o.c1 = paired ? B.recs[r + 1].cell : -1;
-        for (int q = 0; q < 4; ++q) o.n[q] = a.nodes[q];
-        // orientation: (n2 - n1) x (n1 - n0) out of c0 (io.rs:322-326, mesh.rs:216-222)
+    // orientation: (n2 - n1) x (n1 - n0) out of c0 (io.rs:322-326, mesh.rs:216-222)
+    auto orient = [&](OutFace &o) {
         const V3 p0 = B.coords[(size_t)o.n[0]], p1 = B.coords[(size_t)o.n[1]], p2 = B.coords[(size_t)o.n[2]];
         const V3 nrm = cross(sub(p2, p1), sub(p1, p0));
         V3 fc = {0., 0., 0.};
@@ -372,6 +423,48 @@ extern "C" int orc_mixed_channel_write_msh(const char *path, int64_t nx, int64_t
         const double cnt = (double)B.cell_cnt[(size_t)o.c0];
         const V3 cc = {cs.x / cnt, cs.y / cnt, cs.z / cnt};
         if (dot(sub(fc, cc), nrm) < 0.) std::reverse(o.n, o.n + o.nn);
+    };
+    // interior triangles of agglomerated cells, by cell pair: the second triangle between the same two cells closes a rhombus
+    std::unordered_map<int64_t, OutFace> open_tri;
+    for (size_t r = 0; r < B.recs.size();) {
+        const FaceRec &a = B.recs[r];
+        const bool paired = r + 1 < B.recs.size() && B.recs[r + 1].nn == a.nn && std::equal(a.key, a.key + 4, B.recs[r + 1].key);
+        if (paired && B.recs[r + 1].cell == a.cell) { r += 2; continue; }  // inside an agglomerated cell
+        OutFace o;
+        o.nn = a.nn;
+        o.c0 = a.cell;
+        o.c1 = paired ? B.recs[r + 1].cell : -1;
+        for (int q = 0; q < 4; ++q) o.n[q] = a.nodes[q];
+        if (paired && o.nn == 3 && a.agglomerated && B.recs[r + 1].agglomerated) {
+            const int64_t lo = std::min(o.c0, o.c1), hi = std::max(o.c0, o.c1);
+            const int64_t pair_key = lo * B.n_cells + hi;
+            auto it = open_tri.find(pair_key);
+            if (it == open_tri.end()) {
+                open_tri.emplace(pair_key, o);
+            } else {  // (e0, e1, a) + (e0, e1, b) -> the planar rhombus (e0, a, e1, b)
+                const OutFace &t = it->second;
+                int64_t shared[2], mine = -1, theirs = -1;
+                int ns = 0;
+                for (int q = 0; q < 3; ++q) {
+                    bool in = false;
+                    for (int w = 0; w < 3; ++w) in = in || t.n[w] == o.n[q];
+                    if (in) { if (ns < 2) shared[ns] = o.n[q]; ++ns; }
+                    else mine = o.n[q];
+                }
+                for (int w = 0; w < 3; ++w)
+                    if (t.n[w] != shared[0] && t.n[w] != shared[1]) theirs = t.n[w];
+                if (ns != 2 || mine < 0 || theirs < 0) return ORC_ERR_BAD_ARGUMENT;  // two cells sharing two unrelated faces
+                OutFace qd;
+                qd.nn = 4; qd.c0 = t.c0; qd.c1 = t.c1;
+                qd.n[0] = shared[0]; qd.n[1] = theirs; qd.n[2] = shared[1]; qd.n[3] = mine;
+                orient(qd);
+                zones[0].push_back(qd);
+                open_tri.erase(it);
+            }
+            r += 2;
+            continue;
+        }
+        orient(o);
         int z;
         if (paired) z = 0;
         else {
@@ -392,6 +485,15 @@ extern "C" int orc_mixed_channel_write_msh(const char *path, int64_t nx, int64_t
         }
         zones[z + (o.nn == 3 ? 1 : 0)].push_back(o);
         r += paired ? 2 : 1;
+    }
+    {  // single triangles between agglomerated cells (next to a pyramid that stayed on its own), in a reproducible order
+        std::vector<OutFace> rest;
+        rest.reserve(open_tri.size());
+        for (auto &kv : open_tri) rest.push_back(kv.second);
+        std::sort(rest.begin(), rest.end(), [](const OutFace &a, const OutFace &b) {
+            return std::lexicographical_compare(a.n, a.n + 3, b.n, b.n + 3);
+        });
+        for (OutFace &o : rest) { orient(o); zones[1].push_back(o); }
     }
     int64_t n_faces = 0;
     for (auto &z : zones) n_faces += (int64_t)z.size();
@@ -422,3 +524,5 @@ extern "C" int orc_mixed_channel_write_msh(const char *path, int64_t nx, int64_t
     if (n_faces_out) *n_faces_out = n_faces;
     return ORC_OK;
 }
+
+}  // namespace

@@ -98,14 +98,16 @@ def write_hex_channel_msh(path, nx, ny, nz, lx=0.002, ly=0.001, lz=None):
                                           C.c_double(ly), C.c_double(lz)))
 
 
-def write_mixed_channel_msh(path, nx, ny, nz, lx=0.002, ly=0.001, lz=None):
-    """BASELINE config 5 workload (orc_mixed_channel_write_msh): tet / pyramid / prism / hex channel as a TGRID file.
+def write_mixed_channel_msh(path, nx, ny, nz, lx=0.002, ly=0.001, lz=None, polyhedra=False):
+    """BASELINE config 5 workload (orc_mixed_channel_write_msh): tet / pyramid / prism / hex channel as a TGRID file;
+    polyhedra=True (orc_poly_channel_write_msh) adds a region of agglomerated polyhedral cells (12-face rhombic dodecahedra).
     Returns (n_cells, n_faces)."""
     if lz is None:
         lz = 1e-4 * nz
     nc, nf = C.c_int64(), C.c_int64()
-    check(lib().orc_mixed_channel_write_msh(path.encode(), C.c_int64(nx), C.c_int64(ny), C.c_int64(nz), C.c_double(lx), C.c_double(ly),
-                                            C.c_double(lz), C.byref(nc), C.byref(nf)))
+    fn = lib().orc_poly_channel_write_msh if polyhedra else lib().orc_mixed_channel_write_msh
+    check(fn(path.encode(), C.c_int64(nx), C.c_int64(ny), C.c_int64(nz), C.c_double(lx), C.c_double(ly),
+             C.c_double(lz), C.byref(nc), C.byref(nf)))
     return nc.value, nf.value
 
 

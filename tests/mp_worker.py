@@ -110,6 +110,15 @@ def main():
             print("MP_WORKER_OK" if t.item() == 1.0 else "MP_WORKER_FAIL", flush=True)
         dist.destroy_process_group()
         return
+    if mode == "gpu_converged":
+        ok = gpu_converged_checks(rank, world)
+        t = torch.tensor([1.0 if ok else 0.0])
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        dist.barrier()
+        if rank == 0:
+            print("MP_WORKER_OK" if t.item() == 1.0 else "MP_WORKER_FAIL", flush=True)
+        dist.destroy_process_group()
+        return
     if mode == "gpu_overlap":
         ok = gpu_overlap_checks(rank, world)
         t = torch.tensor([1.0 if ok else 0.0])
@@ -225,6 +234,66 @@ def gpu_general_checks(rank, world):
             if rank == 0:
                 print("  ordering %d %-9s status %d/%d  max rel err vs single rank %.3e  %s" % (ordering, name, st, st_ref, err, "ok" if good else "FAIL"), flush=True)
             ok = ok and good
+    parallel.finalize()
+    return ok
+
+
+def gpu_converged_checks(rank, world):
+    """North-star criterion at N > 1 (converged fields within 1e-6 rel-L2 of the CPU reference, solver.rs:60-222):
+    channel_flow.msh read by the product reader, cut by orc_mesh_partition, the reference's DEFAULT stack (Multigrid arm,
+    50 BiCGSTAB smoothing iterations per level, Jacobi preconditioner, Rhie-Chow, SecondOrder) run partitioned to
+    convergence, against the oracle in the reference's own in-place mode.  The per-rank hierarchies (aggregates never
+    cross the cut) make the partitioned Multigrid a different preconditioner for the same outer system: the transient
+    differs, the SIMPLE fixed point must not."""
+    import orc_amd
+    from oracle import pyoracle as po
+    import helpers as H
+    from orc_amd import io as orc_io
+    from orc_amd.mesh import MeshArrays
+    from orc_amd.settings import NumericalSettings
+    from orc_amd.solver import Solver
+    orc_amd.init(0)
+    parallel.init_host_transport(dist, rank, world)
+    path = os.path.join(ROOT, "tests", "golden", "meshes", "channel_flow.msh")
+    d = orc_io.read_mesh(path)
+    for name, zt, sc in (("WALL", 3, 0.0), ("INLET", 4, -5.0 * 0.002), ("OUTLET", 5, 0.0), ("PERIODIC_-Z", 7, 0.0), ("PERIODIC_+Z", 7, 0.0)):
+        d.set_zone(name, zt, sc)
+    ag = MeshArrays(d.arrays())
+    n = len(np.asarray(ag["cell_volume"]))
+    cc = np.asarray(ag["cell_centroid"])
+    u0 = H.analytical_poiseuille(cc[:, 1]) * (1 + 0.02 * splitmix64_uniform(n, 1))
+    v0 = 1e-7 * splitmix64_uniform(n, 2)
+    w0 = 1e-12 * splitmix64_uniform(n, 3)
+    p0 = -0.01 * (1 - cc[:, 0] / 0.002) * (1 + 0.01 * splitmix64_uniform(n, 4))
+    iters = int(os.environ.get("ORC_CONVERGED_ITERS", "1500"))
+    kw = dict(momentum=1, solver_type=2, iterations=50)
+    ref = None
+    if rank == 0:  # the oracle, once
+        om = H.channel_bcs(po.Mesh.read(path))
+        ref = [x.copy() for x in (u0, v0, w0, p0)]
+        st_o, rep = po.solve_steady(om, *ref, po.default_settings(frozen_diagonals=0, **kw), 1000.0, 1e-3, iters, report=True)
+        assert st_o == 0 and rep[-1][4] < 1e-8, "oracle not converged"
+    box = [ref]
+    dist.broadcast_object_list(box, src=0)
+    ref = box[0]
+    ok = True
+    for ordering in (parallel.ORDER_ORC, parallel.ORDER_RCM):
+        a, halo, gids = parallel.partition_arrays(ag, world, rank, ordering)
+        n_own = halo["n_owned"]
+        sol = Solver(parallel.PartitionedMesh(a, halo), NumericalSettings.default(**kw), 1000.0, 1e-3)
+        sol.set_fields(*[f[gids] for f in (u0, v0, w0, p0)])
+        st, rep = sol.iterate(iters, report=True, raise_on_error=False)
+        loc = sol.get_fields()
+        # squared errors of the owned cells, summed over the ranks
+        num = torch.tensor([float(np.sum((l[:n_own] - g[gids[:n_own]]) ** 2)) for l, g in zip(loc, ref)], dtype=torch.float64)
+        dist.all_reduce(num)
+        un = np.linalg.norm(ref[0])
+        err = [float(np.sqrt(num[0])) / un, float(np.sqrt(num[1])) / un, float(np.sqrt(num[2])) / un, float(np.sqrt(num[3])) / np.linalg.norm(ref[3])]
+        good = st == 0 and rep[-1][6] < 1e-8 and max(err) < 1e-6
+        if rank == 0:
+            print("  ordering %d: status %d, velocity-correction norm %.3e, u/v/w (of |u|) and p rel-L2 vs the oracle: %.2e %.2e %.2e %.2e  %s"
+                  % (ordering, st, rep[-1][6], err[0], err[1], err[2], err[3], "ok" if good else "FAIL"), flush=True)
+        ok = ok and good
     parallel.finalize()
     return ok
 

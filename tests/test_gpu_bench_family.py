@@ -1,0 +1,82 @@
+"""Parity of the BENCH workload family (BASELINE configs[3]) against the oracle at sizes the oracle affords: the same
+generator (`hex_channel`, true 3-D, so SURVEY Q1 — `f64 * Vector` sets z := y, lib.rs:540-548 — is live), the same BCs
+(tests.rs:60-76), the same settings (`bench.py`: TVD-UMIST, Rhie-Chow, SecondOrder, Multigrid arm with 50 BiCGSTAB
+smoothing iterations per level + Jacobi preconditioner, relaxation 0.1 / 0.001) and the same initial-field recipe
+(`bench.initial_fields`).
+
+* in the reference's own mode (in-place diagonals, no guard, nalgebra's reduction order) the device reproduces the oracle's
+  solve_steady (solver.rs:60-222) BIT FOR BIT after each of three iterations;
+* the product default (frozen diagonals, tree reductions, guard) — what bench.py times — follows the same trajectory: its
+  per-iteration report (mean velocities, velocity- and pressure-correction norms, solver.rs:206-216) agrees with the
+  oracle's to the tolerance written below, and the guard never fires (`breakdown_guard_events`), so no kernel of the
+  timed path was skipped.
+"""
+import numpy as np
+import pytest
+
+import bench
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+MULTIGRID, UMIST, REFERENCE = 2, 5, 1
+BENCH_KW = dict(momentum=UMIST, solver_type=MULTIGRID, iterations=50, momentum_relaxation=0.1, pressure_relaxation=0.001)
+
+
+def same_bits(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    na, nb = np.isnan(a), np.isnan(b)
+    return np.array_equal(na, nb) and np.array_equal(a[~na].view(np.uint64), b[~nb].view(np.uint64))
+
+
+def _channel(oracle, shape):
+    from orc_amd.mesh import Mesh, hex_channel, set_channel_bcs
+    a = set_channel_bcs(hex_channel(*shape))
+    return oracle.Mesh.from_arrays(a), Mesh(a), a
+
+
+@pytest.mark.parametrize("shape", [(40, 16, 16), (24, 20, 12)])
+def test_bench_channel_three_iterations_bit_exact_in_reference_order(gpu, oracle, shape):
+    from orc_amd.settings import NumericalSettings
+    from orc_amd.solver import Solver
+    om, dm, a = _channel(oracle, shape)
+    kw = dict(BENCH_KW, frozen_diagonals=0, breakdown_guard=0)
+    f0 = bench.initial_fields(np.asarray(a["cell_centroid"]))
+    s = Solver(dm, NumericalSettings.default(reduction_order=REFERENCE, **kw), 1000.0, 1e-3)
+    s.set_fields(*f0)
+    for it in range(3):
+        std = s.iterate(1, raise_on_error=False)
+        ref = [np.ascontiguousarray(x).copy() for x in f0]
+        sto, _ = oracle.solve_steady(om, *ref, oracle.default_settings(**kw), 1000.0, 1e-3, it + 1)
+        assert std == sto == 0, "iteration %d" % (it + 1)
+        for x, y in zip(s.get_fields(), ref):
+            assert same_bits(x, y), "iteration %d" % (it + 1)
+
+
+def test_bench_channel_product_default_follows_the_reference_trajectory(gpu, oracle):
+    """The timed configuration itself (product default) against the oracle in the reference's mode: the reports of four
+    iterations.  Frozen against in-place diagonals and tree against nalgebra-order sums change the transient in its low
+    digits only on this well-behaved size: 1e-3 relative on the correction norms, 1e-6 of the bulk velocity on the means."""
+    from orc_amd.linear_algebra import breakdown_guard_events
+    from orc_amd.settings import NumericalSettings
+    from orc_amd.solver import Solver
+    om, dm, a = _channel(oracle, (40, 16, 16))
+    f0 = bench.initial_fields(np.asarray(a["cell_centroid"]))
+    ref = [np.ascontiguousarray(x).copy() for x in f0]
+    sto, rep_o = oracle.solve_steady(om, *ref, oracle.default_settings(frozen_diagonals=0, breakdown_guard=0, **BENCH_KW), 1000.0, 1e-3, 4,
+                                     report=True)
+    assert sto == 0
+    ev0 = breakdown_guard_events()
+    s = Solver(dm, NumericalSettings.default(**BENCH_KW), 1000.0, 1e-3)
+    s.set_fields(*f0)
+    std, rep_d = s.iterate(4, report=True, raise_on_error=False)
+    assert std == 0
+    assert breakdown_guard_events() == ev0  # no solve of the timed configuration was frozen
+    u_bulk = abs(rep_o[0, 0])
+    for it in range(4):
+        # device report: means 0-2, Peclet 3-5, velocity correction 6, pressure correction 7; oracle: means 0-2, Peclet 3, 4, 5
+        assert np.allclose(rep_d[it, 0:3], rep_o[it, 0:3], rtol=0, atol=1e-6 * u_bulk), (it, rep_d[it], rep_o[it])
+        assert abs(rep_d[it, 6] - rep_o[it, 4]) <= 1e-3 * rep_o[it, 4], (it, rep_d[it, 6], rep_o[it, 4])
+        assert abs(rep_d[it, 7] - rep_o[it, 5]) <= 1e-3 * rep_o[it, 5], (it, rep_d[it, 7], rep_o[it, 5])
+    for x, y in zip(s.get_fields(), ref):
+        assert H.rel_l2(x, y) < 1e-5

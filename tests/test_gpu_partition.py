@@ -29,6 +29,14 @@ def test_overlapped_level0_product_two_ranks(gpu):
     assert "MP_WORKER_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-4000:]
 
 
+def test_two_ranks_converged_default_stack_matches_the_oracle(gpu):
+    """channel_flow.msh cut in two by orc_mesh_partition (ORC order and RCM), the reference's default stack run partitioned to
+    convergence: u, v, w, p within 1e-6 rel-L2 of the oracle's converged fields (the north-star criterion at N = 2)."""
+    r = launch(2, "gpu_converged", timeout=1500)
+    print(r.stdout[-1500:])
+    assert "MP_WORKER_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-4000:]
+
+
 def test_rccl_selftest_single_rank(gpu):
     """The RCCL branch of HaloPlan::exchange / all-reduce / status agreement on one GPU: a single-rank communicator
     with rank 0 as its own neighbour.  (Two real ranks need two GPUs: the driver's scaling run.)"""

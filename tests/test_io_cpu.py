@@ -335,3 +335,55 @@ def test_mixed_channel_generator_is_conforming_and_readable(oracle, tmp_path):
         assert len(sel) == 0 or set(np.unique(sel).tolist()) == ({3} if name.endswith("_TRI") else {4}), name
     with pytest.raises(Exception):
         write_mixed_channel_msh(path, 10, 3, 2)  # fewer than 20 blocks along x: the regions would collapse
+
+
+def test_poly_channel_generator_agglomerated_polyhedra(oracle, tmp_path):
+    """orc_poly_channel_write_msh (BASELINE config 5: "tet/hex/poly"): the mixed channel with a region of agglomerated
+    polyhedral cells — rhombic dodecahedra of 12 quadrilateral faces in the region's interior — written through triangular
+    and quadrilateral face sections only, which is what the reference's reader parses (io.rs:232-233).  Both readers agree
+    bit for bit, every cell is closed, the volumes fill the box, and no two cells share more than one face (the matrix
+    pattern is "diagonal + one entry per interior face", discretization.rs:312-322)."""
+    from orc_amd import io as orc_io
+    from orc_amd.mesh import write_mixed_channel_msh
+    path = str(tmp_path / "poly.msh")
+    nx, ny, nz = 40, 6, 5
+    nc, nf = write_mixed_channel_msh(path, nx, ny, nz, polyhedra=True)
+    d = orc_io.read_mesh(path)
+    a = d.arrays()
+    om = oracle.Mesh.read(path)
+    ao = om.arrays()
+    assert len(a["cell_volume"]) == nc == om.n_cells and len(a["face_area"]) == nf == om.n_faces
+    for k in ("face_c0", "face_c1", "face_zone", "face_area", "face_normal", "face_centroid", "cell_centroid", "cell_volume", "cell_face_ptr", "cell_faces"):
+        assert np.array_equal(np.asarray(a[k]), np.asarray(ao[k])), k
+    nfc = np.diff(a["cell_face_ptr"])
+    counts = dict(zip(*[x.tolist() for x in np.unique(nfc, return_counts=True)]))
+    # full polyhedra (12 rhombi), partial ones along the region's sides and the walls (a quadrilateral + triangles instead of
+    # the rhombi of the missing pyramids: 13 faces), and the four classic shapes
+    assert counts.get(12, 0) > 0 and max(counts) == 13 and {4, 5, 6} <= set(counts)
+    vol = np.asarray(a["cell_volume"])
+    assert vol.min() > 0 and abs(vol.sum() - 0.002 * 0.001 * 1e-4 * nz) < 1e-13 * vol.sum()
+    c0, c1 = np.asarray(a["face_c0"]), np.asarray(a["face_c1"])
+    An = np.asarray(a["face_normal"]) * np.asarray(a["face_area"])[:, None]
+    S = np.zeros((nc, 3))
+    np.add.at(S, c0, An)
+    m = c1 >= 0
+    np.add.at(S, c1[m], -An[m])
+    assert np.abs(S).max() < 1e-20
+    pairs = np.stack([np.minimum(c0[m], c1[m]), np.maximum(c0[m], c1[m])], axis=1)
+    assert len(np.unique(pairs, axis=0)) == len(pairs)  # one face per pair of neighbours
+    # the 12-face cells: all faces planar quadrilaterals of equal area (rhombi), volume = two blocks' worth
+    fz = np.asarray(a["face_zone"])
+    _, fnp, _ = d.nodes()
+    nn = np.diff(fnp)
+    cfp, cf = np.asarray(a["cell_face_ptr"]), np.asarray(a["cell_faces"])
+    block = 0.002 / nx * 0.001 / ny * 1e-4
+    full = 0
+    for c in np.nonzero(nfc == 12)[0]:
+        faces = cf[cfp[c]:cfp[c + 1]]
+        if set(nn[faces].tolist()) == {4} and np.all(c1[faces] >= 0):  # a whole rhombic dodecahedron: hexahedron + six pyramids
+            full += 1
+            assert abs(vol[c] - 2 * block) < 1e-12 * block
+    assert full > 0
+    for zi, name in enumerate(a["zone_names"]):
+        sel = nn[fz == zi]
+        assert len(sel) == 0 or set(np.unique(sel).tolist()) == ({3} if name.endswith("_TRI") else {4}), name
