@@ -156,6 +156,16 @@ int orc_iterative_solve(int64_t n, const int64_t *row_ptr, const int64_t *col_id
                         const double *b, double *solution_vector /*in/out*/, uint64_t iteration_count,
                         int method /*OrcSolutionMethod*/, double relaxation_factor, double convergence_threshold,
                         int preconditioner /*OrcPreconditionMethod*/);
+/* The same for THREE systems that share one sparsity pattern — what solver::solve_steady's three momentum solves are
+ * (solver.rs:99-136: a_u, a_v, a_w come from one initialize_momentum_matrix pattern, discretization.rs:450-472).  One
+ * column stream and one 24-byte gather per entry serve the three value streams; the fixed iteration count of the BiCGSTAB
+ * arm (linear_algebra.rs:255) keeps the systems in lock-step.  method: ORC_SOLVER_BICGSTAB or ORC_SOLVER_MULTIGRID (tree
+ * reductions, single GPU).  Each system's result is bit-identical to orc_iterative_solve on that system alone;
+ * status_out[k] is system k's verdict (e.g. ORC_ERR_MULTIGRID_DIVERGED), the return value the call's own. */
+int orc_iterative_solve3(int64_t n, const int64_t *row_ptr, const int64_t *col_idx, const double *const values[3],
+                         const double *const b[3], double *const solution_vectors[3] /*in/out*/, uint64_t iteration_count,
+                         int method, double relaxation_factor, double convergence_threshold, int preconditioner,
+                         int status_out[3]);
 /* Process-wide default of OrcSettings.breakdown_guard for orc_iterative_solve (whose signature has no
  * settings argument, like the reference's).  1 (default) = guard on; 0 = NaN like the reference. */
 int orc_set_breakdown_guard(int on);

@@ -23,6 +23,8 @@
 #include <cmath>
 #include <mutex>
 
+#include <thread>
+
 #include "linalg_kernels.hpp"
 
 namespace orc {
@@ -730,6 +732,56 @@ __global__ void prolong_k(const int *__restrict__ choice, const int *__restrict_
 
 __global__ void vec_add_k(double *__restrict__ x, const double *__restrict__ y, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) x[i] += y[i];
+}
+
+// ---- the same for three systems that share a pairing (interleaved vectors, linalg.hpp MatView3): one row of R / R^T per thread,
+// applied to the three systems in the one-system order of additions
+__global__ void restrict3_k(const int *__restrict__ choice, int64_t n_fine, int64_t n_coarse, const double *__restrict__ r3, double *__restrict__ rc3) {
+    for (int64_t I = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; I < n_coarse; I += (int64_t)gridDim.x * blockDim.x) {
+        const RRow R = restriction_row(choice, I, n_fine);
+        double a0 = 0., a1 = 0., a2 = 0.;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+            if (a < R.n) {
+                const int64_t e = 3 * (int64_t)R.idx[a];
+                a0 += R.w[a] * r3[e];
+                a1 += R.w[a] * r3[e + 1];
+                a2 += R.w[a] * r3[e + 2];
+            }
+        rc3[3 * I] = a0; rc3[3 * I + 1] = a1; rc3[3 * I + 2] = a2;
+    }
+}
+// add_to3 += R^T e3
+__global__ void prolong3_k(const int *__restrict__ choice, const int *__restrict__ chooser, int64_t n_fine, const double *__restrict__ e3,
+                           double *__restrict__ add_to3) {
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_fine; j += (int64_t)gridDim.x * blockDim.x) {
+        int J[2];
+        double W[2];
+        const int n = rt_row(choice, chooser, (int)j, J, W);
+        double a0 = 0., a1 = 0., a2 = 0.;
+        for (int a = 0; a < n; ++a) {
+            const int64_t e = 3 * (int64_t)J[a];
+            a0 += W[a] * e3[e];
+            a1 += W[a] * e3[e + 1];
+            a2 += W[a] * e3[e + 2];
+        }
+        add_to3[3 * j] += a0; add_to3[3 * j + 1] += a1; add_to3[3 * j + 2] += a2;
+    }
+}
+// x3[3 i + s] += y_s[i]  (the corrections of the coarser levels, one contiguous vector per system)
+__global__ void vec_add3_k(double *__restrict__ x3, const double *__restrict__ y0, const double *__restrict__ y1, const double *__restrict__ y2, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        x3[3 * i] += y0[i]; x3[3 * i + 1] += y1[i]; x3[3 * i + 2] += y2[i];
+    }
+}
+// counts the entries in which two int arrays differ (pairings / row lengths of sibling systems)
+__global__ void count_diff_k(const int *__restrict__ a, const int *__restrict__ b, int64_t n, int *__restrict__ counter) {
+    int d = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) d += a[i] != b[i];
+    if (d) atomicAdd(counter, d);
+}
+__global__ void nan_to_status3_k(const double *__restrict__ value3, int *status3, int code) {
+    if (blockIdx.x == 0 && threadIdx.x < 3 && isnan(value3[threadIdx.x])) atomicCAS(status3 + threadIdx.x, 0, code);
 }
 
 // ------------------------------------------------------------------ Galerkin product (R A) R^T, one wavefront per coarse row
@@ -2057,6 +2109,221 @@ int multigrid_arm_dev(const MatView &A, const double *b, double *x, uint64_t ite
         stt = h;
     }
     return leave(stt);
+}
+
+
+// ------------------------------------------------------------------ the Multigrid arm for three systems on one pattern
+// linear_algebra.rs:270-296 for the u, v and w momentum systems of one SIMPLE iteration at once (MatView3, linalg.hpp).
+// Per system the operations and their order are those of multigrid_arm_dev / multigrid_solve_dev, so each system's result
+// is bit-identical to its own solve; what changes is who shares a kernel:
+//   * level 0 (the mesh pattern) — smoothing solve and residual for the three systems in lock-step (bicgstab3_dev);
+//   * level 1 — whenever v's and w's fine-level pairings equal u's (the normal case: SiblingPairing), the three Galerkin
+//     operators share their pattern as well and level 1 is solved in lock-step too;
+//   * levels 2 and 3 — the level-1 pairings differ in a few rows, so these stay per system, queued on one stream each;
+//   * the three hierarchies are built by one host thread each (their rounds synchronise their stream) beside the level-0 solve.
+// Anything that does not fit (pairings differ, a level too small) falls back to the per-system coarse part.
+int multigrid_arm3_dev(const MatView3 &A3, const double *const b[3], double *const x[3], uint64_t iteration_count, double relaxation_factor,
+                       double convergence_threshold, int preconditioner, Arena &arena, TripleLane lanes[3], SiblingPairing *sibling, int status_out[3]) {
+    const int64_t n = A3.P.n;
+    for (int k = 0; k < 3; ++k) status_out[k] = ORC_OK;
+    if (n == 0) return ORC_OK;
+    if (!triple_supported()) return set_error(ORC_ERR_BAD_ARGUMENT, "three-system solve: tree reductions on one GPU only");
+    Ctx &g = ctx();
+    hipStream_t st = g.stream;
+    ArenaScope scope(arena);
+    const size_t n3 = (size_t)3 * (size_t)n;
+    const MgParams mp{3 /* MULTIGRID_COARSENING_LEVELS, :10 */, iteration_count, ORC_SOLVER_BICGSTAB, preconditioner, relaxation_factor, convergence_threshold};
+
+    // ---- hierarchies: one thread per system, from now on (they need the matrices only)
+    MatView plain[3];
+    for (int k = 0; k < 3; ++k) {
+        plain[k].P = A3.P;
+        plain[k].val = A3.val[k];
+        plain[k].symmetric = lanes[k].symmetric;
+        plain[k].persistent_pattern = true;
+    }
+    ORC_HIP(hipStreamSynchronize(st));  // the assembled matrices are complete before other streams read them
+    Ctx local[3];
+    std::thread th[3];
+    int st_prep[3] = {ORC_OK, ORC_OK, ORC_OK};
+    bool prepared[3] = {false, false, false};
+    if (sibling) sibling->begin(true);
+    auto prepare = [&](int k) {
+        CtxScope cs(&local[k]);
+        if (hipSetDevice(local[k].device) != hipSuccess) { st_prep[k] = set_error(ORC_ERR_HIP, "hipSetDevice failed in a set-up thread"); return; }
+        lanes[k].hier_arena->release(Arena::Mark{0, 0});
+        int stp = lanes[k].hier_arena->empty() ? lanes[k].hier_arena->reset() : ORC_OK;
+        if (stp == ORC_OK) stp = multigrid_prepare_dev(plain[k], preconditioner, *lanes[k].hier_arena, lanes[k].hierarchy, sibling, k == 0 ? 1 : 2);
+        if (k == 0 && sibling) sibling->finish();  // whatever happened to u: v and w must not wait for a level that will not come
+        if (hipStreamSynchronize(local[k].stream) != hipSuccess && stp == ORC_OK) stp = set_error(ORC_ERR_HIP, "stream synchronisation failed in a set-up thread");
+        st_prep[k] = stp;
+        prepared[k] = true;
+    };
+    struct Joiner {  // no exit path may leave a thread running
+        std::thread *t;
+        ~Joiner() { for (int k = 0; k < 3; ++k) if (t[k].joinable()) t[k].join(); }
+    } joiner{th};
+    for (int k = 0; k < 3; ++k) {
+        local[k] = g;
+        local[k].stream = lanes[k].setup_stream;
+        local[k].last_error.clear();
+        try { th[k] = std::thread(prepare, k); } catch (...) { /* no thread to be had: prepared below, before the join */ }
+    }
+
+    // ---- level 0 in lock-step
+    double *b3, *x3, *r3;
+    int *dev_status;
+    ORC_TRY(arena.alloc(n3, &b3));
+    ORC_TRY(arena.alloc(n3, &x3));
+    ORC_TRY(arena.alloc(n3, &r3));
+    ORC_TRY(arena.alloc((size_t)4, &dev_status));
+    ORC_HIP(hipMemsetAsync(dev_status, 0, 4 * sizeof(int), st));
+    ORC_TRY(interleave3_dev(b[0], b[1], b[2], b3, n));
+    ORC_TRY(interleave3_dev(x[0], x[1], x[2], x3, n));
+    MatView3 V = A3;
+    const double *bp3 = b3;
+    if (preconditioner == ORC_PRECOND_JACOBI) {  // iterative_solve's own scaling of the system the arm sees (:159-166)
+        double *dinv3, *bt3;
+        ORC_TRY(arena.alloc(n3, &dinv3));
+        ORC_TRY(arena.alloc(n3, &bt3));
+        ORC_TRY(diag_inverse3_dev(A3, dinv3));
+        ORC_TRY(scale_vec_dev(dinv3, b3, bt3, (int64_t)n3));
+        V.s1 = dinv3;
+        bp3 = bt3;
+    }
+    ORC_TRY(bicgstab3_dev(V, bp3, x3, iteration_count, preconditioner, arena));  // :273-282 (scaled again inside: Q4)
+    ORC_TRY(residual3_dev(V, bp3, x3, r3));                                       // :283
+
+    // ---- the hierarchies
+    for (int k = 0; k < 3; ++k) {
+        if (th[k].joinable()) th[k].join();
+        if (!prepared[k]) prepare(k);
+    }
+    for (int k = 0; k < 3; ++k)
+        if (st_prep[k] != ORC_OK) { g.last_error = local[k].last_error; return st_prep[k]; }
+    const AmgHierarchy *H[3] = {&lanes[0].hierarchy, &lanes[1].hierarchy, &lanes[2].hierarchy};
+    bool shared = H[0]->n_levels >= 1 && H[1]->n_levels == H[0]->n_levels && H[2]->n_levels == H[0]->n_levels;
+    const int64_t nc = shared ? H[0]->level[0].n : 0;
+    if (shared) {
+        for (int k = 1; k < 3; ++k) shared = shared && H[k]->level[0].n == nc && H[k]->level[0].padded == H[0]->level[0].padded;
+    }
+    if (shared) {  // same pairing and same coarse row lengths => same coarse pattern (the symbolic part of the product depends on nothing else)
+        int *diff;
+        ORC_TRY(arena.alloc((size_t)1, &diff));
+        ORC_HIP(hipMemsetAsync(diff, 0, sizeof(int), st));
+        for (int k = 1; k < 3; ++k) {
+            hipLaunchKernelGGL(count_diff_k, dim3(grid_for(n)), dim3(kBlock), 0, st, (const int *)H[0]->level[0].choice, (const int *)H[k]->level[0].choice, n, diff);
+            hipLaunchKernelGGL(count_diff_k, dim3(grid_for(nc)), dim3(kBlock), 0, st, H[0]->level[0].P.row_len, H[k]->level[0].P.row_len, nc, diff);
+        }
+        int hd = 0;
+        ORC_HIP(hipMemcpyAsync(&hd, diff, sizeof(int), hipMemcpyDeviceToHost, st));
+        ORC_HIP(hipStreamSynchronize(st));
+        shared = hd == 0;
+    }
+    static const bool trace = getenv("ORC_AMG_TRACE") != nullptr;
+    if (trace) fprintf(stderr, "[amg triple n=%lld] level 1 %s\n", (long long)n, shared ? "in lock-step" : "per system");
+
+    hipEvent_t ev_main = nullptr, ev_lane[3] = {nullptr, nullptr, nullptr};
+    struct Events {
+        hipEvent_t *m, *l;
+        ~Events() { if (*m) (void)hipEventDestroy(*m); for (int k = 0; k < 3; ++k) if (l[k]) (void)hipEventDestroy(l[k]); }
+    } events{&ev_main, ev_lane};
+    ORC_HIP(hipEventCreateWithFlags(&ev_main, hipEventDisableTiming));
+    for (int k = 0; k < 3; ++k) ORC_HIP(hipEventCreateWithFlags(&ev_lane[k], hipEventDisableTiming));
+    // every lane stream is drained before its arena is unwound, whatever happens below
+    struct Drain {
+        TripleLane *l;
+        ~Drain() { for (int k = 0; k < 3; ++k) { (void)hipStreamSynchronize(l[k].solve_stream); l[k].vec_arena->release(Arena::Mark{0, 0}); } }
+    } drain{lanes};
+    for (int k = 0; k < 3; ++k) {
+        lanes[k].vec_arena->release(Arena::Mark{0, 0});
+        if (lanes[k].vec_arena->empty()) ORC_TRY(lanes[k].vec_arena->reset());
+        lanes[k].stats = SolveStats();
+        lanes[k].stats.hierarchy = &lanes[k].hierarchy;
+    }
+    // queues `fn` on lane k's solve stream (the calling thread keeps issuing; nothing below synchronises with the host)
+    auto on_lane = [&](int k, auto &&fn) {
+        hipStream_t saved = g.stream;
+        g.stream = lanes[k].solve_stream;
+        const int r = fn();
+        g.stream = saved;
+        return r;
+    };
+
+    if (!shared) {
+        // per-system coarse parts (multigrid_coarse_part_dev) side by side: r and x per system, contiguous
+        double *rk[3];
+        for (int k = 0; k < 3; ++k) ORC_TRY(arena.alloc((size_t)n, &rk[k]));
+        ORC_TRY(deinterleave3_dev(r3, rk[0], rk[1], rk[2], n));
+        ORC_TRY(deinterleave3_dev(x3, x[0], x[1], x[2], n));
+        ORC_HIP(hipEventRecord(ev_main, st));
+        for (int k = 0; k < 3; ++k) {
+            ORC_HIP(hipStreamWaitEvent(lanes[k].solve_stream, ev_main, 0));
+            ORC_TRY(on_lane(k, [&] {
+                return multigrid_coarse_part_dev(plain[k], rk[k], x[k], iteration_count, relaxation_factor, convergence_threshold, preconditioner,
+                                                 *lanes[k].vec_arena, &lanes[k].stats, dev_status + k);
+            }));
+            ORC_HIP(hipEventRecord(ev_lane[k], lanes[k].solve_stream));
+            ORC_HIP(hipStreamWaitEvent(st, ev_lane[k], 0));
+        }
+    } else {
+        // ---- level 1 in lock-step (multigrid_solve_dev, level 1)
+        const AmgHierarchy::Level &L0 = H[0]->level[0];
+        MatView3 Ac3;
+        Ac3.P = L0.P;
+        for (int k = 0; k < 3; ++k) Ac3.val[k] = H[k]->level[0].val;
+        const size_t nc3 = (size_t)3 * (size_t)nc;
+        double *r1, *e1, *partials, *norm3;
+        ORC_TRY(arena.alloc(nc3, &r1));
+        ORC_TRY(arena.alloc(nc3, &e1));
+        ORC_TRY(arena.alloc((size_t)3 * kMaxPartials, &partials));
+        ORC_TRY(arena.alloc((size_t)4, &norm3));
+        hipLaunchKernelGGL(restrict3_k, dim3(grid_for(nc)), dim3(kBlock), 0, st, (const int *)L0.choice, n, nc, (const double *)r3, r1);  // :82
+        ORC_HIP(hipGetLastError());
+        ORC_TRY(vec_fill(e1, 0., (int64_t)nc3));                                                                                      // :86
+        ORC_TRY(bicgstab3_dev(Ac3, r1, e1, iteration_count, preconditioner, arena));                                                  // :87-96
+        ORC_TRY(residual_norm2_3_dev(Ac3, r1, e1, partials, norm3));                                                                  // :97-105
+        hipLaunchKernelGGL(nan_to_status3_k, dim3(1), dim3(64), 0, st, (const double *)norm3, dev_status, (int)ORC_ERR_MULTIGRID_DIVERGED);
+        ORC_HIP(hipGetLastError());
+        for (int k = 0; k < 3; ++k) {
+            lanes[k].stats.amg_levels = 1;
+            lanes[k].stats.amg_rows[1] = nc;
+            lanes[k].stats.amg_nnz[1] = H[k]->level[0].padded;
+            lanes[k].stats.amg_rounds[1] = H[k]->level[0].rounds;
+        }
+        if (1 < mp.max_levels && nc > 16) {  // :109
+            // :110-121 — levels 2.. per system (their level-1 pairings differ), each on its own stream; the recursion receives r'
+            double *rk[3], *ck[3];
+            for (int k = 0; k < 3; ++k) {
+                ORC_TRY(arena.alloc((size_t)nc, &rk[k]));
+                ORC_TRY(arena.alloc((size_t)nc, &ck[k]));
+            }
+            ORC_TRY(deinterleave3_dev(r1, rk[0], rk[1], rk[2], nc));
+            ORC_HIP(hipEventRecord(ev_main, st));
+            for (int k = 0; k < 3; ++k) {
+                MatView Ak;
+                Ak.P = H[k]->level[0].P; Ak.val = H[k]->level[0].val; Ak.pk = H[k]->level[0].pk; Ak.xw = H[k]->level[0].xw; Ak.rows = H[k]->level[0].rows;
+                Ak.symmetric = plain[k].symmetric;
+                ORC_HIP(hipStreamWaitEvent(lanes[k].solve_stream, ev_main, 0));
+                ORC_TRY(on_lane(k, [&] {
+                    return multigrid_solve_dev(Ak, rk[k], 2, mp, convergence_threshold, *lanes[k].vec_arena, &lanes[k].stats, dev_status + k, ck[k], nullptr, nullptr);
+                }));
+                ORC_HIP(hipEventRecord(ev_lane[k], lanes[k].solve_stream));
+                ORC_HIP(hipStreamWaitEvent(st, ev_lane[k], 0));
+            }
+            hipLaunchKernelGGL(vec_add3_k, dim3(grid_for(nc)), dim3(kBlock), 0, st, e1, (const double *)ck[0], (const double *)ck[1], (const double *)ck[2], nc);  // e' += ...
+            ORC_HIP(hipGetLastError());
+            ORC_TRY(bicgstab3_dev(Ac3, r1, e1, iteration_count, preconditioner, arena));  // :123-132
+        }
+        hipLaunchKernelGGL(prolong3_k, dim3(grid_for(n)), dim3(kBlock), 0, st, (const int *)L0.choice, (const int *)L0.chooser, n, (const double *)e1, x3);  // :140, :284
+        ORC_HIP(hipGetLastError());
+        ORC_TRY(deinterleave3_dev(x3, x[0], x[1], x[2], n));
+    }
+    int h[4] = {0, 0, 0, 0};
+    ORC_HIP(hipMemcpyAsync(h, dev_status, sizeof(h), hipMemcpyDeviceToHost, st));
+    ORC_HIP(hipStreamSynchronize(st));
+    for (int k = 0; k < 3; ++k) status_out[k] = h[k];
+    return ORC_OK;
 }
 
 }  // namespace orc

@@ -44,6 +44,71 @@ int orc_iterative_solve(int64_t n, const int64_t *row_ptr, const int64_t *col_id
     return st != ORC_OK ? st : st2;
 }
 
+// Three systems on one pattern (the u, v, w momentum matrices): values, b and x per system, contiguous, in CSR (ORC) order.
+int orc_iterative_solve3(int64_t n, const int64_t *row_ptr, const int64_t *col_idx, const double *const values[3], const double *const b[3],
+                         double *const solution_vectors[3], uint64_t iteration_count, int method, double relaxation_factor,
+                         double convergence_threshold, int preconditioner, int status_out[3]) {
+    using namespace orc;
+    ORC_TRY(ensure_init());
+    if (n < 0 || !row_ptr || (!col_idx && n > 0) || !values || !b || !solution_vectors) return set_error(ORC_ERR_BAD_ARGUMENT, "null argument");
+    if (method != ORC_SOLVER_BICGSTAB && method != ORC_SOLVER_MULTIGRID)
+        return set_error(ORC_ERR_BAD_ARGUMENT, "orc_iterative_solve3: BiCGSTAB and Multigrid arms only (method %d)", method);
+    SellMatrix pat;
+    ORC_TRY(sell_from_csr_host(n, n, row_ptr, col_idx, pat));
+    const size_t nn = (size_t)std::max<int64_t>(n, 1);
+    DevBuf<double> csr_vals, vals[3], db[3], dx[3];
+    MatView3 A3;
+    A3.P = pat.dev();
+    for (int k = 0; k < 3; ++k) {
+        ORC_TRY(csr_vals.upload(values[k], (size_t)pat.nnz));
+        ORC_TRY(vals[k].alloc((size_t)std::max<int64_t>(pat.padded, 1)));
+        ORC_TRY(sell_import_values(pat, csr_vals.p, vals[k].p));
+        ORC_HIP(hipStreamSynchronize(ctx().stream));
+        ORC_TRY(db[k].alloc(nn));
+        ORC_TRY(dx[k].alloc(nn));
+        ORC_TRY(db[k].upload(b[k], (size_t)n));
+        ORC_TRY(dx[k].upload(solution_vectors[k], (size_t)n));
+        A3.val[k] = vals[k].p;
+    }
+    Arena arena;
+    int st = ORC_OK;
+    int st3[3] = {ORC_OK, ORC_OK, ORC_OK};
+    if (method == ORC_SOLVER_BICGSTAB) {
+        double *b3, *x3;
+        ORC_TRY(arena.alloc(3 * nn, &b3));
+        ORC_TRY(arena.alloc(3 * nn, &x3));
+        ORC_TRY(interleave3_dev(db[0].p, db[1].p, db[2].p, b3, n));
+        ORC_TRY(interleave3_dev(dx[0].p, dx[1].p, dx[2].p, x3, n));
+        st = bicgstab3_dev(A3, b3, x3, iteration_count, preconditioner, arena);
+        if (st == ORC_OK) st = deinterleave3_dev(x3, dx[0].p, dx[1].p, dx[2].p, n);
+    } else {
+        TripleLane lanes[3];
+        Arena hier[3], vec[3];
+        SiblingPairing sibling;
+        hipStream_t streams[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        for (int k = 0; k < 6 && st == ORC_OK; ++k)
+            if (hipStreamCreateWithFlags(&streams[k], hipStreamNonBlocking) != hipSuccess) st = set_error(ORC_ERR_HIP, "hipStreamCreate failed");
+        for (int k = 0; k < 3; ++k) {
+            lanes[k].setup_stream = streams[2 * k]; lanes[k].solve_stream = streams[2 * k + 1];
+            lanes[k].hier_arena = &hier[k]; lanes[k].vec_arena = &vec[k];
+            lanes[k].symmetric = pat.symmetric;
+        }
+        const double *bb[3] = {db[0].p, db[1].p, db[2].p};
+        double *xx[3] = {dx[0].p, dx[1].p, dx[2].p};
+        if (st == ORC_OK)
+            st = multigrid_arm3_dev(A3, bb, xx, iteration_count, relaxation_factor, convergence_threshold, preconditioner, arena, lanes, &sibling, st3);
+        (void)hipDeviceSynchronize();
+        for (int k = 0; k < 6; ++k)
+            if (streams[k]) (void)hipStreamDestroy(streams[k]);
+    }
+    for (int k = 0; k < 3; ++k) {
+        const int st2 = dx[k].download(solution_vectors[k], (size_t)n);
+        if (st == ORC_OK) st = st2;
+        if (status_out) status_out[k] = st3[k];
+    }
+    return st;
+}
+
 int orc_csr_spmv(int64_t n, const int64_t *row_ptr, const int64_t *col_idx, const double *values, const double *x, double *y,
                  int reps, double *avg_ms) {
     using namespace orc;

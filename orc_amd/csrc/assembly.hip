@@ -937,6 +937,7 @@ int solver_init(SolverState &s, OrcMesh *m, const OrcSettings *settings, double 
     s.rho = rho; s.mu = mu; s.n = m->n_cells; s.n_own = m->n_own;
     s.concurrent_momentum = !(getenv("ORC_CONCURRENT_MOMENTUM") && atoi(getenv("ORC_CONCURRENT_MOMENTUM")) == 0);
     s.two_stream_multigrid = !(getenv("ORC_TWO_STREAM_MULTIGRID") && atoi(getenv("ORC_TWO_STREAM_MULTIGRID")) == 0);
+    s.triple_momentum = !(getenv("ORC_TRIPLE_MOMENTUM") && atoi(getenv("ORC_TRIPLE_MOMENTUM")) == 0);
     s.early_p_hierarchy = !(getenv("ORC_EARLY_P_HIERARCHY") && atoi(getenv("ORC_EARLY_P_HIERARCHY")) == 0);
     s.sibling_pairing = !(getenv("ORC_AMG_SIBLING") && atoi(getenv("ORC_AMG_SIBLING")) == 0);
     ORC_TRY(validate_settings(s.settings));
@@ -1432,6 +1433,56 @@ static int solve_momentum_concurrently(SolverState &s, bool setup_first, Prepare
     return ORC_OK;
 }
 
+// The three momentum systems in lock-step (linalg.hpp MatView3 / multigrid_arm3_dev, bicgstab3_dev): single GPU, tree
+// reductions, Multigrid or BiCGSTAB solver.  Returns the first non-zero status in u, v, w order, like the sequential loop.
+static int solve_momentum_triple(SolverState &s) {
+    Ctx &g = ctx();
+    const OrcSettings &t = s.settings;
+    g.breakdown_guard = t.breakdown_guard != 0;
+    g.reduction_order = t.reduction_order;
+    MatView3 A3;
+    A3.P = s.mesh->pat.dev();
+    A3.val[0] = s.a_u.p; A3.val[1] = s.a_v.p; A3.val[2] = s.a_w.p;
+    const double *b[3] = {s.b_u.p, s.b_v.p, s.b_w.p};
+    double *x[3] = {s.u.p, s.v.p, s.w.p};
+    if (s.arena.empty()) ORC_TRY(s.arena.reset());
+    if (t.solver_type == ORC_SOLVER_BICGSTAB) {
+        ArenaScope scope(s.arena);
+        const size_t n3 = (size_t)3 * (size_t)s.n_own;
+        double *b3, *x3;
+        ORC_TRY(s.arena.alloc(n3, &b3));
+        ORC_TRY(s.arena.alloc(n3, &x3));
+        ORC_TRY(interleave3_dev(b[0], b[1], b[2], b3, s.n_own));
+        ORC_TRY(interleave3_dev(x[0], x[1], x[2], x3, s.n_own));
+        ORC_TRY(bicgstab3_dev(A3, b3, x3, t.iterations, t.preconditioner, s.arena));
+        ORC_TRY(deinterleave3_dev(x3, x[0], x[1], x[2], s.n_own));
+        ORC_HIP(hipStreamSynchronize(g.stream));
+        return ORC_OK;
+    }
+    for (int k = 0; k < 3; ++k) {
+        SolverState::Lane &L = s.lanes[k];
+        if (!L.stream) ORC_TRY(create_stream(&L.stream, kSetupStream, k));
+        if (!L.side.stream) {
+            ORC_TRY(create_stream(&L.side.stream, kSolveStream, k));
+            ORC_HIP(hipEventCreateWithFlags(&L.side.ev_setup, hipEventDisableTiming));
+            ORC_HIP(hipEventCreateWithFlags(&L.side.ev_solve, hipEventDisableTiming));
+            L.side.arena = &L.side_arena;
+        }
+        s.triple[k].setup_stream = L.stream;
+        s.triple[k].solve_stream = L.side.stream;
+        s.triple[k].hier_arena = &L.arena;
+        s.triple[k].vec_arena = &L.side_arena;
+        s.triple[k].symmetric = s.mesh->pat.symmetric;
+    }
+    int st3[3] = {ORC_OK, ORC_OK, ORC_OK};
+    ORC_TRY(multigrid_arm3_dev(A3, b, x, t.iterations, t.relaxation, t.relative_convergence_threshold, t.preconditioner, s.arena, s.triple,
+                               s.sibling_pairing ? &s.sibling : nullptr, st3));
+    s.stats = s.triple[0].stats;
+    for (int k = 0; k < 3; ++k)
+        if (st3[k] != ORC_OK) return st3[k];
+    return ORC_OK;
+}
+
 static void debug_field(SolverState &s, const char *name, const DevBuf<double> &f) {
     std::vector<double> h((size_t)s.n);
     (void)f.download(h.data(), (size_t)s.n);
@@ -1470,7 +1521,11 @@ int solver_iterate(SolverState &s, uint64_t iterations, double *report) {
                               (method == ORC_SOLVER_MULTIGRID || method == ORC_SOLVER_BICGSTAB || method == ORC_SOLVER_JACOBI ||
                                method == ORC_SOLVER_MULTIGRID_GS || method == ORC_SOLVER_BICGSTAB_GS_PRECOND || method == ORC_SOLVER_MULTICOLOR_GS);
         const bool lanes_partitioned = s.concurrent_momentum && H.active() && !dbg && !ctx().profile && method == ORC_SOLVER_MULTIGRID;
-        if (lanes_ok) {
+        const bool triple_ok = lanes_ok && s.triple_momentum && triple_supported() && s.settings.reduction_order != ORC_REDUCTION_REFERENCE &&
+                               (method == ORC_SOLVER_MULTIGRID || method == ORC_SOLVER_BICGSTAB);
+        if (triple_ok) {
+            ORC_TRY(solve_momentum_triple(s));                          // :99-136, the three systems in lock-step on their shared pattern
+        } else if (lanes_ok) {
             static const int setup_first_env = getenv("ORC_SETUP_FIRST") ? atoi(getenv("ORC_SETUP_FIRST")) : 0;  // measured: exact, +8 % wall (1.24 s against 1.15 s)
             const bool setup_first = setup_first_env != 0 && method == ORC_SOLVER_MULTIGRID;
             ORC_TRY(solve_momentum_concurrently(s, setup_first, prep.running ? &prep : nullptr));  // :99-136, the three systems side by side

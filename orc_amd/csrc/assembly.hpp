@@ -86,6 +86,11 @@ struct SolverState {
         AmgHierarchy hierarchy;        // partitioned runs: built by the lane while the library stream does the level-0 work
         hipEvent_t level0_done = nullptr;
     } lanes[3];
+    // The three momentum systems solved in lock-step on their shared pattern (MatView3, linalg.hpp): one column stream and one
+    // 24-byte gather per entry for three value streams on level 0 and, when the pairings coincide, on level 1.  Uses the
+    // lanes' streams and arenas for the hierarchy set-ups and the per-system coarse levels.  ORC_TRIPLE_MOMENTUM=0: off.
+    TripleLane triple[3];
+    bool triple_momentum = true;
     // The pressure-correction matrix depends on the momentum diagonals and the geometry only (discretization.rs:401-438;
     // the new velocities enter its RHS), so its Multigrid hierarchy is built on a stream of its own while the momentum
     // systems are being solved, and the p' solve finds it ready.

@@ -531,7 +531,12 @@ __global__ __launch_bounds__(kBlock) void bicg_p_k(double *__restrict__ scal, in
                                                    const double *__restrict__ nu, double *__restrict__ p, int64_t n, int guard,
                                                    const double *__restrict__ fold, int fold_count) {
     __shared__ double lds16[16];
-    if (bicg_frozen(scal, guard)) return;
+    if (bicg_frozen(scal, guard)) {
+        // bicg_xr_k took x = h, r = s and published through S_FROZEN2, which it does not read itself: promote it, or the next
+        // iteration's bicg_xr_k would add alpha p once more (every workgroup of THIS launch returns here either way)
+        if (guard && scal[S_FROZEN2] != 0. && blockIdx.x == 0 && threadIdx.x == 0) scal[S_FROZEN] = 1.;
+        return;
+    }
     const int64_t n2 = n >> 1, stride = (int64_t)gridDim.x * blockDim.x;
     double2 *p2 = reinterpret_cast<double2 *>(p);
     const double2 *r2 = reinterpret_cast<const double2 *>(r), *nu2 = reinterpret_cast<const double2 *>(nu);
@@ -661,6 +666,423 @@ int bench_bicgstab_dev(const MatView &A, const double *b, double *x, int reps, A
     arena.release(mk);
     return ORC_OK;
 }
+
+
+// ------------------------------------------------------------------ three systems in lock-step (MatView3, linalg.hpp)
+// The u, v and w momentum systems of an iteration: one pattern, three value arrays, interleaved vectors.  Every kernel
+// below keeps, per system, the thread -> element map, the order of the additions and the fold of its one-system
+// counterpart above, so a system solved here and the same system solved alone agree in every bit
+// (tests/test_gpu_triple.py).  Scalars of system s: scal3[idx * 3 + s].
+bool triple_supported() { return ctx().reduction_order != ORC_REDUCTION_REFERENCE && ctx().world == 1; }
+
+struct EpiStore3 {
+    static constexpr int kReductions = 0;
+    double *y3;
+    __device__ __forceinline__ void apply(int64_t row, const double (&acc)[3], double (&)[3][2]) const {
+        reinterpret_cast<Vec3d *>(y3)[row] = Vec3d{acc[0], acc[1], acc[2]};
+    }
+};
+struct EpiStoreSum3 {
+    static constexpr int kReductions = 1;
+    double *y3;
+    __device__ __forceinline__ void apply(int64_t row, const double (&acc)[3], double (&red)[3][2]) const {
+        reinterpret_cast<Vec3d *>(y3)[row] = Vec3d{acc[0], acc[1], acc[2]};
+        red[0][0] += acc[0]; red[1][0] += acc[1]; red[2][0] += acc[2];
+    }
+};
+struct EpiResidual3 {
+    static constexpr int kReductions = 1;
+    const double *b3;
+    double *r3, *p3;
+    __device__ __forceinline__ void apply(int64_t row, const double (&acc)[3], double (&red)[3][2]) const {
+        const Vec3d b = reinterpret_cast<const Vec3d *>(b3)[row];
+        const Vec3d v = {b.a - acc[0], b.b - acc[1], b.c - acc[2]};
+        reinterpret_cast<Vec3d *>(r3)[row] = v;
+        if (p3) reinterpret_cast<Vec3d *>(p3)[row] = v;
+        red[0][0] += v.a; red[1][0] += v.b; red[2][0] += v.c;
+    }
+};
+struct EpiResidualNorm3 {
+    static constexpr int kReductions = 1;
+    const double *b3;
+    __device__ __forceinline__ void apply(int64_t row, const double (&acc)[3], double (&red)[3][2]) const {
+        const Vec3d b = reinterpret_cast<const Vec3d *>(b3)[row];
+        const double v0 = b.a - acc[0], v1 = b.b - acc[1], v2 = b.c - acc[2];
+        red[0][0] += v0 * v0; red[1][0] += v1 * v1; red[2][0] += v2 * v2;
+    }
+};
+struct EpiTs3 {
+    static constexpr int kReductions = 2;
+    const double *s3;
+    double *t3;
+    __device__ __forceinline__ void apply(int64_t row, const double (&acc)[3], double (&red)[3][2]) const {
+        const Vec3d sv = reinterpret_cast<const Vec3d *>(s3)[row];
+        reinterpret_cast<Vec3d *>(t3)[row] = Vec3d{acc[0], acc[1], acc[2]};
+        red[0][0] += acc[0] * sv.a; red[0][1] += acc[0] * acc[0];
+        red[1][0] += acc[1] * sv.b; red[1][1] += acc[1] * acc[1];
+        red[2][0] += acc[2] * sv.c; red[2][1] += acc[2] * acc[2];
+    }
+};
+
+template <class Epi3>
+static int launch_spmv3(const MatView3 &A, const double *x3, const Epi3 &epi, double *partials, int *grid_out) {
+    const int g = spmv_grid(A.P.n_slices);  // the one-system grid: same walk, same partial sums
+    if (grid_out) *grid_out = g;
+    if (A.P.n == 0) return ORC_OK;
+    static const int chunk = getenv("ORC_SPMV3_CHUNK") ? atoi(getenv("ORC_SPMV3_CHUNK")) : 4;
+    if (chunk == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 8>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
+    else if (chunk == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 2>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
+    ORC_HIP(hipGetLastError());
+    return ORC_OK;
+}
+
+int spmv3_dev(const MatView3 &A, const double *x3, double *y3) { return launch_spmv3(A, x3, EpiStore3{y3}, nullptr, nullptr); }
+
+static double *triple_scratch() {  // partial sums nobody reads (residual3_dev); one allocation per process
+    static double *const p = [] {
+        double *q = nullptr;
+        return hipMalloc((void **)&q, sizeof(double) * 3 * kMaxPartials) == hipSuccess ? q : nullptr;
+    }();
+    return p;
+}
+int residual3_dev(const MatView3 &A, const double *b3, const double *x3, double *r3) {
+    double *dummy = triple_scratch();
+    if (!dummy) return set_error(ORC_ERR_HIP, "hipMalloc of the residual scratch failed");
+    return launch_spmv3(A, x3, EpiResidual3{b3, r3, nullptr}, dummy, nullptr);
+}
+int residual_norm2_3_dev(const MatView3 &A, const double *b3, const double *x3, double *partials, double *out3) {
+    int g = 0;
+    ORC_TRY(launch_spmv3(A, x3, EpiResidualNorm3{b3}, partials, &g));
+    return reduce_partials(partials, g, 3, out3, false);
+}
+
+__global__ void interleave3_k(const double *__restrict__ a, const double *__restrict__ b, const double *__restrict__ c, double *__restrict__ out3, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        reinterpret_cast<Vec3d *>(out3)[i] = Vec3d{a[i], b[i], c[i]};
+}
+__global__ void deinterleave3_k(const double *__restrict__ in3, double *__restrict__ a, double *__restrict__ b, double *__restrict__ c, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const Vec3d v = reinterpret_cast<const Vec3d *>(in3)[i];
+        if (a) a[i] = v.a;
+        if (b) b[i] = v.b;
+        if (c) c[i] = v.c;
+    }
+}
+int interleave3_dev(const double *a, const double *b, const double *c, double *out3, int64_t n) {
+    if (n == 0) return ORC_OK;
+    hipLaunchKernelGGL(interleave3_k, dim3(grid_for(n)), dim3(kBlock), 0, ctx().stream, a, b, c, out3, n);
+    ORC_HIP(hipGetLastError());
+    return ORC_OK;
+}
+int deinterleave3_dev(const double *in3, double *a, double *b, double *c, int64_t n) {
+    if (n == 0) return ORC_OK;
+    hipLaunchKernelGGL(deinterleave3_k, dim3(grid_for(n)), dim3(kBlock), 0, ctx().stream, in3, a, b, c, n);
+    ORC_HIP(hipGetLastError());
+    return ORC_OK;
+}
+
+__global__ void diag_inverse3_k(MatView3 A, double *__restrict__ dinv3) {
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < A.P.n; r += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t d = A.P.diag_pos[r];
+        double o[3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            double v = 0.;
+            if (d >= 0) {  // view_value per system
+                v = A.val[s][d];
+                if (A.s1) v = A.s1[3 * r + s] * v;
+                if (A.s2) v = A.s2[3 * r + s] * v;
+                v = 1. / v;
+            }
+            o[s] = v;
+        }
+        reinterpret_cast<Vec3d *>(dinv3)[r] = Vec3d{o[0], o[1], o[2]};
+    }
+}
+int diag_inverse3_dev(const MatView3 &A, double *dinv3) {
+    if (A.P.n == 0) return ORC_OK;
+    hipLaunchKernelGGL(diag_inverse3_k, dim3(grid_for(A.P.n)), dim3(kBlock), 0, ctx().stream, A, dinv3);
+    ORC_HIP(hipGetLastError());
+    return ORC_OK;
+}
+
+#define SC3(idx, s) ((idx) * 3 + (s))
+__device__ __forceinline__ bool bicg_frozen3(const double *__restrict__ scal3, int s, int guard) {
+    return guard && (scal3[SC3(S_FROZEN, s)] != 0. || scal3[SC3(S_FROZEN2, s)] != 0.);
+}
+
+// bicg_s_k for three systems: s = r - alpha nu, alpha = rho / sum(nu); fold: the product's partial sums, system s at fold + s * fold_count
+__global__ __launch_bounds__(kBlock) void bicg_s3_k(double *__restrict__ scal3, int rho_idx, const double *__restrict__ r3, const double *__restrict__ nu3,
+                                                    double *__restrict__ s3, int64_t n, int guard, const double *__restrict__ fold, int fold_count) {
+    __shared__ double lds16[16];
+    const int64_t n2 = n >> 1, stride = (int64_t)gridDim.x * blockDim.x;
+    const double2 *r2 = reinterpret_cast<const double2 *>(r3), *nu2 = reinterpret_cast<const double2 *>(nu3);
+    double2 *s2 = reinterpret_cast<double2 *>(s3);
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double2 a0, a1, a2, b0, b1, b2;
+    a0 = a1 = a2 = b0 = b1 = b2 = make_double2(0., 0.);
+    if (i < n2) { a0 = r2[3 * i]; a1 = r2[3 * i + 1]; a2 = r2[3 * i + 2]; b0 = nu2[3 * i]; b1 = nu2[3 * i + 1]; b2 = nu2[3 * i + 2]; }
+    double alpha[3];
+    bool act[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const bool frz = bicg_frozen3(scal3, s, guard);
+        const double sum_nu = fold_partials_block(fold + (size_t)s * fold_count, fold_count, lds16);
+        const double rho = scal3[SC3(rho_idx, s)];
+        alpha[s] = rho / sum_nu;
+        const bool bad = guard && !(finite_nonzero(rho) && finite_nonzero(sum_nu) && isfinite(alpha[s]));
+        act[s] = !frz && !bad;
+        if (blockIdx.x == 0 && threadIdx.x == 0 && !frz) {
+            scal3[SC3(S_SUM_NU, s)] = sum_nu;
+            if (bad) scal3[SC3(S_FROZEN, s)] = 1.;
+        }
+    }
+    if (act[0] && act[1] && act[2]) {
+        // a pair of rows = six consecutive doubles: systems (0,1) (2,0) (1,2)
+        while (i < n2) {
+            const int64_t nx = i + stride;
+            double2 an0, an1, an2, bn0, bn1, bn2;
+            an0 = an1 = an2 = bn0 = bn1 = bn2 = make_double2(0., 0.);
+            if (nx < n2) { an0 = r2[3 * nx]; an1 = r2[3 * nx + 1]; an2 = r2[3 * nx + 2]; bn0 = nu2[3 * nx]; bn1 = nu2[3 * nx + 1]; bn2 = nu2[3 * nx + 2]; }
+            s2[3 * i] = make_double2(a0.x - alpha[0] * b0.x, a0.y - alpha[1] * b0.y);
+            s2[3 * i + 1] = make_double2(a1.x - alpha[2] * b1.x, a1.y - alpha[0] * b1.y);
+            s2[3 * i + 2] = make_double2(a2.x - alpha[1] * b2.x, a2.y - alpha[2] * b2.y);
+            a0 = an0; a1 = an1; a2 = an2; b0 = bn0; b1 = bn1; b2 = bn2; i = nx;
+        }
+        if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+#pragma unroll
+            for (int s = 0; s < 3; ++s) s3[3 * (n - 1) + s] = r3[3 * (n - 1) + s] - alpha[s] * nu3[3 * (n - 1) + s];
+        }
+    } else {  // a system broke down or is frozen: element by element, the others as usual
+        for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+                if (act[s]) s3[3 * e + s] = r3[3 * e + s] - alpha[s] * nu3[3 * e + s];
+        }
+    }
+}
+
+// bicg_xr_k for three systems.  partials: system s at partials + s * gridDim.x; fold: the product's sums, (t.s, t.t) of system s
+// at fold + (2 s) * fold_count and fold + (2 s + 1) * fold_count
+__global__ __launch_bounds__(kBlock) void bicg_xr3_k(double *__restrict__ scal3, int rho_idx, double *__restrict__ x3, const double *__restrict__ p3,
+                                                     const double *__restrict__ s3, const double *__restrict__ t3, double *__restrict__ r3, int64_t n,
+                                                     double *__restrict__ partials, int guard, const double *__restrict__ fold, int fold_count) {
+    __shared__ double lds[8];
+    __shared__ double lds16[16];
+    const int64_t n2 = n >> 1, stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double2 *x2 = reinterpret_cast<double2 *>(x3), *r2 = reinterpret_cast<double2 *>(r3);
+    const double2 *p2 = reinterpret_cast<const double2 *>(p3), *s2 = reinterpret_cast<const double2 *>(s3), *t2 = reinterpret_cast<const double2 *>(t3);
+    double alpha[3], omega[3];
+    int state[3];  // 0 = normal, 1 = t = A s vanished or overflowed (x = h, r = s, stop), 2 = frozen (no-op)
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const bool frz = guard && scal3[SC3(S_FROZEN, s)] != 0.;
+        const double ts = fold_partials_block(fold + (size_t)(2 * s) * fold_count, fold_count, lds16);
+        const double tt = fold_partials_block(fold + (size_t)(2 * s + 1) * fold_count, fold_count, lds16);
+        alpha[s] = scal3[SC3(rho_idx, s)] / scal3[SC3(S_SUM_NU, s)];
+        omega[s] = ts / tt;
+        const bool bad = guard && !(finite_nonzero(tt) && isfinite(omega[s]));
+        state[s] = frz ? 2 : (bad ? 1 : 0);
+        if (blockIdx.x == 0 && threadIdx.x == 0 && !frz) { scal3[SC3(S_TS, s)] = ts; scal3[SC3(S_TT, s)] = tt; }
+    }
+    double acc[3] = {0., 0., 0.};
+    if (state[0] == 0 && state[1] == 0 && state[2] == 0) {
+        int64_t i = i0;
+        while (i < n2) {
+            const double2 xa = x2[3 * i], xb = x2[3 * i + 1], xc = x2[3 * i + 2];
+            const double2 pa = p2[3 * i], pb = p2[3 * i + 1], pc = p2[3 * i + 2];
+            const double2 sa = s2[3 * i], sb = s2[3 * i + 1], sc = s2[3 * i + 2];
+            const double2 ta = t2[3 * i], tb = t2[3 * i + 1], tc = t2[3 * i + 2];
+            // row 2i: (xa.x, xa.y, xb.x) = systems 0, 1, 2; row 2i + 1: (xb.y, xc.x, xc.y)
+            const double h00 = xa.x + alpha[0] * pa.x, h01 = xa.y + alpha[1] * pa.y, h02 = xb.x + alpha[2] * pb.x;
+            const double h10 = xb.y + alpha[0] * pb.y, h11 = xc.x + alpha[1] * pc.x, h12 = xc.y + alpha[2] * pc.y;
+            x2[3 * i] = make_double2(h00 + omega[0] * sa.x, h01 + omega[1] * sa.y);
+            x2[3 * i + 1] = make_double2(h02 + omega[2] * sb.x, h10 + omega[0] * sb.y);
+            x2[3 * i + 2] = make_double2(h11 + omega[1] * sc.x, h12 + omega[2] * sc.y);
+            const double q00 = sa.x - omega[0] * ta.x, q01 = sa.y - omega[1] * ta.y, q02 = sb.x - omega[2] * tb.x;
+            const double q10 = sb.y - omega[0] * tb.y, q11 = sc.x - omega[1] * tc.x, q12 = sc.y - omega[2] * tc.y;
+            r2[3 * i] = make_double2(q00, q01);
+            r2[3 * i + 1] = make_double2(q02, q10);
+            r2[3 * i + 2] = make_double2(q11, q12);
+            acc[0] += q00; acc[0] += q10;
+            acc[1] += q01; acc[1] += q11;
+            acc[2] += q02; acc[2] += q12;
+            i += stride;
+        }
+        if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int64_t e = 3 * (n - 1) + s;
+                const double h = x3[e] + alpha[s] * p3[e];
+                const double si = s3[e];
+                x3[e] = h + omega[s] * si;
+                const double ri = si - omega[s] * t3[e];
+                r3[e] = ri;
+                acc[s] += ri;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            if (state[s] == 1) {  // bicg_xr_k's breakdown branch: one element per step of the grid-stride loop
+                for (int64_t e = i0; e < n; e += stride) {
+                    x3[3 * e + s] = x3[3 * e + s] + alpha[s] * p3[3 * e + s];
+                    const double si = s3[3 * e + s];
+                    r3[3 * e + s] = si;
+                    acc[s] += si;
+                }
+                if (blockIdx.x == 0 && threadIdx.x == 0) scal3[SC3(S_FROZEN2, s)] = 1.;
+            } else if (state[s] == 0) {  // bicg_xr_k's pair loop, this system's entries only
+                for (int64_t i = i0; i < n2; i += stride) {
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2) {
+                        const int64_t e = 3 * (2 * i + h2) + s;
+                        const double h = x3[e] + alpha[s] * p3[e];
+                        const double si = s3[e];
+                        x3[e] = h + omega[s] * si;
+                        const double q = si - omega[s] * t3[e];
+                        r3[e] = q;
+                        acc[s] += q;
+                    }
+                }
+                if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+                    const int64_t e = 3 * (n - 1) + s;
+                    const double h = x3[e] + alpha[s] * p3[e];
+                    const double si = s3[e];
+                    x3[e] = h + omega[s] * si;
+                    const double ri = si - omega[s] * t3[e];
+                    r3[e] = ri;
+                    acc[s] += ri;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const double tsum = block_sum(acc[s], lds);
+        if (threadIdx.x == 0 && state[s] != 2) partials[(size_t)s * gridDim.x + blockIdx.x] = tsum;
+    }
+}
+
+// bicg_p_k for three systems; fold: bicg_xr3_k's partial sums, system s at fold + s * fold_count
+__global__ __launch_bounds__(kBlock) void bicg_p3_k(double *__restrict__ scal3, int rho_prev_idx, int rho_idx, const double *__restrict__ r3,
+                                                    const double *__restrict__ nu3, double *__restrict__ p3, int64_t n, int guard,
+                                                    const double *__restrict__ fold, int fold_count) {
+    __shared__ double lds16[16];
+    const int64_t n2 = n >> 1, stride = (int64_t)gridDim.x * blockDim.x;
+    double2 *p2 = reinterpret_cast<double2 *>(p3);
+    const double2 *r2 = reinterpret_cast<const double2 *>(r3), *nu2 = reinterpret_cast<const double2 *>(nu3);
+    double beta[3], omega[3];
+    bool act[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const bool frz = bicg_frozen3(scal3, s, guard);
+        const double rho = fold_partials_block(fold + (size_t)s * fold_count, fold_count, lds16);
+        const double rho_prev = scal3[SC3(rho_prev_idx, s)];
+        const double alpha = rho_prev / scal3[SC3(S_SUM_NU, s)];
+        omega[s] = scal3[SC3(S_TS, s)] / scal3[SC3(S_TT, s)];
+        beta[s] = rho / rho_prev * alpha / omega[s];
+        const bool bad = guard && !(finite_nonzero(omega[s]) && isfinite(beta[s]));
+        act[s] = !frz && !bad;
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            if (!frz) {
+                scal3[SC3(rho_idx, s)] = rho;
+                if (bad) scal3[SC3(S_FROZEN, s)] = 1.;
+            } else if (scal3[SC3(S_FROZEN2, s)] != 0.) {
+                scal3[SC3(S_FROZEN, s)] = 1.;  // see bicg_p_k
+            }
+        }
+    }
+    if (act[0] && act[1] && act[2]) {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+            const double2 ra = r2[3 * i], rb = r2[3 * i + 1], rc = r2[3 * i + 2];
+            const double2 pa = p2[3 * i], pb = p2[3 * i + 1], pc = p2[3 * i + 2];
+            const double2 na = nu2[3 * i], nb = nu2[3 * i + 1], nc = nu2[3 * i + 2];
+            p2[3 * i] = make_double2(ra.x + beta[0] * (pa.x - omega[0] * na.x), ra.y + beta[1] * (pa.y - omega[1] * na.y));
+            p2[3 * i + 1] = make_double2(rb.x + beta[2] * (pb.x - omega[2] * nb.x), rb.y + beta[0] * (pb.y - omega[0] * nb.y));
+            p2[3 * i + 2] = make_double2(rc.x + beta[1] * (pc.x - omega[1] * nc.x), rc.y + beta[2] * (pc.y - omega[2] * nc.y));
+        }
+        if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int64_t e = 3 * (n - 1) + s;
+                p3[e] = r3[e] + beta[s] * (p3[e] - omega[s] * nu3[e]);
+            }
+        }
+    } else {
+        for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+                if (act[s]) p3[3 * e + s] = r3[3 * e + s] + beta[s] * (p3[3 * e + s] - omega[s] * nu3[3 * e + s]);
+        }
+    }
+}
+
+__global__ void guard_event3_k(const double *__restrict__ scal3, int *__restrict__ counter) {
+    int c = 0;
+    for (int s = 0; s < 3; ++s)
+        if (scal3[SC3(S_FROZEN, s)] != 0. || scal3[SC3(S_FROZEN2, s)] != 0.) ++c;
+    if (c) atomicAdd(counter, c);
+}
+
+int bicgstab3_dev(const MatView3 &A_in, const double *b3_in, double *x3, uint64_t iteration_count, int preconditioner, Arena &arena) {
+    const int64_t n = A_in.P.n;
+    if (n == 0) return ORC_OK;
+    if (!triple_supported()) return set_error(ORC_ERR_BAD_ARGUMENT, "three-system solve: tree reductions on one GPU only");
+    ArenaScope scope(arena);
+    const size_t n3 = (size_t)3 * (size_t)n;
+    MatView3 A = A_in;
+    const double *b3 = b3_in;
+    if (preconditioner == ORC_PRECOND_JACOBI) {  // :159-167, as iterative_solve_body does it
+        double *dinv3, *bt3;
+        ORC_TRY(arena.alloc(n3, &dinv3));
+        ORC_TRY(arena.alloc(n3, &bt3));
+        ORC_TRY(diag_inverse3_dev(A_in, dinv3));
+        ORC_TRY(scale_vec_dev(dinv3, b3_in, bt3, (int64_t)n3));
+        if (!A.s1) A.s1 = dinv3;
+        else if (!A.s2) A.s2 = dinv3;
+        else return set_error(ORC_ERR_BAD_ARGUMENT, "more than two nested Jacobi scalings");
+        b3 = bt3;
+    } else if (preconditioner != ORC_PRECOND_NONE) {
+        return set_error(ORC_ERR_BAD_ARGUMENT, "unknown preconditioner %d", preconditioner);
+    }
+    double *r3, *p3, *nu3, *s3, *t3, *partials, *partials2, *scal3;
+    ORC_TRY(arena.alloc(n3, &r3));
+    ORC_TRY(arena.alloc(n3, &p3));
+    ORC_TRY(arena.alloc(n3, &nu3));
+    ORC_TRY(arena.alloc(n3, &s3));
+    ORC_TRY(arena.alloc(n3, &t3));
+    ORC_TRY(arena.alloc((size_t)6 * kMaxPartials, &partials));
+    ORC_TRY(arena.alloc((size_t)3 * kMaxPartials, &partials2));
+    ORC_TRY(arena.alloc((size_t)3 * S_COUNT, &scal3));
+    hipStream_t st = ctx().stream;
+    ORC_HIP(hipMemsetAsync(scal3, 0, 3 * S_COUNT * sizeof(double), st));
+    const int guard = ctx().breakdown_guard ? 1 : 0;
+    const int vg = grid_for((n + 1) / 2);
+    int g = 0;
+    ORC_TRY(launch_spmv3(A, x3, EpiResidual3{b3, r3, p3}, partials, &g));  // r = b - A x ; p = r ; rho = sum(r)   (:250-254)
+    ORC_TRY(reduce_partials(partials, g, 3, scal3 + SC3(S_RHO0, 0), false));
+    for (uint64_t it = 0; it < iteration_count; ++it) {
+        const int cur = (int)(it & 1), nxt = cur ^ 1;
+        ORC_TRY(launch_spmv3(A, p3, EpiStoreSum3{nu3}, partials, &g));                                   // nu = A p, sum(nu)   (:256-257)
+        hipLaunchKernelGGL(bicg_s3_k, dim3(vg), dim3(kBlock), 0, st, scal3, S_RHO0 + cur, (const double *)r3, (const double *)nu3, s3, n, guard,
+                           (const double *)partials, g);                                                 // s = r - alpha nu    (:259)
+        ORC_TRY(launch_spmv3(A, s3, EpiTs3{s3, t3}, partials, &g));                                      // t = A s, t.s, t.t   (:260-261)
+        hipLaunchKernelGGL(bicg_xr3_k, dim3(vg), dim3(kBlock), 0, st, scal3, S_RHO0 + cur, x3, (const double *)p3, (const double *)s3, (const double *)t3, r3,
+                           n, partials2, guard, (const double *)partials, g);                            // x, r, sum(r)        (:258, :262-265)
+        hipLaunchKernelGGL(bicg_p3_k, dim3(vg), dim3(kBlock), 0, st, scal3, S_RHO0 + cur, S_RHO0 + nxt, (const double *)r3, (const double *)nu3, p3, n,
+                           guard, (const double *)partials2, vg);                                        // p                   (:266-267)
+    }
+    ORC_HIP(hipGetLastError());
+    if (guard && ctx().guard_events) {
+        hipLaunchKernelGGL(guard_event3_k, dim3(1), dim3(1), 0, st, (const double *)scal3, ctx().guard_events);
+        ORC_HIP(hipGetLastError());
+    }
+    return ORC_OK;
+}
+#undef SC3
 
 // ------------------------------------------------------------------ Jacobi arm (linear_algebra.rs:172-218)
 struct JacobiCtrl {

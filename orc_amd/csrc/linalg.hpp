@@ -84,6 +84,19 @@ struct MatView {
     int32_t slice_lo = 0, slice_hi = -1, part_stride = 0, part_base = 0;
 };
 
+// Three systems on ONE sparsity pattern — the u, v and w momentum matrices of a SIMPLE iteration (they share the mesh
+// pattern, discretization.rs:450-472, and on the first coarse level the pattern of (R a) R^T whenever their fine-level
+// pairings coincide).  One column stream serves three value streams, and the three vectors are INTERLEAVED
+// (x3[3 * i + s] = entry i of system s) so that one 24-byte gather fetches what three 8-byte gathers did: per entry
+// 28 bytes and five vector-memory instructions instead of 36 and nine.  Every row of every system is still summed in
+// ascending-column order from 0.0, every reduction keeps the thread -> element map and the fold of the one-system
+// kernels, so each system's results are bit-identical to its own one-system solve.
+struct MatView3 {
+    SellDev P;
+    const double *val[3] = {nullptr, nullptr, nullptr};
+    const double *s1 = nullptr, *s2 = nullptr;  // row scalings, interleaved [3 n] (MatView::s1 / s2 per system)
+};
+
 // Owning pattern (built on the host from CSR, e.g. the mesh pattern or a user matrix).
 struct SellMatrix {
     int64_t n = 0, ncols = 0, nnz = 0, padded = 0;
@@ -208,6 +221,34 @@ int residual_dev(const MatView &A, const double *b, const double *x, double *r);
 int residual_norm2_dev(const MatView &A, const double *b, const double *x, double *partials, double *out, double *r_scratch = nullptr);
 // out[0] = a . b in nalgebra's dotx association (a == nullptr: the all-ones vector); one wavefront, verification mode only
 int dot_reference(const double *a, const double *b, int64_t n, double *out, const double *skip_flags);
+
+// ---- three systems in lock-step (MatView3): interleaved vectors of 3 n doubles
+int interleave3_dev(const double *a, const double *b, const double *c, double *out3, int64_t n);
+int deinterleave3_dev(const double *in3, double *a, double *b, double *c, int64_t n);
+int diag_inverse3_dev(const MatView3 &A, double *dinv3);
+int spmv3_dev(const MatView3 &A, const double *x3, double *y3);
+int residual3_dev(const MatView3 &A, const double *b3, const double *x3, double *r3);
+// out[s] = sum((b - A x)^2) of system s
+int residual_norm2_3_dev(const MatView3 &A, const double *b3, const double *x3, double *partials /* 3 * kMaxPartials */, double *out3);
+// iterative_solve's BiCGSTAB arm (linear_algebra.rs:247-269) with its Jacobi preconditioner (:159-167) for the three systems at
+// once; fixed iteration count, so the three stay in lock-step; the breakdown guard acts per system.  Tree reductions only.
+int bicgstab3_dev(const MatView3 &A, const double *b3, double *x3, uint64_t iteration_count, int preconditioner, Arena &arena);
+// is the triple path usable in the calling context (single GPU, tree reductions)?
+bool triple_supported();
+
+// One system's share of a three-system Multigrid solve: the streams its hierarchy set-up and its per-system coarse levels
+// run on, their arenas, and the hierarchy itself (owned by the caller so that it outlives the call's arenas' unwinding).
+struct TripleLane {
+    hipStream_t setup_stream = nullptr, solve_stream = nullptr;
+    Arena *hier_arena = nullptr, *vec_arena = nullptr;
+    AmgHierarchy hierarchy;
+    SolveStats stats;
+    bool symmetric = true;
+};
+// The Multigrid arm (linear_algebra.rs:270-296, BiCGSTAB smoother) for three systems on one pattern: b[k], x[k] are the
+// systems' own contiguous vectors (x in/out); status_out[k] = ORC_OK or ORC_ERR_MULTIGRID_DIVERGED per system.
+int multigrid_arm3_dev(const MatView3 &A3, const double *const b[3], double *const x[3], uint64_t iteration_count, double relaxation_factor,
+                       double convergence_threshold, int preconditioner, Arena &arena, TripleLane lanes[3], SiblingPairing *sibling, int status_out[3]);
 
 // plain vector helpers used by the SIMPLE driver
 int vec_fill(double *x, double v, int64_t n);

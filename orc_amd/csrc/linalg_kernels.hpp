@@ -197,6 +197,76 @@ __global__ __launch_bounds__(kBlock) void spmv_uniform_k(MatView A, const double
 }
 
 
+// Three systems on one pattern (MatView3): one column load and one 24-byte gather per entry serve three value streams.
+// Epi3::apply(row, acc[3], r[3][2]) consumes the three row results; partial sums of reduction q of system s go to
+// partials[(s * Epi3::kReductions + q) * gridDim.x + blockIdx.x].  Same grid, same SliceWalk and same per-thread order as
+// spmv_uniform_k, so every system's row sums AND partial sums are those of its own one-system product.
+struct __attribute__((aligned(8))) Vec3d { double a, b, c; };
+
+template <class Epi3, int kChunk = 4>
+__global__ __launch_bounds__(kBlock) void spmv3_uniform_k(MatView3 A, const double *__restrict__ x3, Epi3 epi, double *__restrict__ partials) {
+    __shared__ double lds[8];
+    const int lane = threadIdx.x & 63;
+    double red[3][2] = {{0., 0.}, {0., 0.}, {0., 0.}};
+    const Vec3d *__restrict__ xv3 = reinterpret_cast<const Vec3d *>(x3);
+    const Vec3d *__restrict__ s1v = reinterpret_cast<const Vec3d *>(A.s1);
+    const Vec3d *__restrict__ s2v = reinterpret_cast<const Vec3d *>(A.s2);
+    SliceWalk w(A.P.n_slices);
+    for (int64_t slice = w.begin; slice < w.end; slice += w.step) {
+        const int64_t row = slice * 64 + lane;
+        const int64_t base = A.P.slice_ptr[slice];
+        const int width = (int)((A.P.slice_ptr[slice + 1] - base) >> 6);
+        const bool live = row < A.P.n;
+        const int len = live ? A.P.row_len[row] : 0;
+        Vec3d s1 = {1., 1., 1.}, s2 = {1., 1., 1.};
+        if (A.s1 && live) s1 = s1v[row];
+        if (A.s2 && live) s2 = s2v[row];
+        double acc0 = 0., acc1 = 0., acc2 = 0.;
+        for (int k0 = 0; k0 < width; k0 += kChunk) {
+            int c[kChunk];
+            double v0[kChunk], v1[kChunk], v2[kChunk];
+            Vec3d xv[kChunk];
+            const int64_t p0 = base + (int64_t)k0 * 64 + lane;
+#pragma unroll
+            for (int u = 0; u < kChunk; ++u) {  // wave-uniform matrix loads at compile-time offsets from one chunk base
+                const bool in = k0 + u < width;
+                c[u] = in ? A.P.col[p0 + (int64_t)u * 64] : 0;
+                v0[u] = in ? A.val[0][p0 + (int64_t)u * 64] : 0.;
+                v1[u] = in ? A.val[1][p0 + (int64_t)u * 64] : 0.;
+                v2[u] = in ? A.val[2][p0 + (int64_t)u * 64] : 0.;
+            }
+#pragma unroll
+            for (int u = 0; u < kChunk; ++u) {
+                if (k0 + u < len) xv[u] = xv3[c[u]];
+                else xv[u] = Vec3d{0., 0., 0.};
+            }
+#pragma unroll
+            for (int u = 0; u < kChunk; ++u) {
+                if (k0 + u < len) {
+                    double t0 = v0[u], t1 = v1[u], t2 = v2[u];
+                    if (A.s1) { t0 = s1.a * t0; t1 = s1.b * t1; t2 = s1.c * t2; }
+                    if (A.s2) { t0 = s2.a * t0; t1 = s2.b * t1; t2 = s2.c * t2; }
+                    acc0 += t0 * xv[u].a;
+                    acc1 += t1 * xv[u].b;
+                    acc2 += t2 * xv[u].c;
+                }
+            }
+        }
+        if (live) {
+            const double acc[3] = {acc0, acc1, acc2};
+            epi.apply(row, acc, red);
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+#pragma unroll
+        for (int q = 0; q < Epi3::kReductions; ++q) {
+            const double t = block_sum(red[s][q], lds);
+            if (threadIdx.x == 0) partials[(size_t)(s * Epi3::kReductions + q) * gridDim.x + blockIdx.x] = t;
+        }
+    }
+}
+
 // The same product software-pipelined across chunks AND slices: the column/value loads of the next chunk (of the same
 // slice or of the wave's next slice) are issued right behind the current chunk's x gathers, so a wave's HBM round trip
 // overlaps its gather round trip instead of following it (vmcnt counts in order: gathers first, then the younger

@@ -36,6 +36,28 @@ def iterative_solve(a, b, solution_vector, iteration_count, method, relaxation_f
     return st
 
 
+def iterative_solve3(a_list, b_list, x_list, iteration_count, method, relaxation_factor, convergence_threshold, preconditioner):
+    """orc_iterative_solve3: three systems on ONE pattern (scipy CSR matrices with identical indptr / indices) in lock-step;
+    x_list is updated in place.  Returns (status, [status per system])."""
+    a0 = a_list[0]
+    n = a0.shape[0]
+    rp, ci = _i64(a0.indptr), _i64(a0.indices)
+    for a in a_list[1:]:
+        assert np.array_equal(a.indptr, a0.indptr) and np.array_equal(a.indices, a0.indices), "the three systems must share their pattern"
+    vals = [_f64(a.data) for a in a_list]
+    bs = [_f64(b) for b in b_list]
+    for x in x_list:
+        assert x.dtype == np.float64 and x.flags.c_contiguous and len(x) == n
+    PD = C.POINTER(C.c_double)
+    v3 = (PD * 3)(*[_p(v, C.c_double) for v in vals])
+    b3 = (PD * 3)(*[_p(b, C.c_double) for b in bs])
+    x3 = (PD * 3)(*[_p(x, C.c_double) for x in x_list])
+    st3 = (C.c_int * 3)()
+    st = lib().orc_iterative_solve3(C.c_int64(n), _p(rp, C.c_int64), _p(ci, C.c_int64), v3, b3, x3, C.c_uint64(iteration_count), C.c_int(method),
+                                    C.c_double(relaxation_factor), C.c_double(convergence_threshold), C.c_int(preconditioner), st3)
+    return st, [st3[0], st3[1], st3[2]]
+
+
 def set_breakdown_guard(on):
     """process-wide OrcSettings.breakdown_guard for iterative_solve (default on); off = NaN like the reference"""
     check(lib().orc_set_breakdown_guard(C.c_int(1 if on else 0)))

@@ -184,7 +184,8 @@ def test_default_stack_is_reproducible_run_to_run(gpu, oracle, mesh_path):
 
 @pytest.mark.parametrize("solver", [MULTIGRID, BICGSTAB, 17, 18])  # 17 / 18: GS-preconditioned BiCGSTAB / Multigrid with GS smoother
 def test_stream_scheduling_does_not_change_a_bit(gpu, oracle, mesh_path, monkeypatch, solver):
-    """The momentum lanes (u, v, w on three streams / host threads), the two-stream Multigrid arm (set-up beside
+    """The three-system momentum solve (u, v, w in lock-step on their shared pattern: one column stream, interleaved vectors),
+    the momentum lanes (u, v, w on three streams / host threads), the two-stream Multigrid arm (set-up beside
     smoothing) and the early p' hierarchy (built beside the momentum solves) only reorder independent work, and the
     sibling pairing (v and w take u's fine-level pairing when it verifies as their own) only skips work whose result is
     known: three SIMPLE iterations give identical bits with any of them switched off."""
@@ -195,8 +196,12 @@ def test_stream_scheduling_does_not_change_a_bit(gpu, oracle, mesh_path, monkeyp
     a = set_channel_bcs(hex_channel(24, 16, 10))
     s = NumericalSettings.default(momentum=5, solver_type=solver, iterations=6, momentum_relaxation=0.1, pressure_relaxation=0.001)
     out = []
-    for lanes, two, early, sibling in (("1", "1", "1", "1"), ("0", "0", "0", "1"), ("1", "0", "0", "1"), ("0", "1", "0", "1"), ("0", "0", "1", "1"),
-                                       ("1", "1", "0", "1"), ("1", "1", "1", "0"), ("0", "0", "0", "0")):
+    # the first and the last but one run the three momentum systems in lock-step on their shared pattern (ORC_TRIPLE_MOMENTUM,
+    # the default); the others the per-system lanes or the plain sequential loop
+    for lanes, two, early, sibling, triple in (("1", "1", "1", "1", "1"), ("0", "0", "0", "1", "0"), ("1", "0", "0", "1", "0"), ("0", "1", "0", "1", "0"),
+                                               ("0", "0", "1", "1", "0"), ("1", "1", "0", "1", "0"), ("1", "1", "1", "0", "0"), ("1", "1", "1", "1", "0"),
+                                               ("1", "1", "0", "0", "1"), ("0", "0", "0", "0", "0")):
+        monkeypatch.setenv("ORC_TRIPLE_MOMENTUM", triple)
         monkeypatch.setenv("ORC_CONCURRENT_MOMENTUM", lanes)
         monkeypatch.setenv("ORC_TWO_STREAM_MULTIGRID", two)
         monkeypatch.setenv("ORC_EARLY_P_HIERARCHY", early)
