@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+PMC_FILE = "r03_spmv_pmc.json"  # written by scripts/pmc_summary_r03.py from the rocprofv3 --pmc passes of scripts/gpu_pmc_r03.sh
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy ceiling)
 REF_CELLS = 400 * 160 * 160
 
@@ -57,6 +58,11 @@ def cpu_baseline(settings_kw, sample=(100, 40, 40), iters=6):
     kw = dict(settings_kw)
     kw["frozen_diagonals"] = 0  # the reference's own mode
     kw["breakdown_guard"] = 0
+    note = ""
+    if int(kw["solver_type"]) >= 16:  # multicolour-GS extensions do not exist in ORC: time its own arm of the same family
+        ref_solver = 2 if int(kw["solver_type"]) == 18 else 3
+        note = "; the GS extension has no reference counterpart (linear_algebra.rs:219-246 panics): the oracle runs ORC's %s arm" % ("Multigrid" if ref_solver == 2 else "BiCGSTAB")
+        kw["solver_type"] = ref_solver
     s = po.default_settings(**kw)
     t0 = time.perf_counter()
     st, _ = po.solve_steady(om, u, v, w, p, s, 1000.0, 1e-3, iters)
@@ -81,7 +87,7 @@ def cpu_baseline(settings_kw, sample=(100, 40, 40), iters=6):
         "rust_toolchain": "present" if shutil.which("cargo") else "absent (ORC itself cannot be built: the port is timed)",
         "kind": "port",
         "sample": "%dx%dx%d hex channel (%d cells = 1/%d of the workload), %d SIMPLE iterations in %.2f s, status %d; scaled by cells"
-                  % (nx, ny, nz, n, REF_CELLS // n, iters, dt, st),
+                  % (nx, ny, nz, n, REF_CELLS // n, iters, dt, st) + note,
     }
 
 
@@ -101,6 +107,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--spmv-reps", type=int, default=50)
     ap.add_argument("--levels-csv", default=None, help="write the per-level product table (profiles/rNN_levels.csv)")
+    ap.add_argument("--spin-up", type=int, default=2, help="untimed SIMPLE iterations before the snapshot every timed step restores "
+                    "(the timed iteration is number spin-up + 1 of the run; its cost grows slowly with the state)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -174,12 +182,16 @@ def main():
     # then every warm-up and timed step = restore the snapshot (device-to-device, 0.57 GB, inside the timed region)
     # + one full SIMPLE iteration (iteration 3 of the run).  Nothing is skipped or cached between steps: assembly,
     # the four hierarchy set-ups and all solves run in full each time.
-    SPIN_UP = 2
+    SPIN_UP = max(args.spin_up, 0)
+    trajectory = []  # report of every untimed iteration: mean u, v, w, velocity- and pressure-correction norms (solver.rs:206-216)
     for _ in range(SPIN_UP):
-        st_, _ = solver.iterate(1, report=True, raise_on_error=False)
+        st_, rep_ = solver.iterate(1, report=True, raise_on_error=False)
         if st_ != 0:
             raise SystemExit("bench.py: spin-up iteration failed with status %d" % st_)
+        trajectory.append([float(rep_[0][k]) for k in (0, 1, 2, 6, 7)])
     solver.snapshot()
+    from orc_amd.linear_algebra import breakdown_guard_events
+    guard_before = breakdown_guard_events()
     step_ms = []
 
     def run(k, record):
@@ -210,6 +222,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    guard_events_timed = breakdown_guard_events() - guard_before  # solves of the warm-up + timed steps the breakdown guard froze
     # device memory in use by the timed run (before the measurement legs below build a hierarchy of their own)
     import ctypes
     free_b, total_b = ctypes.c_int64(0), ctypes.c_int64(0)
@@ -217,11 +230,17 @@ def main():
     hbm_used_gb = (total_b.value - free_b.value) / 1e9
 
     # dominant kernel: CSR(SELL-64) SpMV inside BiCGSTAB, timed live with HIP events on the library stream
-    spmv_ms, _ = solver.bench_spmv(args.spmv_reps)
+    solver.restore()  # the matrices of the timed iteration's state
+    solver.assemble_momentum_only()
+    spmv_ms, _ = solver.bench_spmv(args.spmv_reps)  # the plain product y = A x (no scalings, no epilogue): secondary figure
     n_local = getattr(mesh, "n_owned", mesh.n_cells)  # rows of this rank's matrices
     nnz_local = mesh.nnz
     spmv_bytes = 12.0 * nnz_local + 20.0 * n_local  # f64 value + i32 column per nnz; row_ptr, x, y per row
-    achieved = spmv_bytes / (spmv_ms * 1e-3) / 1e9
+    # the products INSIDE the BiCGSTAB loop, as the solver launches them on level 0 (two Jacobi scalings, reduction epilogues)
+    inloop = solver.bench_inloop_products(args.spmv_reps)
+    inloop_ms = 0.5 * (inloop[0] + inloop[1])  # one of each per BiCGSTAB iteration (linear_algebra.rs:256, :260)
+    achieved = spmv_bytes / (inloop_ms * 1e-3) / 1e9
+    triple_ms = 0.5 * (inloop[2] + inloop[3]) if inloop[2] > 0 else None
     bicg_ms = solver.bench_bicgstab_iteration(10)
     # per level of the momentum system's Multigrid hierarchy: rows, nnz, padded entries, product time, roofline fraction
     levels = []
@@ -248,11 +267,14 @@ def main():
     # --pmc passes: scripts/gpu_pmc_r02.sh; equal to FETCH_SIZE x 2 + WRITE_SIZE of MI355X_MICROARCH.md §HBM for this
     # kernel): bench.py cannot collect counters itself, so it quotes the committed profile of the same kernel on the same
     # matrix when one exists, else null.
-    traffic = None
+    KERNEL = "spmv_uniform_k<EpiStoreSum, false, true> / <EpiTs, false, true>"
+    traffic, traffic_source = None, None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_spmv_pmc.json")))
-        if pmc["n"] == n_local and pmc["nnz"] == nnz_local:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
+        # the counters must be those of THIS kernel on THIS matrix: anything else is not quoted
+        if pmc["n"] == n_local and pmc["nnz"] == nnz_local and pmc["kernel"] == KERNEL:
             traffic = pmc["hbm_bytes_per_launch"]
+            traffic_source = "profiles/%s (%s)" % (PMC_FILE, pmc.get("method", "rocprofv3 --pmc"))
     except Exception:
         traffic = None
 
@@ -284,26 +306,51 @@ def main():
                             "full SIMPLE iteration" % (workload_name, nx, ny, nz, n_cells_total, args.momentum.upper(), args.solver, args.inner,
                                                        args.momentum_relaxation, args.pressure_relaxation),
                 "cells_total": int(n_cells_total),
-                "parallelism": "cell slabs x%d, RCCL halo + all-reduce" % world if world > 1 else "single GPU",
+                "parallelism": ("cell slabs x%d, halo exchange + all-reduce over %s" % (world, "the host-staged debug transport (gloo; ranks share one GPU: a "
+                                "rehearsal, not a measurement)" if host_transport else "RCCL (ncclSend/ncclRecv + ncclAllReduce over xGMI)")) if world > 1 else "single GPU",
+                "transport": ("host" if host_transport else "rccl") if world > 1 else None,
+                "momentum_solves": "u, v, w in lock-step on their shared pattern (one column stream, interleaved vectors)" if (world == 1 and args.solver in ("multigrid", "bicgstab") and os.environ.get("ORC_TRIPLE_MOMENTUM", "1") != "0") else "one system per solve",
                 "setup_s": round(t_setup, 2),
                 "hbm_used_gb": round(hbm_used_gb, 1),
             },
             "roofline": {
-                "kernel": "spmv_uniform_k<EpiStore, false> (SELL-64 SpMV inside BiCGSTAB, a_u of the momentum system)",
+                "kernel": KERNEL,
+                "kernel_role": "SELL-64 CSR SpMV INSIDE the BiCGSTAB loop on level 0 (a_u of the momentum system through the arm's Jacobi scaling and the "
+                               "smoother's nested one, with the reduction epilogues: nu = A p + sum(nu), t = A s + t.s, t.t), one system per launch — "
+                               "what the p' solve and every one-system solve launch; HIP events on the library stream around %d launches each" % args.spmv_reps,
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "traffic_source": "profiles/r02_spmv_pmc.json (rocprofv3 --pmc TCC_EA0_RDREQ_{32B,64B,128B} + TCC_EA0_WRREQ, bytes by request size)" if traffic else None,
-                "avg_launch_ms": spmv_ms,
+                "traffic_source": traffic_source,
+                "avg_launch_ms": inloop_ms,
+                "avg_launch_ms_by_epilogue": {"EpiStoreSum": inloop[0], "EpiTs": inloop[1]},
                 "algorithmic_bytes_per_launch": spmv_bytes,
+                "algorithmic_bytes_definition": "SURVEY 8(d): 12 nnz + 20 n per system (f64 value + i32 column per entry; row length, x, y per row); the scaling "
+                                                "vectors (16 n) and the epilogue's operand (8 n, EpiTs) the in-loop kernels also read are NOT counted",
+                "three_systems_per_launch": None if triple_ms is None else {
+                    "kernel": "spmv3_uniform_k<EpiStoreSum3, 4, true> / <EpiTs3, 4, true>",
+                    "avg_launch_ms": triple_ms,
+                    "avg_launch_ms_by_epilogue": {"EpiStoreSum3": inloop[2], "EpiTs3": inloop[3]},
+                    "algorithmic_bytes_per_launch": 3.0 * spmv_bytes,
+                    "achieved": 3.0 * spmv_bytes / (triple_ms * 1e-3) / 1e9,
+                    "frac": 3.0 * spmv_bytes / (triple_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "note": "u, v, w momentum products in one launch: 3 SpMV units of SURVEY 8(d); the launch itself moves 28 nnz + 60 n bytes (one "
+                            "column stream for three value streams), so `frac` is algorithmic throughput, not traffic",
+                },
+                "plain_product": {"kernel": "spmv_uniform_k<EpiStore, false, true>", "avg_launch_ms": spmv_ms,
+                                  "frac": spmv_bytes / (spmv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
                 "bicgstab_iteration_ms": bicg_ms,
                 "bicgstab_iteration_GBs": bicg_bytes / (bicg_ms * 1e-3) / 1e9,
             },
             "amg_levels": levels,
             "report_last": [float(x) for x in rep[-1]] if rep is not None and len(rep) else None,
+            "report_trajectory": {"columns": ["u_mean", "v_mean", "w_mean", "velocity_correction_norm", "pressure_correction_norm"],
+                                  "spin_up": trajectory,
+                                  "timed": [float(rep[-1][k]) for k in (0, 1, 2, 6, 7)] if rep is not None and len(rep) else None},
+            "breakdown_guard_events_in_timed_region": int(guard_events_timed),
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(settings_kw)

@@ -274,6 +274,10 @@ int orc_bench_bicgstab_iteration(OrcSolver *s, int reps, double *avg_ms);
 /* The Multigrid hierarchy of the momentum system a_u as the solver builds it (Jacobi-scaled operator, levels 0..3):
  * per level rows, stored non-zeros, padded SELL-64 entries and the HIP-event average of `reps` products y = A x.
  * Arrays hold up to 4 entries; *n_levels receives the count (level 0 = the mesh-pattern matrix). */
+/* bench.py's headline roofline: the level-0 products of a_u as the solver's BiCGSTAB iterations launch them inside the
+ * Multigrid arm (two Jacobi scalings, reduction epilogues), timed with HIP events on the library stream.  avg_ms[0], [1]: one
+ * system per launch (nu = A p with sum(nu); t = A s with t.s, t.t); avg_ms[2], [3]: u, v, w in one launch (0 when unsupported). */
+int orc_bench_inloop_products(OrcSolver *s, int reps, double avg_ms[4]);
 int orc_bench_amg_levels(OrcSolver *s, int reps, int64_t *rows, int64_t *nnz, int64_t *padded, double *avg_ms, int *n_levels);
 /* Measurement only: force a product kernel variant for the next launches (0 = production choice, 1 = padded SELL-64,
  * 2 = padded with predicated padding, 3 = packed where a mirror exists, 4/5 = packed/padded WITHOUT the x gathers —

@@ -2123,7 +2123,8 @@ int multigrid_arm_dev(const MatView &A, const double *b, double *x, uint64_t ite
 //   * the three hierarchies are built by one host thread each (their rounds synchronise their stream) beside the level-0 solve.
 // Anything that does not fit (pairings differ, a level too small) falls back to the per-system coarse part.
 int multigrid_arm3_dev(const MatView3 &A3, const double *const b[3], double *const x[3], uint64_t iteration_count, double relaxation_factor,
-                       double convergence_threshold, int preconditioner, Arena &arena, TripleLane lanes[3], SiblingPairing *sibling, int status_out[3]) {
+                       double convergence_threshold, int preconditioner, Arena &arena, TripleLane lanes[3], SiblingPairing *sibling, int status_out[3],
+                       const std::function<void()> &on_hierarchies_built) {
     const int64_t n = A3.P.n;
     for (int k = 0; k < 3; ++k) status_out[k] = ORC_OK;
     if (n == 0) return ORC_OK;
@@ -2199,6 +2200,7 @@ int multigrid_arm3_dev(const MatView3 &A3, const double *const b[3], double *con
         if (th[k].joinable()) th[k].join();
         if (!prepared[k]) prepare(k);
     }
+    if (on_hierarchies_built) on_hierarchies_built();
     for (int k = 0; k < 3; ++k)
         if (st_prep[k] != ORC_OK) { g.last_error = local[k].last_error; return st_prep[k]; }
     const AmgHierarchy *H[3] = {&lanes[0].hierarchy, &lanes[1].hierarchy, &lanes[2].hierarchy};

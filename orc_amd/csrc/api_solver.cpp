@@ -497,6 +497,7 @@ int orc_bench_spmv(OrcSolver *s, int reps, double *avg_ms, double *checksum) {
     MatView A;
     A.P = t.mesh->pat.dev();
     A.val = t.a_u.p;
+    A.persistent_pattern = true;
     Arena::Mark mk = t.arena.mark();
     double *y;
     ORC_TRY(t.arena.alloc((size_t)t.n, &y));
@@ -521,6 +522,60 @@ int orc_bench_spmv(OrcSolver *s, int reps, double *avg_ms, double *checksum) {
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     t.arena.release(mk);
+    return ORC_OK;
+}
+
+// The level-0 products of the momentum system a_u exactly as the solver's BiCGSTAB iterations launch them inside the Multigrid
+// arm: through the arm's Jacobi scaling and the smoother's nested one, with the reduction epilogues.
+// avg_ms[0], [1]: spmv_uniform_k<EpiStoreSum, false, true>, <EpiTs, false, true> (one system: what the p' solve and any one-system
+// solve run); avg_ms[2], [3]: spmv3_uniform_k<EpiStoreSum3, 4, true>, <EpiTs3, 4, true> (u, v, w in one launch).
+int orc_bench_inloop_products(OrcSolver *s, int reps, double avg_ms[4]) {
+    if (!s || !avg_ms) return set_error(ORC_ERR_BAD_ARGUMENT, "null argument");
+    SolverState &t = s->st;
+    if (reps < 1) reps = 1;
+    ArenaScope scope(t.arena);
+    const size_t n = (size_t)std::max<int64_t>(t.n, 1);
+    MatView A;
+    A.P = t.mesh->pat.dev();
+    A.val = t.a_u.p;
+    A.symmetric = t.mesh->pat.symmetric;
+    A.persistent_pattern = true;
+    double *d1, *d2, *y, *partials;
+    ORC_TRY(t.arena.alloc(n, &d1));
+    ORC_TRY(t.arena.alloc(n, &d2));
+    ORC_TRY(t.arena.alloc(n, &y));
+    ORC_TRY(t.arena.alloc((size_t)6 * kMaxPartials, &partials));
+    const bool jac = t.settings.preconditioner == ORC_PRECOND_JACOBI;
+    if (jac) {
+        ORC_TRY(diag_inverse_dev(A, d1));
+        A.s1 = d1;
+        ORC_TRY(diag_inverse_dev(A, d2));
+        A.s2 = d2;
+    }
+    float ms[2];
+    ORC_TRY(bench_inloop_products_dev(A, t.u.p, y, partials, reps, ms));
+    avg_ms[0] = ms[0]; avg_ms[1] = ms[1];
+    avg_ms[2] = avg_ms[3] = 0.;
+    if (triple_supported()) {
+        MatView3 A3;
+        A3.P = t.mesh->pat.dev();
+        A3.val[0] = t.a_u.p; A3.val[1] = t.a_v.p; A3.val[2] = t.a_w.p;
+        A3.mesh_pattern = true;
+        double *e1, *e2, *x3, *y3;
+        ORC_TRY(t.arena.alloc(3 * n, &e1));
+        ORC_TRY(t.arena.alloc(3 * n, &e2));
+        ORC_TRY(t.arena.alloc(3 * n, &x3));
+        ORC_TRY(t.arena.alloc(3 * n, &y3));
+        ORC_TRY(interleave3_dev(t.u.p, t.v.p, t.w.p, x3, t.n));
+        if (jac) {
+            ORC_TRY(diag_inverse3_dev(A3, e1));
+            A3.s1 = e1;
+            ORC_TRY(diag_inverse3_dev(A3, e2));
+            A3.s2 = e2;
+        }
+        ORC_TRY(bench_inloop_products3_dev(A3, x3, y3, partials, reps, ms));
+        avg_ms[2] = ms[0]; avg_ms[3] = ms[1];
+    }
     return ORC_OK;
 }
 

@@ -1435,7 +1435,7 @@ static int solve_momentum_concurrently(SolverState &s, bool setup_first, Prepare
 
 // The three momentum systems in lock-step (linalg.hpp MatView3 / multigrid_arm3_dev, bicgstab3_dev): single GPU, tree
 // reductions, Multigrid or BiCGSTAB solver.  Returns the first non-zero status in u, v, w order, like the sequential loop.
-static int solve_momentum_triple(SolverState &s) {
+static int solve_momentum_triple(SolverState &s, const std::function<void()> &on_hierarchies_built) {
     Ctx &g = ctx();
     const OrcSettings &t = s.settings;
     g.breakdown_guard = t.breakdown_guard != 0;
@@ -1443,6 +1443,7 @@ static int solve_momentum_triple(SolverState &s) {
     MatView3 A3;
     A3.P = s.mesh->pat.dev();
     A3.val[0] = s.a_u.p; A3.val[1] = s.a_v.p; A3.val[2] = s.a_w.p;
+    A3.mesh_pattern = true;
     const double *b[3] = {s.b_u.p, s.b_v.p, s.b_w.p};
     double *x[3] = {s.u.p, s.v.p, s.w.p};
     if (s.arena.empty()) ORC_TRY(s.arena.reset());
@@ -1476,7 +1477,7 @@ static int solve_momentum_triple(SolverState &s) {
     }
     int st3[3] = {ORC_OK, ORC_OK, ORC_OK};
     ORC_TRY(multigrid_arm3_dev(A3, b, x, t.iterations, t.relaxation, t.relative_convergence_threshold, t.preconditioner, s.arena, s.triple,
-                               s.sibling_pairing ? &s.sibling : nullptr, st3));
+                               s.sibling_pairing ? &s.sibling : nullptr, st3, on_hierarchies_built));
     s.stats = s.triple[0].stats;
     for (int k = 0; k < 3; ++k)
         if (st3[k] != ORC_OK) return st3[k];
@@ -1512,19 +1513,26 @@ int solver_iterate(SolverState &s, uint64_t iterations, double *report) {
         const int method = s.settings.solver_type;
         PrepareThread prep;
         s.p_hierarchy.n_levels = 0;
-        if (s.early_p_hierarchy && (method == ORC_SOLVER_MULTIGRID || method == ORC_SOLVER_MULTIGRID_GS) && !dbg && !ctx().profile) {
-            if (!s.prep_stream) ORC_TRY(create_stream(&s.prep_stream, kSetupStream, 2));
-            ORC_HIP(hipStreamSynchronize(ctx().stream));  // the diagonals (and their ghosts) are in place
-            prep.start(s);
-        }
+        const bool early_p = s.early_p_hierarchy && (method == ORC_SOLVER_MULTIGRID || method == ORC_SOLVER_MULTIGRID_GS) && !dbg && !ctx().profile;
+        if (early_p && !s.prep_stream) ORC_TRY(create_stream(&s.prep_stream, kSetupStream, 2));
         const bool lanes_ok = s.concurrent_momentum && !H.active() && !dbg && !ctx().profile &&
                               (method == ORC_SOLVER_MULTIGRID || method == ORC_SOLVER_BICGSTAB || method == ORC_SOLVER_JACOBI ||
                                method == ORC_SOLVER_MULTIGRID_GS || method == ORC_SOLVER_BICGSTAB_GS_PRECOND || method == ORC_SOLVER_MULTICOLOR_GS);
         const bool lanes_partitioned = s.concurrent_momentum && H.active() && !dbg && !ctx().profile && method == ORC_SOLVER_MULTIGRID;
         const bool triple_ok = lanes_ok && s.triple_momentum && triple_supported() && s.settings.reduction_order != ORC_REDUCTION_REFERENCE &&
                                (method == ORC_SOLVER_MULTIGRID || method == ORC_SOLVER_BICGSTAB);
+        // The p' hierarchy is needed after the momentum solves.  Beside the per-system lanes it is built from the start; in the
+        // lock-step schedule the momentum set-ups are the critical path of the first phase (nothing bandwidth-bound but the
+        // level-0 solve runs beside them), so it starts when they are through and runs beside the bandwidth-bound coarse levels.
+        static const int p_late_env = getenv("ORC_P_HIERARCHY_LATE") ? atoi(getenv("ORC_P_HIERARCHY_LATE")) : 1;
+        const bool p_late = early_p && triple_ok && method == ORC_SOLVER_MULTIGRID && p_late_env != 0;
+        if (early_p && !p_late) {
+            ORC_HIP(hipStreamSynchronize(ctx().stream));  // the diagonals (and their ghosts) are in place
+            prep.start(s);
+        }
         if (triple_ok) {
-            ORC_TRY(solve_momentum_triple(s));                          // :99-136, the three systems in lock-step on their shared pattern
+            // :99-136, the three systems in lock-step on their shared pattern
+            ORC_TRY(solve_momentum_triple(s, p_late ? std::function<void()>([&] { prep.start(s); }) : std::function<void()>()));
         } else if (lanes_ok) {
             static const int setup_first_env = getenv("ORC_SETUP_FIRST") ? atoi(getenv("ORC_SETUP_FIRST")) : 0;  // measured: exact, +8 % wall (1.24 s against 1.15 s)
             const bool setup_first = setup_first_env != 0 && method == ORC_SOLVER_MULTIGRID;

@@ -126,7 +126,9 @@ static inline bool reference_order(const MatView &A) { return ctx().reduction_or
 
 static inline int spmv_grid(int32_t n_slices) {
     int64_t g = ((int64_t)n_slices + 3) / 4;  // 4 waves (slices) per workgroup
-    if (g > kMaxGrid) g = kMaxGrid;
+    // ORC_SPMV_GRID (measurement): fewer resident workgroups per CU leave wave slots to the set-up kernels of other streams
+    static const int cap = getenv("ORC_SPMV_GRID") ? std::max(8, std::min(kMaxGrid, atoi(getenv("ORC_SPMV_GRID")))) : kMaxGrid;
+    if (g > cap) g = cap;
     if (g >= 8) g = (g / 8) * 8;  // multiple of 8 for the XCD-aware walk
     if (g < 1) g = 1;
     return (int)g;
@@ -381,7 +383,9 @@ static int launch_spmv(const MatView &A, const double *x, const Epi &epi, double
         hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi, kSpmvPacked>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
     else if (ragged_enabled && A.P.ragged == 1)  // long ragged rows without a mirror: every slot clamped, nothing skipped
         hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi, kSpmvRagged>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
-    else  // mesh-pattern matrices and short ragged rows (first coarse level): wave-uniform loads, predicated gathers
+    else if (A.persistent_pattern)  // mesh-pattern matrices (level 0): wave-uniform loads, predicated gathers
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_uniform_k<Epi, false, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
+    else  // short ragged rows (first coarse level): the same kernel under its own name
         hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_uniform_k<Epi, false>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
     ORC_HIP(hipGetLastError());
     return ORC_OK;
@@ -643,6 +647,28 @@ static int bicgstab_dev(const MatView &A, const double *b, double *x, uint64_t i
     return ORC_OK;
 }
 
+template <class Fn>
+static int time_launches(int reps, float *ms, Fn &&launch) {
+    hipEvent_t e0, e1;
+    ORC_HIP(hipEventCreate(&e0));
+    ORC_HIP(hipEventCreate(&e1));
+    int st = launch();  // warm
+    if (st == ORC_OK && hipEventRecord(e0, ctx().stream) != hipSuccess) st = set_error(ORC_ERR_HIP, "hipEventRecord failed");
+    for (int i = 0; i < reps && st == ORC_OK; ++i) st = launch();
+    if (st == ORC_OK && (hipEventRecord(e1, ctx().stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess)) st = set_error(ORC_ERR_HIP, "hipEventRecord failed");
+    if (st == ORC_OK && hipEventElapsedTime(ms, e0, e1) != hipSuccess) st = set_error(ORC_ERR_HIP, "hipEventElapsedTime failed");
+    if (st == ORC_OK) *ms /= (float)std::max(reps, 1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return st;
+}
+int bench_inloop_products_dev(const MatView &A, const double *x, double *y, double *partials, int reps, float ms[2]) {
+    int g = 0;
+    ORC_TRY(time_launches(reps, &ms[0], [&] { return launch_spmv(A, x, EpiStoreSum{y}, partials, &g, nullptr); }));
+    ORC_TRY(time_launches(reps, &ms[1], [&] { return launch_spmv(A, x, EpiTs{x, y}, partials, &g, nullptr); }));
+    return ORC_OK;
+}
+
 int bench_bicgstab_dev(const MatView &A, const double *b, double *x, int reps, Arena &arena, float *ms) {
     const int64_t n = A.P.n;
     Arena::Mark mk = arena.mark();
@@ -732,6 +758,7 @@ static int launch_spmv3(const MatView3 &A, const double *x3, const Epi3 &epi, do
     static const int chunk = getenv("ORC_SPMV3_CHUNK") ? atoi(getenv("ORC_SPMV3_CHUNK")) : 4;
     if (chunk == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 8>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
     else if (chunk == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 2>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
+    else if (A.mesh_pattern) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
     ORC_HIP(hipGetLastError());
     return ORC_OK;
@@ -1083,6 +1110,12 @@ int bicgstab3_dev(const MatView3 &A_in, const double *b3_in, double *x3, uint64_
     return ORC_OK;
 }
 #undef SC3
+int bench_inloop_products3_dev(const MatView3 &A, const double *x3, double *y3, double *partials, int reps, float ms[2]) {
+    int g = 0;
+    ORC_TRY(time_launches(reps, &ms[0], [&] { return launch_spmv3(A, x3, EpiStoreSum3{y3}, partials, &g); }));
+    ORC_TRY(time_launches(reps, &ms[1], [&] { return launch_spmv3(A, x3, EpiTs3{x3, y3}, partials, &g); }));
+    return ORC_OK;
+}
 
 // ------------------------------------------------------------------ Jacobi arm (linear_algebra.rs:172-218)
 struct JacobiCtrl {

@@ -1,6 +1,7 @@
 // linalg.hpp — device sparse matrix format and the iterative solvers (K1-K8 of SURVEY §2.1).
 #pragma once
 #include <condition_variable>
+#include <functional>
 #include <mutex>
 #include "common.hpp"
 #include "halo.hpp"
@@ -95,6 +96,7 @@ struct MatView3 {
     SellDev P;
     const double *val[3] = {nullptr, nullptr, nullptr};
     const double *s1 = nullptr, *s2 = nullptr;  // row scalings, interleaved [3 n] (MatView::s1 / s2 per system)
+    bool mesh_pattern = false;                  // level 0 (kernel-name tag only, see spmv_uniform_k's kMesh)
 };
 
 // Owning pattern (built on the host from CSR, e.g. the mesh pattern or a user matrix).
@@ -233,6 +235,10 @@ int residual_norm2_3_dev(const MatView3 &A, const double *b3, const double *x3, 
 // iterative_solve's BiCGSTAB arm (linear_algebra.rs:247-269) with its Jacobi preconditioner (:159-167) for the three systems at
 // once; fixed iteration count, so the three stay in lock-step; the breakdown guard acts per system.  Tree reductions only.
 int bicgstab3_dev(const MatView3 &A, const double *b3, double *x3, uint64_t iteration_count, int preconditioner, Arena &arena);
+// bench.py: the level-0 products exactly as a BiCGSTAB iteration launches them (scalings of the view, reduction epilogues):
+// ms[0] = nu = A p with sum(nu) (EpiStoreSum), ms[1] = t = A s with t.s, t.t (EpiTs); average per launch over `reps`
+int bench_inloop_products_dev(const MatView &A, const double *x, double *y, double *partials, int reps, float ms[2]);
+int bench_inloop_products3_dev(const MatView3 &A, const double *x3, double *y3, double *partials, int reps, float ms[2]);
 // is the triple path usable in the calling context (single GPU, tree reductions)?
 bool triple_supported();
 
@@ -248,7 +254,8 @@ struct TripleLane {
 // The Multigrid arm (linear_algebra.rs:270-296, BiCGSTAB smoother) for three systems on one pattern: b[k], x[k] are the
 // systems' own contiguous vectors (x in/out); status_out[k] = ORC_OK or ORC_ERR_MULTIGRID_DIVERGED per system.
 int multigrid_arm3_dev(const MatView3 &A3, const double *const b[3], double *const x[3], uint64_t iteration_count, double relaxation_factor,
-                       double convergence_threshold, int preconditioner, Arena &arena, TripleLane lanes[3], SiblingPairing *sibling, int status_out[3]);
+                       double convergence_threshold, int preconditioner, Arena &arena, TripleLane lanes[3], SiblingPairing *sibling, int status_out[3],
+                       const std::function<void()> &on_hierarchies_built = nullptr);  // called once, from the calling thread, when the three set-ups are through
 
 // plain vector helpers used by the SIMPLE driver
 int vec_fill(double *x, double v, int64_t n);

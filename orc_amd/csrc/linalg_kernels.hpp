@@ -139,7 +139,9 @@ __global__ __launch_bounds__(kBlock) void spmv_k(MatView A, const double *__rest
 // Generic thread-per-row SELL-64 SpMV.  Epi::apply(row, acc, r0, r1) consumes the row result and
 // may accumulate up to two per-thread reduction terms; partial sums per workgroup go to
 // partials[q * gridDim.x + blockIdx.x] and are folded by reduce_partials_k.
-template <class Epi, bool kRagged = false>
+// kMesh: a tag, no code — products on the mesh pattern (level 0: a_u, a_v, a_w, A_p) get a kernel name of their own, so that a
+// kernel trace separates them from the first coarse level's (profiles/: the roofline of bench.py is about level 0).
+template <class Epi, bool kRagged = false, bool kMesh = false>
 __global__ __launch_bounds__(kBlock) void spmv_uniform_k(MatView A, const double *__restrict__ x, Epi epi, double *__restrict__ partials,
                                                  const double *__restrict__ skip_flags /* 2 doubles or null: non-zero = no-op */) {
     __shared__ double lds[8];
@@ -203,7 +205,7 @@ __global__ __launch_bounds__(kBlock) void spmv_uniform_k(MatView A, const double
 // spmv_uniform_k, so every system's row sums AND partial sums are those of its own one-system product.
 struct __attribute__((aligned(8))) Vec3d { double a, b, c; };
 
-template <class Epi3, int kChunk = 4>
+template <class Epi3, int kChunk = 4, bool kMesh = false>
 __global__ __launch_bounds__(kBlock) void spmv3_uniform_k(MatView3 A, const double *__restrict__ x3, Epi3 epi, double *__restrict__ partials) {
     __shared__ double lds[8];
     const int lane = threadIdx.x & 63;

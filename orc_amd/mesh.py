@@ -123,7 +123,8 @@ def renumber_cells(a, new_of_old):
     cfp, cf = np.asarray(a["cell_face_ptr"]), np.asarray(a["cell_faces"])
     counts = np.diff(cfp)[old_of_new]
     new_cfp = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
-    idx = np.concatenate([np.arange(cfp[o], cfp[o + 1]) for o in old_of_new]) if n else np.zeros(0, np.int64)
+    # face-list positions of the new cells, one after the other: old start of each cell + offset inside it
+    idx = (np.repeat(cfp[:-1][old_of_new], counts) + (np.arange(int(new_cfp[-1]), dtype=np.int64) - np.repeat(new_cfp[:-1], counts))) if n else np.zeros(0, np.int64)
     out = MeshArrays(a)
     out.update(face_c0=new_of_old[c0], face_c1=np.where(c1 >= 0, new_of_old[np.maximum(c1, 0)], -1),
                cell_centroid=np.asarray(a["cell_centroid"])[old_of_new].copy(), cell_volume=np.asarray(a["cell_volume"])[old_of_new].copy(),

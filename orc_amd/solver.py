@@ -92,6 +92,10 @@ class Solver:
         check(lib().orc_solver_assemble_pressure(self.ptr, _p(a), _p(b)))
         return a, b
 
+    def assemble_momentum_only(self):
+        """the momentum assembly of the current state, matrices left on the device (bench.py's product measurements)"""
+        check(lib().orc_solver_assemble_momentum(self.ptr, None, None, None, None, None, None, None))
+
     def snapshot(self):
         """device-side copy of the state the next SIMPLE iteration starts from"""
         check(lib().orc_solver_snapshot(self.ptr))
@@ -112,6 +116,13 @@ class Solver:
         ms, cs = C.c_double(0.0), C.c_double(0.0)
         check(lib().orc_bench_spmv(self.ptr, C.c_int(reps), C.byref(ms), C.byref(cs)))
         return ms.value, cs.value
+
+    def bench_inloop_products(self, reps=50):
+        """orc_bench_inloop_products: ms per launch of the level-0 products as the BiCGSTAB loop launches them —
+        (one system: EpiStoreSum, EpiTs; three systems in one launch: EpiStoreSum3, EpiTs3)."""
+        ms = (C.c_double * 4)()
+        check(lib().orc_bench_inloop_products(self.ptr, C.c_int(reps), ms))
+        return [ms[k] for k in range(4)]
 
     def bench_bicgstab_iteration(self, reps=20):
         ms = C.c_double(0.0)

@@ -10,8 +10,9 @@ for x in csv.DictReader(open(sys.argv[1])):
     rows.append((int(x["Start_Timestamp"]), int(x["End_Timestamp"]), x["Kernel_Name"].split("(")[0].replace("void ", "").replace("orc::", ""), x["Stream_Id"]))
 rows.sort()
 marks = [r[0] for r in rows if r[2].startswith("momentum_k")]
-a = marks[-1]
-b = min(r[1] for r in rows if r[2].startswith("correction_k") and r[0] >= a)  # the iteration ends with the correction
+corr = [r for r in rows if r[2].startswith("correction_k")]
+a = max(m for m in marks if any(c[0] >= m for c in corr))  # the last momentum assembly that a correction follows (bench.py assembles once more for its product timings)
+b = min(r[1] for r in corr if r[0] >= a)  # the iteration ends with the correction
 it = [r for r in rows if a <= r[0] <= b]
 pk = [r for r in it if r[2] == "pressure_k"]
 split = pk[-1][0]
@@ -31,3 +32,36 @@ for name, ph in (("momentum", [r for r in it if r[0] < split]), ("p'", [r for r 
         last = t
     print("%s: GPU non-idle %.1f ms; busy per stream %s" % (name, tot / 1e6, {k: round(v, 1) for k, v in sorted(busy.items())}))
     print("   ", ", ".join("%s %.0f" % kv for kv in sorted(cls.items(), key=lambda x: -x[1])[:9]))
+
+# ---- three-system schedule: when each family of kernels runs inside the momentum phase (ms from its start)
+def family(name):
+    if name.startswith("spmv3_uniform_k") or name.startswith("bicg_") and "3_k" in name:
+        return "L0/L1 lock-step products" if "spmv3" in name else "lock-step vector kernels"
+    if name.startswith("spmv_xwin_k") or name.startswith("spmv_k"):
+        return "levels 2-3 products"
+    if name.startswith("spmv_uniform_k"):
+        return "one-system level 0/1 products"
+    if name.startswith(("agg_", "tail_", "chase_", "chooser_k")):
+        return "aggregation"
+    if name.startswith(("galerkin_", "xwin_build", "slice_sizes", "scan")):
+        return "Galerkin + mirrors"
+    if name.startswith("bicg_"):
+        return "one-system vector kernels"
+    return None
+
+mom = [r for r in it if r[0] < split]
+fam = collections.defaultdict(list)
+for r in mom:
+    f = family(r[2])
+    if f:
+        fam[f].append(r)
+print("momentum phase by kernel family (first start .. last end, ms from the phase start; summed kernel time; launches):")
+for f, rs in sorted(fam.items(), key=lambda kv: min(r[0] for r in kv[1])):
+    print("  %-32s %7.1f .. %7.1f   %7.1f ms  %6d" % (f, (min(r[0] for r in rs) - a) / 1e6, (max(r[1] for r in rs) - a) / 1e6, sum(r[1] - r[0] for r in rs) / 1e6, len(rs)))
+l0 = [r for r in mom if r[2].startswith("spmv3_uniform_k") and r[2].rstrip().endswith("true>")]
+l1 = [r for r in mom if r[2].startswith("spmv3_uniform_k") and not r[2].rstrip().endswith("true>")]
+for nm, rs in (("level 0 lock-step products", l0), ("level 1 lock-step products", l1)):
+    if rs:
+        d = sorted(r[1] - r[0] for r in rs)
+        print("  %s: %d launches, median %.1f us, mean %.1f us, window %.1f .. %.1f ms" % (nm, len(rs), d[len(d) // 2] / 1e3, sum(d) / len(d) / 1e3,
+              (min(r[0] for r in rs) - a) / 1e6, (max(r[1] for r in rs) - a) / 1e6))

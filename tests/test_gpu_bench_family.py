@@ -54,29 +54,40 @@ def test_bench_channel_three_iterations_bit_exact_in_reference_order(gpu, oracle
 
 
 def test_bench_channel_product_default_follows_the_reference_trajectory(gpu, oracle):
-    """The timed configuration itself (product default) against the oracle in the reference's mode: the reports of four
-    iterations.  Frozen against in-place diagonals and tree against nalgebra-order sums change the transient in its low
-    digits only on this well-behaved size: 1e-3 relative on the correction norms, 1e-6 of the bulk velocity on the means."""
+    """The timed configuration itself (product default: frozen diagonals, tree reductions, guard) against the oracle: the
+    reports of four iterations (mean velocities, velocity- and pressure-correction norms, solver.rs:206-216).
+    * against the oracle with frozen diagonals only the association of the dot products differs: measured 4e-7 relative on the
+      norms in iteration 1, 2e-4 in iteration 4 (the reference's r_hat_0 = 1 BiCGSTAB amplifies rounding,
+      tests/test_oracle_sensitivity.py) — bar 1e-3 on the norms, 1e-6 on the means, 1e-4 rel-L2 on the fields;
+    * against the oracle in the reference's own in-place mode (DESIGN D1) the transient differs at the per-cent
+      level (measured 0.9 % in iteration 1, 0.01 % in iteration 4; same fixed point) — bar 2 %.
+    (scripts/probe_bench_family.py prints the numbers; at 80x32x32 the association alone moves iteration 3 by O(1).)"""
     from orc_amd.linear_algebra import breakdown_guard_events
     from orc_amd.settings import NumericalSettings
     from orc_amd.solver import Solver
     om, dm, a = _channel(oracle, (40, 16, 16))
     f0 = bench.initial_fields(np.asarray(a["cell_centroid"]))
-    ref = [np.ascontiguousarray(x).copy() for x in f0]
-    sto, rep_o = oracle.solve_steady(om, *ref, oracle.default_settings(frozen_diagonals=0, breakdown_guard=0, **BENCH_KW), 1000.0, 1e-3, 4,
-                                     report=True)
-    assert sto == 0
+    reps, refs = {}, {}
+    for frozen in (1, 0):
+        ref = [np.ascontiguousarray(x).copy() for x in f0]
+        sto, reps[frozen] = oracle.solve_steady(om, *ref, oracle.default_settings(frozen_diagonals=frozen, breakdown_guard=0, **BENCH_KW), 1000.0, 1e-3, 4,
+                                                report=True)
+        assert sto == 0
+        refs[frozen] = ref
     ev0 = breakdown_guard_events()
     s = Solver(dm, NumericalSettings.default(**BENCH_KW), 1000.0, 1e-3)
     s.set_fields(*f0)
     std, rep_d = s.iterate(4, report=True, raise_on_error=False)
     assert std == 0
     assert breakdown_guard_events() == ev0  # no solve of the timed configuration was frozen
-    u_bulk = abs(rep_o[0, 0])
-    for it in range(4):
-        # device report: means 0-2, Peclet 3-5, velocity correction 6, pressure correction 7; oracle: means 0-2, Peclet 3, 4, 5
-        assert np.allclose(rep_d[it, 0:3], rep_o[it, 0:3], rtol=0, atol=1e-6 * u_bulk), (it, rep_d[it], rep_o[it])
-        assert abs(rep_d[it, 6] - rep_o[it, 4]) <= 1e-3 * rep_o[it, 4], (it, rep_d[it, 6], rep_o[it, 4])
-        assert abs(rep_d[it, 7] - rep_o[it, 5]) <= 1e-3 * rep_o[it, 5], (it, rep_d[it, 7], rep_o[it, 5])
-    for x, y in zip(s.get_fields(), ref):
-        assert H.rel_l2(x, y) < 1e-5
+    for frozen, tol_norm, tol_mean in ((1, 1e-3, 1e-6), (0, 2e-2, 1e-2)):
+        rep_o = reps[frozen]
+        u_bulk = abs(rep_o[0, 0])
+        for it in range(4):
+            # device report: means 0-2, Peclet 3-5, velocity correction 6, pressure correction 7; oracle: means 0-2, Peclet 3, 4, 5
+            assert np.allclose(rep_d[it, 0:3], rep_o[it, 0:3], rtol=0, atol=tol_mean * u_bulk), (frozen, it, rep_d[it], rep_o[it])
+            assert abs(rep_d[it, 6] - rep_o[it, 4]) <= tol_norm * rep_o[it, 4], (frozen, it, rep_d[it, 6], rep_o[it, 4])
+            assert abs(rep_d[it, 7] - rep_o[it, 5]) <= tol_norm * rep_o[it, 5], (frozen, it, rep_d[it, 7], rep_o[it, 5])
+    un = np.linalg.norm(refs[1][0])
+    for k, (x, y) in enumerate(zip(s.get_fields(), refs[1])):
+        assert np.linalg.norm(x - y) < 1e-4 * (un if k < 3 else np.linalg.norm(y))
