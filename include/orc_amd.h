@@ -327,6 +327,11 @@ int orc_comm_finalize(void);
 /* One-GPU self-check of the RCCL data path (single-rank communicator, rank 0 as its own neighbour): halo exchange of
  * two fields, sum/max all-reduce, status agreement.  Needs an uninitialised communicator. */
 int orc_comm_selftest(void);
+/* Debug/test: a persistent single-rank RCCL communicator posing as a two-rank world whose only peer is this rank.  A
+ * partitioned mesh whose halo plan names peer 0 everywhere then runs the whole partitioned path (RCCL halos, all-reduces,
+ * status agreement, the products that overlap their halo exchange) on ONE GPU; the run is self-coupled (ghost values are
+ * the rank's own cells), so it is compared with itself under other switches.  Ended by orc_comm_finalize. */
+int orc_comm_init_self_loop(void);
 /* Debug transport for tests where ranks share one GPU (RCCL refuses duplicate devices): halo exchange and all-reduce
  * are staged through host memory and carried by the caller's callbacks (e.g. torch.distributed/gloo).
  * exchange_fn: void(int n_peers, const int* peers, const double* send, const int64_t* send_off, const int64_t* send_cnt,

@@ -1286,6 +1286,13 @@ static int solve_momentum_partitioned(SolverState &s) {
         L.arena.release(Arena::Mark{0, 0});
         int st = multigrid_prepare_dev(plain[k], t.preconditioner, L.arena, L.hierarchy);  // (2)
         if (st == ORC_OK && hipStreamSynchronize(local[k].stream) != hipSuccess) st = set_error(ORC_ERR_HIP, "stream synchronisation failed in a solve thread");
+        // test hook (tests/mp_worker.py, mode gpu_lane_error): ORC_DEBUG_INJECT_LANE_ERROR="rank:lane" makes that rank's lane fail
+        // locally after its set-up — every rank must still leave the solve with the same verdict and nobody may hang
+        if (const char *inj = getenv("ORC_DEBUG_INJECT_LANE_ERROR")) {
+            int r_ = -1, k_ = -1;
+            if (sscanf(inj, "%d:%d", &r_, &k_) == 2 && r_ == local[k].rank && k_ == k && st == ORC_OK)
+                st = set_error(ORC_ERR_HIP, "injected lane error (rank %d, lane %d)", r_, k_);
+        }
         {
             std::unique_lock<std::mutex> lk(mu);
             cv.wait(lk, [&] { return ready[k] || abort_all; });

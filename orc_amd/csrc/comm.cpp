@@ -195,6 +195,26 @@ int orc_comm_selftest(void) {
     return st;
 }
 
+// Debug/test: a persistent single-rank RCCL communicator that poses as a two-rank world in which every peer is this rank (what
+// orc_comm_selftest sets up for the duration of one call).  A partitioned mesh whose halo plan names peer 0 everywhere then
+// runs the WHOLE partitioned path — grouped ncclSend/ncclRecv halos, ncclAllReduce, the status agreement, the momentum lanes
+// and the level-0 products that overlap their exchange (the `exchange_first` branch, which the host-staged transport cannot
+// take) — on one GPU.  Its ghost values are the rank's own cells, so the run is self-coupled, not a cut of a larger mesh: it
+// is compared with itself under ORC_HALO_OVERLAP=0, not with a single-rank run.  orc_comm_finalize ends it.
+int orc_comm_init_self_loop(void) {
+    ORC_TRY(orc::ensure_init());
+    orc::Ctx &c = orc::ctx();
+    if (c.nccl_comm || c.world != 1) return orc::set_error(ORC_ERR_BAD_ARGUMENT, "the self-loop communicator needs an uninitialised communicator");
+    ncclUniqueId uid;
+    ORC_NCCL(ncclGetUniqueId(&uid));
+    ncclComm_t comm;
+    ORC_NCCL(ncclCommInitRank(&comm, 1, uid, 0));
+    c.nccl_comm = comm;
+    c.rank = 0;
+    c.world = 2;
+    return ORC_OK;
+}
+
 int orc_comm_finalize(void) {
     orc::Ctx &c = orc::ctx();
     if (c.nccl_comm) {

@@ -30,11 +30,80 @@ def test_overlapped_level0_product_two_ranks(gpu):
 
 
 def test_two_ranks_converged_default_stack_matches_the_oracle(gpu):
-    """channel_flow.msh cut in two by orc_mesh_partition (ORC order and RCM), the reference's default stack run partitioned to
-    convergence: u, v, w, p within 1e-6 rel-L2 of the oracle's converged fields (the north-star criterion at N = 2)."""
+    """channel_flow.msh cut in two by orc_mesh_partition (RCM order), the reference's default stack run partitioned to
+    convergence (700 SIMPLE iterations, velocity-correction norm < 1e-8): u, v, w, p within 1e-6 rel-L2 of the oracle's
+    converged fields (the north-star criterion at N = 2).  About four minutes: every halo and all-reduce is staged through
+    the host."""
     r = launch(2, "gpu_converged", timeout=1500)
     print(r.stdout[-1500:])
     assert "MP_WORKER_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-4000:]
+
+
+def test_lane_error_on_one_rank_reaches_every_rank(gpu):
+    """Status agreement of the partitioned momentum solve on its failing path: an error injected into one lane of one rank
+    (after its hierarchy set-up, before its coarse levels) leaves every rank with the same non-zero status — no rank waits in a
+    collective for one that has gone — for every rank x lane; the next iteration is clean."""
+    r = launch(2, "gpu_lane_error", timeout=900)
+    print(r.stdout[-1500:])
+    assert "MP_WORKER_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-4000:]
+
+
+def test_rccl_overlapped_product_on_a_self_loop_communicator(gpu):
+    """The RCCL branch of the level-0 products that overlap their halo exchange (`exchange_first`: the exchange is queued on the
+    library stream, the interior slices run on a second stream beside the RCCL kernels) cannot be reached by two ranks on one
+    GPU (RCCL refuses duplicate devices; the host-staged transport takes the other branch).  A single-rank communicator posing
+    as its own neighbour (orc_comm_init_self_loop) runs it: the whole partitioned path with real ncclSend/ncclRecv halos and
+    ncclAllReduce on one GPU, self-coupled, compared with the same run under ORC_HALO_OVERLAP=0 (only the layout of the partial
+    sums differs) and counted by orc_debug_halo_overlaps."""
+    import ctypes
+    import os
+    import numpy as np
+    from orc_amd import parallel
+    from orc_amd._lib import check, lib
+    from orc_amd.mesh import set_channel_bcs
+    from orc_amd.settings import NumericalSettings
+    from orc_amd.solver import Solver
+    import mp_worker
+    L = lib()
+    L.orc_debug_halo_overlaps.restype = ctypes.c_longlong
+    nx, ny, nzl = 40, 26, 16  # 260 slices, 17 of them along the cut: the interior run is long enough to overlap
+    a, halo, gids = parallel.slab_arrays(nx, ny, nzl, 0, 2)
+    set_channel_bcs(a)
+    halo = dict(halo)
+    halo["peers"] = np.zeros_like(np.asarray(halo["peers"]))  # the only peer is this rank
+    from orc_amd.mesh import hex_channel
+    ag = set_channel_bcs(hex_channel(nx, ny, nzl * 2))
+    ug = mp_worker.global_fields(ag)
+    check(L.orc_comm_init_self_loop())
+    try:
+        # the two forms differ in the layout of the partial sums only; the reference's r_hat_0 = 1 BiCGSTAB amplifies that last-bit
+        # difference quickly (tests/test_oracle_sensitivity.py), so the sharp comparisons are the one-iteration runs — a wrong or
+        # stale row would show at O(1) there (same cases and bars as the host-transport test, mp_worker.gpu_overlap_checks)
+        for name, kw, its, tol in (("bicgstab-1", dict(momentum=5, solver_type=3, iterations=1), 1, 1e-13),
+                                   ("multigrid-1", dict(momentum=1, solver_type=2, iterations=1), 1, 1e-11),
+                                   ("bicgstab", dict(momentum=5, solver_type=3, iterations=8), 2, 1e-7),
+                                   ("multigrid", dict(momentum=1, solver_type=2, iterations=20), 2, 0.05)):
+            runs = {}
+            for form in ("overlapped", "plain"):
+                if form == "plain":
+                    os.environ["ORC_HALO_OVERLAP"] = "0"
+                try:
+                    before = L.orc_debug_halo_overlaps()
+                    sol = Solver(parallel.PartitionedMesh(a, halo), NumericalSettings.default(**kw), 1000.0, 1e-3)
+                    sol.set_fields(*[f[gids] for f in ug])
+                    st = sol.iterate(its, raise_on_error=False)
+                    runs[form] = (st, sol.get_fields(), L.orc_debug_halo_overlaps() - before)
+                finally:
+                    os.environ.pop("ORC_HALO_OVERLAP", None)
+            n_own = halo["n_owned"]
+            (st, f, overlapped), (st_p, f_p, overlapped_p) = runs["overlapped"], runs["plain"]
+            assert st == st_p == 0, name
+            assert overlapped > 0 and overlapped_p == 0, (name, overlapped, overlapped_p)
+            for x, y in zip(f, f_p):
+                assert np.isfinite(x[:n_own]).all()
+                assert np.linalg.norm(x[:n_own] - y[:n_own]) <= tol * max(np.linalg.norm(y[:n_own]), 1e-300), name
+    finally:
+        check(L.orc_comm_finalize())
 
 
 def test_rccl_selftest_single_rank(gpu):
