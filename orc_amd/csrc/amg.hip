@@ -1838,7 +1838,7 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
     ORC_TRY(arena.alloc((size_t)std::max<int64_t>(padded, 1), &col));
     ORC_TRY(arena.alloc((size_t)std::max<int64_t>(padded, 1), &val));
     SellDev Pc;
-    Pc.n = nc; Pc.ncols = nc; Pc.n_slices = n_slices; Pc.ragged = padded < 24 * nc ? 2 : 1; Pc.slice_ptr = slice_ptr; Pc.row_len = row_len; Pc.col = col; Pc.diag_pos = diag;
+    Pc.n = nc; Pc.ncols = nc; Pc.n_slices = n_slices; Pc.ragged = padded < 24 * nc ? 2 : 1; Pc.padded = padded; Pc.slice_ptr = slice_ptr; Pc.row_len = row_len; Pc.col = col; Pc.diag_pos = diag;
     // Packed mirror + LDS x windows for the levels whose rows are long enough for a window to be re-used (measured at
     // 10.24 M fine rows: 33 entries per row +2 %, 70 entries per row +17 % against the padded product; 15 entries per row
     // -10 %, so that level keeps the padded image).  ORC_SPMV_XWIN_MIN_NNZ < 0 switches the mirror off.
@@ -2171,6 +2171,18 @@ int multigrid_arm3_dev(const MatView3 &A3, const double *const b[3], double *con
         try { th[k] = std::thread(prepare, k); } catch (...) { /* no thread to be had: prepared below, before the join */ }
     }
 
+    // ORC_TRIPLE_SETUP_FIRST=1 (measurement): the three set-ups run with the chip to themselves, the level-0 solve follows (beside the
+    // p' hierarchy, which the callback starts) instead of sharing the chip with them
+    static const bool setup_first = getenv("ORC_TRIPLE_SETUP_FIRST") && atoi(getenv("ORC_TRIPLE_SETUP_FIRST")) != 0;
+    auto join_hierarchies = [&] {
+        for (int k = 0; k < 3; ++k) {
+            if (th[k].joinable()) th[k].join();
+            if (!prepared[k]) prepare(k);
+        }
+        if (on_hierarchies_built) on_hierarchies_built();
+    };
+    if (setup_first) join_hierarchies();
+
     // ---- level 0 in lock-step
     double *b3, *x3, *r3;
     int *dev_status;
@@ -2196,11 +2208,7 @@ int multigrid_arm3_dev(const MatView3 &A3, const double *const b[3], double *con
     ORC_TRY(residual3_dev(V, bp3, x3, r3));                                       // :283
 
     // ---- the hierarchies
-    for (int k = 0; k < 3; ++k) {
-        if (th[k].joinable()) th[k].join();
-        if (!prepared[k]) prepare(k);
-    }
-    if (on_hierarchies_built) on_hierarchies_built();
+    if (!setup_first) join_hierarchies();
     for (int k = 0; k < 3; ++k)
         if (st_prep[k] != ORC_OK) { g.last_error = local[k].last_error; return st_prep[k]; }
     const AmgHierarchy *H[3] = {&lanes[0].hierarchy, &lanes[1].hierarchy, &lanes[2].hierarchy};

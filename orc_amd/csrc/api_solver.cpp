@@ -552,6 +552,7 @@ int orc_bench_inloop_products(OrcSolver *s, int reps, double avg_ms[4]) {
         ORC_TRY(diag_inverse_dev(A, d2));
         A.s2 = d2;
     }
+    ORC_TRY(materialize_scaled_view(A, t.settings.iterations, t.arena));  // as a smoothing solve of the configured length does
     float ms[2];
     ORC_TRY(bench_inloop_products_dev(A, t.u.p, y, partials, reps, ms));
     avg_ms[0] = ms[0]; avg_ms[1] = ms[1];
@@ -573,6 +574,7 @@ int orc_bench_inloop_products(OrcSolver *s, int reps, double avg_ms[4]) {
             ORC_TRY(diag_inverse3_dev(A3, e2));
             A3.s2 = e2;
         }
+        ORC_TRY(materialize_scaled_view3(A3, t.settings.iterations, t.arena));
         ORC_TRY(bench_inloop_products3_dev(A3, x3, y3, partials, reps, ms));
         avg_ms[2] = ms[0]; avg_ms[3] = ms[1];
     }
@@ -650,6 +652,7 @@ int orc_bench_amg_levels(OrcSolver *s, int reps, int64_t *rows, int64_t *nnz, in
                 V.s2 = d2;
             }
         }
+        ORC_TRY(materialize_scaled_view(V, t.settings.iterations, t.arena));  // levels 0 and 1, as their smoothing solves do
         ORC_TRY(spmv_dev(V, x, y));
         ORC_HIP(hipEventRecord(e0, ctx().stream));
         for (int i = 0; i < reps; ++i) ORC_TRY(spmv_dev(V, x, y));

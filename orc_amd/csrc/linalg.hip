@@ -628,10 +628,52 @@ static int bicg_iteration(const MatView &A, double *x, const BicgWork &w, uint64
     return ORC_OK;
 }
 
-static int bicgstab_dev(const MatView &A, const double *b, double *x, uint64_t iteration_count, Arena &arena) {
-    const int64_t n = A.P.n;
+// Jacobi-scaled values, materialised: out[p] = s2[row] * (s1[row] * val[p]) — the product kernels' own expression, evaluated once per
+// solve instead of once per product.  The reference materialises `p_inv * a` too (linear_algebra.rs:159-166); on the device the
+// point is bytes: a level-0 product is bandwidth-bound at 5.6 TB/s of real traffic (profiles/r03_pmc_products.csv) and the two
+// scaling vectors are 16 of its ~125 bytes per row — read 101 times per smoothing solve, against one extra pass over the values.
+__global__ __launch_bounds__(kBlock) void scale_values_k(MatView A, double *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    SliceWalk w(A.P.n_slices);
+    for (int64_t slice = w.begin; slice < w.end; slice += w.step) {
+        const int64_t row = slice * 64 + lane;
+        const int64_t base = A.P.slice_ptr[slice];
+        const int width = (int)((A.P.slice_ptr[slice + 1] - base) >> 6);
+        const bool live = row < A.P.n;
+        const double s1 = (A.s1 && live) ? A.s1[row] : 1.;
+        const double s2 = (A.s2 && live) ? A.s2[row] : 1.;
+        for (int k = 0; k < width; ++k) {
+            const int64_t p = base + (int64_t)k * 64 + lane;
+            double t = A.val[p];
+            if (A.s1) t = s1 * t;
+            if (A.s2) t = s2 * t;
+            out[p] = t;
+        }
+    }
+}
+// from how many iterations on a solve materialises its scaled values (ORC_MATERIALIZE_SCALING=0: never)
+static inline bool materialize_scaling(uint64_t iteration_count) {
+    static const int min_its = getenv("ORC_MATERIALIZE_SCALING") ? atoi(getenv("ORC_MATERIALIZE_SCALING")) : 4;
+    return min_its > 0 && iteration_count >= (uint64_t)min_its;
+}
+
+int materialize_scaled_view(MatView &A, uint64_t iteration_count, Arena &arena) {
+    if (!((A.s1 || A.s2) && A.P.padded > 0 && !A.pk.ptr && A.P.n > 0 && materialize_scaling(iteration_count))) return ORC_OK;
+    double *scaled;
+    ORC_TRY(arena.alloc((size_t)A.P.padded, &scaled));
+    hipLaunchKernelGGL(scale_values_k, dim3(spmv_grid(A.P.n_slices)), dim3(kBlock), 0, ctx().stream, A, scaled);
+    ORC_HIP(hipGetLastError());
+    A.val = scaled;
+    A.s1 = A.s2 = nullptr;
+    return ORC_OK;
+}
+
+static int bicgstab_dev(const MatView &A_in, const double *b, double *x, uint64_t iteration_count, Arena &arena) {
+    const int64_t n = A_in.P.n;
     if (n == 0) return ORC_OK;
     ArenaScope scope(arena);
+    MatView A = A_in;
+    ORC_TRY(materialize_scaled_view(A, iteration_count, arena));
     BicgWork w;
     ORC_TRY(bicg_alloc(arena, std::max(A.P.ncols, n), w));
     const int guard = ctx().breakdown_guard ? 1 : 0;
@@ -831,6 +873,41 @@ int diag_inverse3_dev(const MatView3 &A, double *dinv3) {
     if (A.P.n == 0) return ORC_OK;
     hipLaunchKernelGGL(diag_inverse3_k, dim3(grid_for(A.P.n)), dim3(kBlock), 0, ctx().stream, A, dinv3);
     ORC_HIP(hipGetLastError());
+    return ORC_OK;
+}
+
+// scale_values_k for system `sys` of a MatView3 (scalings interleaved)
+__global__ __launch_bounds__(kBlock) void scale_values3_k(MatView3 A, int sys, double *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const double *__restrict__ val = A.val[sys];
+    SliceWalk w(A.P.n_slices);
+    for (int64_t slice = w.begin; slice < w.end; slice += w.step) {
+        const int64_t row = slice * 64 + lane;
+        const int64_t base = A.P.slice_ptr[slice];
+        const int width = (int)((A.P.slice_ptr[slice + 1] - base) >> 6);
+        const bool live = row < A.P.n;
+        const double s1 = (A.s1 && live) ? A.s1[3 * row + sys] : 1.;
+        const double s2 = (A.s2 && live) ? A.s2[3 * row + sys] : 1.;
+        for (int k = 0; k < width; ++k) {
+            const int64_t p = base + (int64_t)k * 64 + lane;
+            double t = val[p];
+            if (A.s1) t = s1 * t;
+            if (A.s2) t = s2 * t;
+            out[p] = t;
+        }
+    }
+}
+
+int materialize_scaled_view3(MatView3 &A, uint64_t iteration_count, Arena &arena) {
+    if (!((A.s1 || A.s2) && A.P.padded > 0 && A.P.n > 0 && materialize_scaling(iteration_count))) return ORC_OK;
+    for (int s = 0; s < 3; ++s) {
+        double *scaled;
+        ORC_TRY(arena.alloc((size_t)A.P.padded, &scaled));
+        hipLaunchKernelGGL(scale_values3_k, dim3(spmv_grid(A.P.n_slices)), dim3(kBlock), 0, ctx().stream, A, s, scaled);
+        A.val[s] = scaled;  // the kernel reads A.val[sys] only; the scalings are dropped once all three are through
+    }
+    ORC_HIP(hipGetLastError());
+    A.s1 = A.s2 = nullptr;
     return ORC_OK;
 }
 
@@ -1075,6 +1152,7 @@ int bicgstab3_dev(const MatView3 &A_in, const double *b3_in, double *x3, uint64_
     } else if (preconditioner != ORC_PRECOND_NONE) {
         return set_error(ORC_ERR_BAD_ARGUMENT, "unknown preconditioner %d", preconditioner);
     }
+    ORC_TRY(materialize_scaled_view3(A, iteration_count, arena));
     double *r3, *p3, *nu3, *s3, *t3, *partials, *partials2, *scal3;
     ORC_TRY(arena.alloc(n3, &r3));
     ORC_TRY(arena.alloc(n3, &p3));
