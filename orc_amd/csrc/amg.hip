@@ -1861,7 +1861,7 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
     static const bool rows_enabled = !(getenv("ORC_AMG_ROWS_MIRROR") && atoi(getenv("ORC_AMG_ROWS_MIRROR")) == 0);
     if (rows_enabled) { L.rows.slice_base = slice_base; L.rows.intra_off = intra_off; L.rows.col = s_col; L.rows.val = s_val; }
     if (mirror) {
-        L.pk.ptr = pk_ptr; L.pk.col = pk_col; L.pk.val = pk_val;
+        L.pk.ptr = pk_ptr; L.pk.col = pk_col; L.pk.val = pk_val; L.pk.total = packed_total;
         const int64_t n_blocks = ((int64_t)n_slices + 3) / 4;
         int *wcol, *wsize;
         unsigned short *lidx;

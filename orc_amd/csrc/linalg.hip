@@ -299,9 +299,20 @@ static int launch_spmv(const MatView &A, const double *x, const Epi &epi, double
     int g = spmv_grid(A.P.n_slices);
     const int variant = ctx().spmv_variant;  // measurement hook (orc_debug_set_spmv_variant); 0 in production
     const bool xwin = A.xw.lidx != nullptr && A.pk.ptr != nullptr && (variant == 0 || (variant >= 20 && variant <= 22));
-    if (xwin) {  // one workgroup per 256-row block, at most 5 resident per CU (32 KB of LDS each)
+    if (xwin) {
+        // One workgroup per 256-row block.  The blocks differ in cost (row lengths; blocks without a window gather from global
+        // memory), and a workgroup's share is fixed, so MORE workgroups than are resident balance better: r02's 5 per CU left the
+        // chip at 10 of 20 waves per CU on average (profiles/r03_pmc_products.csv: SQ_WAVE_CYCLES / GRBM_GUI_ACTIVE; 4 are resident
+        // with 32.7 KB of LDS and 92-96 VGPRs each); 8 per CU = the 2048 partial sums a product may write (kMaxPartials) measured
+        // level 2: 251 -> 245 us, level 3: 289 -> 270 us.
+        static const int per_cu = getenv("ORC_XWIN_WGS_PER_CU") ? std::max(1, std::min(8, atoi(getenv("ORC_XWIN_WGS_PER_CU")))) : 8;
+        static const int n_cu = [] {
+            hipDeviceProp_t prop;
+            int dev = 0;
+            return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        }();
         int64_t gb = ((int64_t)A.P.n_slices + 3) / 4;
-        if (gb > 256 * 5) gb = 256 * 5;
+        if (gb > (int64_t)n_cu * per_cu) gb = (int64_t)n_cu * per_cu;
         if (gb >= 8) gb = (gb / 8) * 8;
         g = (int)std::max<int64_t>(gb, 1);
     }
@@ -359,6 +370,7 @@ static int launch_spmv(const MatView &A, const double *x, const Epi &epi, double
     if (xwin) {
         if (variant == 21) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_xwin_k<Epi, 1>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
         else if (variant == 22) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_xwin_k<Epi, 2>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
+        else if (!A.s1 && !A.s2) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_xwin_k<Epi, 0, false>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_xwin_k<Epi>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
         ORC_HIP(hipGetLastError());
         return ORC_OK;
@@ -657,8 +669,48 @@ static inline bool materialize_scaling(uint64_t iteration_count) {
     return min_its > 0 && iteration_count >= (uint64_t)min_its;
 }
 
+// the same over a packed mirror (PackedDev): entries of depth k of a slice sit back to back in lane order
+__global__ __launch_bounds__(kBlock) void scale_packed_k(MatView A, double *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    SliceWalk w(A.P.n_slices);
+    for (int64_t slice = w.begin; slice < w.end; slice += w.step) {
+        const int64_t row = slice * 64 + lane;
+        const int width = (int)((A.P.slice_ptr[slice + 1] - A.P.slice_ptr[slice]) >> 6);
+        const bool live = row < A.P.n;
+        const int len = live ? A.P.row_len[row] : 0;
+        const double s1 = (A.s1 && live) ? A.s1[row] : 1.;
+        const double s2 = (A.s2 && live) ? A.s2[row] : 1.;
+        int64_t off = A.pk.ptr[slice];
+        for (int k = 0; k < width; ++k) {
+            const bool in = k < len;
+            const unsigned long long m = __ballot(in);
+            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            if (in) {
+                double t = A.pk.val[off + rank];
+                if (A.s1) t = s1 * t;
+                if (A.s2) t = s2 * t;
+                out[off + rank] = t;
+            }
+            off += __popcll(m);
+        }
+    }
+}
+
 int materialize_scaled_view(MatView &A, uint64_t iteration_count, Arena &arena) {
-    if (!((A.s1 || A.s2) && A.P.padded > 0 && !A.pk.ptr && A.P.n > 0 && materialize_scaling(iteration_count))) return ORC_OK;
+    if (!((A.s1 || A.s2) && A.P.n > 0 && materialize_scaling(iteration_count))) return ORC_OK;
+    if (A.pk.ptr) {
+        // levels with a packed mirror + LDS windows: their products stream pk.val only (launch_spmv: production variant)
+        if (!(A.xw.lidx && A.pk.total > 0 && ctx().spmv_variant == 0)) return ORC_OK;
+        double *scaled;
+        ORC_TRY(arena.alloc((size_t)A.pk.total, &scaled));
+        hipLaunchKernelGGL(scale_packed_k, dim3(spmv_grid(A.P.n_slices)), dim3(kBlock), 0, ctx().stream, A, scaled);
+        ORC_HIP(hipGetLastError());
+        A.pk.val = scaled;
+        A.val = nullptr;  // the padded image keeps the unscaled values: nothing may read it through this view
+        A.s1 = A.s2 = nullptr;
+        return ORC_OK;
+    }
+    if (A.P.padded <= 0) return ORC_OK;
     double *scaled;
     ORC_TRY(arena.alloc((size_t)A.P.padded, &scaled));
     hipLaunchKernelGGL(scale_values_k, dim3(spmv_grid(A.P.n_slices)), dim3(kBlock), 0, ctx().stream, A, scaled);

@@ -37,6 +37,7 @@ struct PackedDev {
     const int64_t *ptr = nullptr;  // [n_slices+1] element offsets, multiples of 16 (128-byte aligned values)
     const int32_t *col = nullptr;
     const double *val = nullptr;
+    int64_t total = 0;             // stored entries (ptr[n_slices]) when the host knows it, else 0
 };
 
 // LDS-staged x tiles for the packed mirror (BASELINE north star: "LDS-staged x-vector tiles").  Rows are taken in

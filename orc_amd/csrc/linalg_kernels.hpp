@@ -382,7 +382,10 @@ __global__ __launch_bounds__(kBlock) void spmv_pipe_k(MatView A, const double *_
 // Product on the packed mirror with LDS-staged x windows (XWinDev): one workgroup per block of 256 rows, its 4 waves on
 // the block's 4 slices.  Workgroups b and b + 8 share an XCD, so XCD g walks a contiguous eighth of the blocks.
 // kDebug (measurement only): 1 = window loads skipped, 2 = stream phase skipped
-template <class Epi, int kDebug = 0>
+// kScaled = false: the view carries no row scaling (a smoothing solve has materialised its scaled values, materialize_scaled_view):
+// the two scaling multiplications per entry and their selects are not compiled in — the stream loop of this kernel is bound by
+// instruction issue as much as by memory (39 vector instructions per entry and wavefront, profiles/r03_pmc_products.csv)
+template <class Epi, int kDebug = 0, bool kScaled = true>
 __global__ __launch_bounds__(kBlock) void spmv_xwin_k(MatView A, const double *__restrict__ x, Epi epi, double *__restrict__ partials,
                                                       const double *__restrict__ skip_flags) {
     __shared__ double lds[8];
@@ -432,8 +435,8 @@ __global__ __launch_bounds__(kBlock) void spmv_xwin_k(MatView A, const double *_
             const int width = (int)((A.P.slice_ptr[slice + 1] - base) >> 6);
             const bool live = row < A.P.n;
             const int len = live ? A.P.row_len[row] : 0;
-            const double s1 = (A.s1 && live) ? A.s1[row] : 1.;
-            const double s2 = (A.s2 && live) ? A.s2[row] : 1.;
+            const double s1 = (kScaled && A.s1 && live) ? A.s1[row] : 1.;
+            const double s2 = (kScaled && A.s2 && live) ? A.s2[row] : 1.;
             double acc = 0.;
             int64_t pk_off = A.pk.ptr[slice];
             if (ws >= 0) {
@@ -469,8 +472,8 @@ __global__ __launch_bounds__(kBlock) void spmv_xwin_k(MatView A, const double *_
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         double t = v[u];
-                        if (A.s1) t = s1 * t;
-                        if (A.s2) t = s2 * t;
+                        if (kScaled && A.s1) t = s1 * t;
+                        if (kScaled && A.s2) t = s2 * t;
                         const double next = acc + t * xv[u];
                         acc = (k0 + u < len) ? next : acc;
                     }
@@ -498,8 +501,8 @@ __global__ __launch_bounds__(kBlock) void spmv_xwin_k(MatView A, const double *_
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         double t = v[u];
-                        if (A.s1) t = s1 * t;
-                        if (A.s2) t = s2 * t;
+                        if (kScaled && A.s1) t = s1 * t;
+                        if (kScaled && A.s2) t = s2 * t;
                         const double next = acc + t * xv[u];
                         acc = (k0 + u < len) ? next : acc;
                     }
