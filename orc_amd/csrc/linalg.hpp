@@ -49,7 +49,7 @@ struct PackedDev {
 // instead of 8 + 4.  Same values, same order, same sums.  A block whose window does not fit (wsize < 0) keeps the
 // global gathers.
 constexpr int kXWinRows = 256;   // rows per block = 4 slices = one workgroup
-constexpr int kXWinCap = 4080;   // window entries per block (just under 32 KB of LDS: five workgroups per CU)
+constexpr int kXWinCap = 5000;   // window entries per block: 40 KB of LDS, four workgroups per CU (r02: 4080 "for five" — four were resident)
 struct XWinDev {
     const int32_t *wcol = nullptr;   // [n_blocks * kXWinCap]
     const int32_t *wsize = nullptr;  // [n_blocks], -1 = no window for this block

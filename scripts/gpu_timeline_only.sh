@@ -1,0 +1,7 @@
+#!/bin/bash
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+env "$@" timeout -k 10 400 rocprofv3 --kernel-trace -d gpurun_out/tl --output-format csv -- python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline > gpurun_out/tl.log 2>&1
+f=$(ls gpurun_out/tl/*/*kernel_trace.csv | head -1)
+python3 scripts/timeline.py "$f"
+rm -rf gpurun_out/tl
