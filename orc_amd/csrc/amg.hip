@@ -395,7 +395,15 @@ __global__ __launch_bounds__(1024) void tail_small_k(MatView A, int *choice, int
 // performed at the device's coherence point, so all that is needed is to wait for the previous ones to complete before
 // the next is issued (s_waitcnt).  A device-scope fence would also write back and invalidate the XCD's L2 — measured at
 // hundreds of microseconds per fence with thousands of wavefronts doing it — and there is no plain shared data to flush.
-__device__ __forceinline__ void chase_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+// The workgroup-scope fence keeps the COMPILER from moving accesses across this point; the wait makes the HARDWARE finish every
+// outstanding vector-memory access of this wavefront (the relaxed agent-scope atomics above it: stores and returning atomics
+// count in vmcnt, loads too) before the next one is issued — at workgroup scope the fence alone need not wait for global stores
+// to be performed.  No cache is written back or invalidated.
+__device__ __forceinline__ void chase_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) expcnt(0) lgkmcnt(0)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+}
 __device__ __forceinline__ int ld_i(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_i(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ int first_taker(const unsigned long long *tb, int j) {

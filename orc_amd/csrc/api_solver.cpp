@@ -208,6 +208,18 @@ int orc_solver_get_fields(OrcSolver *s, double *u, double *v, double *w, double 
 }
 
 namespace {
+// one device vector of the mesh's internal cell order -> the caller's array in ORC cell order (orc_mesh_create_reordered)
+int download_in_orc_order(const OrcMesh &m, const DevBuf<double> &src, double *dst, size_t n) {
+    const std::vector<int64_t> &g = m.h_global_ids;
+    if (g.empty()) return src.download(dst, n);
+    std::vector<double> tmp(n);
+    ORC_TRY(src.download(tmp.data(), n));
+    for (size_t c = 0; c < n; ++c) dst[g[c]] = tmp[c];
+    return ORC_OK;
+}
+}  // namespace
+
+namespace {
 // A drop-in for solver::solve_steady must not hide that the breakdown guard (default on) kept a solve alive where the
 // reference divides 0/0 and panics "solution diverged" (solver.rs:217-221): an ORC_OK return then carries a note.
 struct GuardNote {
@@ -417,9 +429,18 @@ int orc_initialize_pressure_field(const OrcMesh *m, double *p) {
     const OrcSettings t = initializer_settings(nullptr);
     auto s = std::make_unique<OrcSolver>();
     ORC_TRY(solver_init(s->st, const_cast<OrcMesh *>(m), &t, 1.0, 1.0));
-    ORC_TRY(s->st.p.upload(p, (size_t)s->st.n));
+    {  // the incoming p (the reference overwrites it) in the mesh's internal order, the result back in ORC order
+        const std::vector<int64_t> &g = m->h_global_ids;
+        const size_t n = (size_t)s->st.n;
+        if (g.empty()) ORC_TRY(s->st.p.upload(p, n));
+        else {
+            std::vector<double> tmp(n);
+            for (size_t c = 0; c < n; ++c) tmp[c] = p[g[c]];
+            ORC_TRY(s->st.p.upload(tmp.data(), n));
+        }
+    }
     int st = initialize_pressure_field_dev(s->st);
-    ORC_TRY(s->st.p.download(p, (size_t)s->st.n));
+    ORC_TRY(download_in_orc_order(*m, s->st.p, p, (size_t)s->st.n));
     return st;
 }
 
@@ -443,10 +464,10 @@ int orc_initialize_velocity_field(const OrcMesh *m, const OrcSettings *settings,
     ORC_TRY(solver_init(s->st, const_cast<OrcMesh *>(m), &t, 1.0, 1.0));
     int st = initialize_velocity_field_dev(s->st);
     const size_t n = (size_t)s->st.n;
-    int st2 = s->st.u.download(u, n);
-    if (st2 == ORC_OK) st2 = s->st.v.download(v, n);
-    if (st2 == ORC_OK) st2 = s->st.w.download(w, n);
-    if (st2 == ORC_OK && psi) st2 = s->st.p_prime.download(psi, n);
+    int st2 = download_in_orc_order(*m, s->st.u, u, n);
+    if (st2 == ORC_OK) st2 = download_in_orc_order(*m, s->st.v, v, n);
+    if (st2 == ORC_OK) st2 = download_in_orc_order(*m, s->st.w, w, n);
+    if (st2 == ORC_OK && psi) st2 = download_in_orc_order(*m, s->st.p_prime, psi, n);
     return st != ORC_OK ? st : st2;
 }
 

@@ -125,7 +125,8 @@ class Arena {
     struct Chunk { char *p; size_t size; };
     std::vector<Chunk> chunks_;
     size_t cur_ = 0, off_ = 0;
-    size_t high_ = 0;  // most bytes in use at once, counting the skipped tails of earlier chunks as used
+    size_t high_ = 0;  // most bytes in use at once since the last reset, counting the skipped tails of earlier chunks as used
+    size_t peak_ = 0;  // the largest high_ of any cycle so far
 };
 
 // Unwinds an arena to where it stood when the scope was entered, on EVERY exit path (ORC_TRY / ORC_HIP return early).

@@ -43,13 +43,17 @@ int Arena::reset() {
     cur_ = 0;
     off_ = 0;
     static const bool compact = !(getenv("ORC_ARENA_COMPACT") && atoi(getenv("ORC_ARENA_COMPACT")) == 0);
-    const size_t used = high_;  // the cycle that just ended
+    // the most any cycle since the last compaction needed: an arena that serves solves of very different footprints in turn
+    // (u, v, w, p' on one stream) must be sized for the largest, not for whichever came last — or it would shrink after a
+    // small solve, spill into extra chunks in the next large one and compact again, freeing and allocating (hipFree
+    // synchronises the device) in every iteration
+    peak_ = std::max(peak_, high_);
+    const size_t used = peak_;
     high_ = 0;
     if (!compact || chunks_.empty() || used == 0) return ORC_OK;
-    const size_t want = used + used / 16 + ((size_t)16 << 20);  // what the cycle needed, plus slack for the next one's drift
-    // one chunk that is not grossly oversized stays (hysteresis: cycles of slightly different sizes must not free and
-    // allocate every time — hipFree synchronises the device)
-    if (chunks_.size() == 1 && chunks_[0].size <= want + want / 2) return ORC_OK;
+    // a single chunk is never shrunk: only a fragmented reservation (several chunks) is folded into one
+    if (chunks_.size() == 1) return ORC_OK;
+    const size_t want = used + used / 16 + ((size_t)16 << 20);  // what the largest cycle needed, plus slack for the next one's drift
     static const bool trace = getenv("ORC_ARENA_TRACE") != nullptr;
     if (trace) fprintf(stderr, "[orc arena %p] compacting %zu chunk(s), reserved %.2f GB -> %.2f GB\n", (void *)this, chunks_.size(), (double)reserved() / 1e9, (double)want / 1e9);
     for (auto &c : chunks_)

@@ -145,3 +145,22 @@ def test_initialize_flow_where_the_unguarded_reference_breaks_down(gpu, oracle, 
     assert np.abs(v - v20).max() < 1e-6 * np.abs(u20).max()
     solve_steady(dm, u, v, w, p, NumericalSettings.default(solver_type=3, iterations=20), 1000.0, 1e-3, 5)
     assert np.isfinite(u).all() and np.isfinite(p).all()
+
+
+def test_initializers_return_orc_order_on_an_internally_reordered_mesh(gpu):
+    """orc_mesh_create_reordered renumbers the cells inside the library only: initialize_pressure_field / initialize_flow_new
+    (like solve_steady and the solver's set/get_fields) hand their fields back in ORC cell order.  A randomly renumbered channel
+    with the internal RCM ordering against the same mesh without it: equal up to the summation order of the face loops."""
+    from orc_amd.mesh import Mesh, hex_channel, renumber_cells, set_channel_bcs
+    from orc_amd.solver import initialize_flow_new, initialize_pressure_field
+    a = set_channel_bcs(hex_channel(12, 9, 7))
+    n = a.n_cells
+    perm = np.random.default_rng(5).permutation(n)
+    sh = renumber_cells(a, perm)
+    plain, reordered = Mesh(sh), Mesh(sh, ordering=1)
+    assert not np.array_equal(reordered.cell_order(), np.arange(n))
+    p0, p1 = initialize_pressure_field(plain), initialize_pressure_field(reordered)
+    assert np.linalg.norm(p1 - p0) <= 1e-12 * np.linalg.norm(p0) and np.linalg.norm(p0) > 0
+    f0, f1 = initialize_flow_new(plain, 1e-3, 1000.0, 10), initialize_flow_new(reordered, 1e-3, 1000.0, 10)
+    for x, y in zip(f0, f1):
+        assert np.linalg.norm(x - y) <= 1e-12 * max(np.linalg.norm(x), 1e-300)

@@ -214,3 +214,28 @@ def test_stream_scheduling_does_not_change_a_bit(gpu, oracle, mesh_path, monkeyp
     for other in out[1:]:
         for x, y in zip(out[0], other):
             assert np.array_equal(x, y)
+
+
+def test_last_slice_dead_lanes_regression(gpu, oracle, mesh_path):
+    """Regression (round 2, fix 5d036f6): channel_flow.msh has 1008 = 15 x 64 + 48 cells, so the last slice of every level has
+    dead lanes; those lanes once gathered through never-written columns of the device-packed coarse operators and the process
+    aborted in the second solver of a run.  Two solvers in one process, four default-stack iterations each: statuses 0,
+    finite fields, identical results."""
+    from orc_amd.mesh import Mesh, MeshArrays
+    from orc_amd.settings import NumericalSettings
+    from orc_amd.solver import Solver
+    import helpers as H
+    om = oracle.Mesh.read(mesh_path("channel_flow"))
+    H.channel_bcs(om)
+    a = MeshArrays(om.arrays())
+    dm = Mesh(a)
+    u, v, w, p = H.seeded_fields(a, seed=4, scale_u=4e-4)
+    out = []
+    for _ in range(2):
+        s = Solver(dm, NumericalSettings.default(iterations=10), 1000.0, 1e-3)
+        s.set_fields(u, v, w, p)
+        for _it in range(4):
+            assert s.iterate(1, raise_on_error=False) == 0
+        out.append(s.get_fields())
+    for x, y in zip(*out):
+        assert np.isfinite(x).all() and np.array_equal(x, y)
