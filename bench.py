@@ -259,6 +259,16 @@ def main():
                 for L in levels:
                     fh.write("%d,%d,%d,%d,%.4f,%.2f,%.0f,%.1f,%.4f\n" % (L["level"], L["rows"], L["nnz"], L["padded"], L["padded"] / max(L["nnz"], 1),
                                                                         L["us_per_product"], L["algorithmic_bytes"], L["GBs"], L["frac_of_peak"]))
+    gs = None
+    if args.solver in ("bicgstab_gs", "multigrid_gs") and world == 1:
+        # BASELINE configs[2]: the time-dominant kernel is the multicolour Gauss-Seidel sweep (preconditioner application): one sweep =
+        # n_colors launches of gs_color_sorted_k and moves one SpMV's bytes + the right-hand side
+        gs_ms, gs_colors = solver.bench_gs_sweep(args.spmv_reps)
+        gs_bytes = spmv_bytes + 8.0 * n_local
+        gs = {"kernel": "gs_color_sorted_k", "launches_per_sweep": gs_colors, "avg_sweep_ms": gs_ms, "avg_launch_ms": gs_ms / max(gs_colors, 1),
+              "algorithmic_bytes_per_sweep": gs_bytes, "achieved": gs_bytes / (gs_ms * 1e-3) / 1e9, "frac": gs_bytes / (gs_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+              "note": "one sweep = 12 nnz + 20 n (SURVEY 8d) + 8 n (the right-hand side); at ~1 M cells the matrix (62 MB) lives in the 256 MiB "
+                      "Infinity Cache and a launch covers 1/n_colors of the rows: these launches are latency-, not HBM-bound"}
     key = (args.nx, args.ny, args.nz, args.momentum, args.solver)
     workload_name = ("BASELINE configs[3]" if key == (400, 160, 160, "umist", "multigrid")
                      else "BASELINE configs[2]" if key == (512, 2016, 1, "quick", "bicgstab_gs") else "custom")
@@ -345,6 +355,7 @@ def main():
                                   "frac": spmv_bytes / (spmv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
                 "bicgstab_iteration_ms": bicg_ms,
                 "bicgstab_iteration_GBs": bicg_bytes / (bicg_ms * 1e-3) / 1e9,
+                "gauss_seidel_sweep": gs,
             },
             "amg_levels": levels,
             "report_last": [float(x) for x in rep[-1]] if rep is not None and len(rep) else None,

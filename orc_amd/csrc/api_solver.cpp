@@ -26,6 +26,10 @@ int download_csr_values(OrcMesh &m, const DevBuf<double> &sell, double *host_val
 
 }  // namespace
 
+namespace orc {
+int bench_gs_sweep_dev(const MatView &A, const double *b, double *x, int reps, Arena &arena, float *ms_per_sweep, int *n_colors);  // gs.hip
+}
+
 extern "C" {
 
 OrcMesh *orc_mesh_create(int64_t n_cells, int64_t n_faces, int32_t n_zones, const int64_t *face_c0, const int64_t *face_c1,
@@ -599,6 +603,27 @@ int orc_bench_inloop_products(OrcSolver *s, int reps, double avg_ms[4]) {
         ORC_TRY(bench_inloop_products3_dev(A3, x3, y3, partials, reps, ms));
         avg_ms[2] = ms[0]; avg_ms[3] = ms[1];
     }
+    return ORC_OK;
+}
+
+// One multicolour Gauss-Seidel sweep over a_u (the preconditioner application of the GS-preconditioned BiCGSTAB, BASELINE configs[2]):
+// n_colors launches of gs_color_sorted_k; average ms per SWEEP over `reps` sweeps.
+int orc_bench_gs_sweep(OrcSolver *s, int reps, double *avg_ms, int *n_colors) {
+    if (!s || !avg_ms) return set_error(ORC_ERR_BAD_ARGUMENT, "null argument");
+    SolverState &t = s->st;
+    MatView A;
+    A.P = t.mesh->pat.dev();
+    A.val = t.a_u.p;
+    A.symmetric = t.mesh->pat.symmetric;
+    A.persistent_pattern = true;
+    ArenaScope scope(t.arena);
+    double *x;
+    ORC_TRY(t.arena.alloc((size_t)std::max<int64_t>(t.n, 1), &x));
+    float ms = 0.f;
+    int nc = 0;
+    ORC_TRY(bench_gs_sweep_dev(A, t.b_u.p, x, std::max(reps, 1), t.arena, &ms, &nc));
+    *avg_ms = ms;
+    if (n_colors) *n_colors = nc;
     return ORC_OK;
 }
 

@@ -696,6 +696,46 @@ int gs_arm_dev(const MatView &A, const double *b, double *x, uint64_t iteration_
     return method == ORC_SOLVER_MULTICOLOR_GS ? h : (h == ORC_ERR_STRUCTURAL_ZERO ? h : ORC_OK);
 }
 
+// bench.py (BASELINE configs[2]): one multicolour sweep = C->n_colors launches of gs_color_sorted_k over the colour-sorted matrix,
+// `reps` sweeps between two HIP events on the library stream; x = M^-1 b from zero, as the preconditioner application does it.
+int bench_gs_sweep_dev(const MatView &A, const double *b, double *x, int reps, Arena &arena, float *ms_per_sweep, int *n_colors) {
+    const int64_t n = A.P.n;
+    if (n == 0) return ORC_OK;
+    hipStream_t st = ctx().stream;
+    std::unique_ptr<Coloring> owned;
+    const Coloring *C = nullptr;
+    ArenaScope scope(arena);
+    ORC_TRY(get_coloring(A, owned, &C, &arena));
+    int *status;
+    ORC_TRY(arena.alloc((size_t)1, &status));
+    ORC_HIP(hipMemsetAsync(status, 0, sizeof(int), st));
+    SortedView view;
+    if (C->sorted.built) {
+        double *vals;
+        ORC_TRY(arena.alloc((size_t)std::max<int64_t>(C->sorted.padded, 1), &vals));
+        hipLaunchKernelGGL(gs_permute_values_k, dim3(grid_for(n)), dim3(kBlock), 0, st, A, C->sorted.slot_of_row.p, C->sorted.slice_ptr.p, vals);
+        ORC_HIP(hipGetLastError());
+        view.sp = C->sorted.slice_ptr.p; view.row_len = C->sorted.row_len.p; view.rowid = C->sorted.rowid.p; view.diag_off = C->sorted.diag_off.p;
+        view.col = C->sorted.col.p; view.val = vals; view.color_slice = C->sorted.color_slice;
+    } else if (!A.persistent_pattern) {
+        ORC_TRY(build_sorted_on_device(A, *C, arena, view));
+    }
+    if (n_colors) *n_colors = C->n_colors;
+    hipEvent_t e0, e1;
+    ORC_HIP(hipEventCreate(&e0));
+    ORC_HIP(hipEventCreate(&e1));
+    ORC_TRY(vec_fill(x, 0., std::max(A.P.ncols, n)));
+    int rc = gs_sweep(A, *C, b, x, 1.0, status, &view);  // warm
+    if (rc == ORC_OK && hipEventRecord(e0, st) != hipSuccess) rc = set_error(ORC_ERR_HIP, "hipEventRecord failed");
+    for (int i = 0; i < reps && rc == ORC_OK; ++i) rc = gs_sweep(A, *C, b, x, 1.0, status, &view);
+    if (rc == ORC_OK && (hipEventRecord(e1, st) != hipSuccess || hipEventSynchronize(e1) != hipSuccess)) rc = set_error(ORC_ERR_HIP, "hipEventRecord failed");
+    if (rc == ORC_OK && hipEventElapsedTime(ms_per_sweep, e0, e1) != hipSuccess) rc = set_error(ORC_ERR_HIP, "hipEventElapsedTime failed");
+    if (rc == ORC_OK) *ms_per_sweep /= (float)std::max(reps, 1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+}
+
 // test hook: the colouring of a pattern (host arrays out)
 int gs_debug_coloring(const SellDev &P, std::vector<int> &colors, int *n_colors) {
     Coloring C;

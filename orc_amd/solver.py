@@ -124,6 +124,12 @@ class Solver:
         check(lib().orc_bench_inloop_products(self.ptr, C.c_int(reps), ms))
         return [ms[k] for k in range(4)]
 
+    def bench_gs_sweep(self, reps=50):
+        """orc_bench_gs_sweep: (ms per multicolour Gauss-Seidel sweep over a_u, number of colours = launches per sweep)"""
+        ms, nc = C.c_double(0.0), C.c_int(0)
+        check(lib().orc_bench_gs_sweep(self.ptr, C.c_int(reps), C.byref(ms), C.byref(nc)))
+        return ms.value, nc.value
+
     def bench_bicgstab_iteration(self, reps=20):
         ms = C.c_double(0.0)
         check(lib().orc_bench_bicgstab_iteration(self.ptr, C.c_int(reps), C.byref(ms)))
