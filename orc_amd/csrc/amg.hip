@@ -401,8 +401,10 @@ __global__ __launch_bounds__(1024) void tail_small_k(MatView A, int *choice, int
 // to be performed.  No cache is written back or invalidated.
 __device__ __forceinline__ void chase_fence() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+#ifdef ORC_CHASE_FENCE_WAIT  // build-time switch: measured no different in wall time or in certification rounds (always 1) at 10.24 M cells
     __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) expcnt(0) lgkmcnt(0)
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+#endif
 }
 __device__ __forceinline__ int ld_i(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_i(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -1731,7 +1733,47 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
     return ORC_OK;
 }
 
-static int galerkin(const MatView &A, const int *choice, const int *chooser, Arena &arena, CoarseLevel &L) {
+// Row-contiguous mirror, compacted: the product's scratch rows (reserved at twice the candidate count per row: the bound of the
+// symbolic step, about 3.7 times what the rows really hold) copied to exact size — entry k of coarse row r at
+// new_base[r >> 6] + new_intra[r] + k — so that the scratch can be handed back.  One wavefront per slice of 64 coarse rows.
+__global__ __launch_bounds__(64) void rows_compact_k(const int *__restrict__ row_len, int64_t n_rows, int n_slices, const long long *__restrict__ old_base,
+                                                     const int *__restrict__ old_intra, const int *__restrict__ s_col, const double *__restrict__ s_val,
+                                                     const int64_t *__restrict__ new_base, int *__restrict__ new_intra, int *__restrict__ out_col,
+                                                     double *__restrict__ out_val) {
+    const int lane = threadIdx.x;
+    for (int64_t slice = blockIdx.x; slice < n_slices; slice += gridDim.x) {
+        const int64_t row = slice * 64 + lane;
+        const bool live = row < n_rows;
+        const int len = live ? row_len[row] : 0;
+        int incl = len;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int y = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += y;
+        }
+        const int excl = incl - len;
+        if (live) new_intra[row] = excl;
+        const long long ob = old_base[slice];
+        const int64_t nb = new_base[slice];
+        const int oi = live ? old_intra[row] : 0;
+        for (int r = 0; r < 64; ++r) {
+            const int n = __shfl(len, r, 64);
+            const long long src = ob + __shfl(oi, r, 64);
+            const int64_t dst = nb + __shfl(excl, r, 64);
+            for (int e = lane; e < n; e += 64) {
+                out_col[dst + e] = s_col[src + e];
+                out_val[dst + e] = s_val[src + e];
+            }
+        }
+    }
+}
+
+// `scratch` (optional): a second arena for everything that is dead when the level is complete — the symbolic bounds, the tier
+// lists and the product's scratch rows, 11 GB of a 10.24 M-row hierarchy's 23 GB — released before returning; the row-contiguous
+// mirror is then a compacted copy in `arena`.  Without it the scratch rows themselves stay alive as the mirror (round 2).
+static int galerkin(const MatView &A, const int *choice, const int *chooser, Arena &arena, CoarseLevel &L, Arena *scratch = nullptr, bool last_level = false) {
+    Arena &tmp = scratch ? *scratch : arena;
+    ArenaScope tmp_scope(tmp);  // with `scratch`: unwinds it on every exit; without: re-marked below so that nothing is released
     const int64_t n = A.P.n, nc = n / 2 + n % 2;  // :13
     hipStream_t st = ctx().stream;
     int *row_len, *diag, *flags, *intra_off;  // flags[0] = max candidates, [1] = overflow (cannot happen: rows are pre-sorted into tiers)
@@ -1752,12 +1794,12 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
     lap(nullptr);
     ORC_TRY(arena.alloc(ncs, &row_len));
     ORC_TRY(arena.alloc(ncs, &diag));
-    ORC_TRY(arena.alloc(ncs, &intra_off));
-    ORC_TRY(arena.alloc((size_t)n_slices + 1, &slice_tot));
-    ORC_TRY(arena.alloc((size_t)n_slices + 1, &slice_base));
+    ORC_TRY(tmp.alloc(ncs, &intra_off));
+    ORC_TRY(tmp.alloc((size_t)n_slices + 1, &slice_tot));
+    ORC_TRY(tmp.alloc((size_t)n_slices + 1, &slice_base));
     ORC_TRY(arena.alloc((size_t)n_slices + 1, &slice_ptr));
-    ORC_TRY(arena.alloc((size_t)4, &flags));
-    ORC_TRY(arena.alloc((size_t)2, &counters));
+    ORC_TRY(tmp.alloc((size_t)4, &flags));
+    ORC_TRY(tmp.alloc((size_t)2, &counters));
     ORC_HIP(hipMemsetAsync(flags, 0, 4 * sizeof(int), st));
     ORC_HIP(hipMemsetAsync(counters, 0, 2 * sizeof(unsigned long long), st));
     const bool use_sort = getenv("ORC_GALERKIN_SORT") != nullptr && atoi(getenv("ORC_GALERKIN_SORT")) != 0;  // per call: tests compare the forms
@@ -1776,8 +1818,8 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
         return g;
     }();
     int *tier_count, *tier_list;
-    ORC_TRY(arena.alloc((size_t)kGalerkinTiers + 1, &tier_count));
-    ORC_TRY(arena.alloc((size_t)kGalerkinTiers * ncs, &tier_list));
+    ORC_TRY(tmp.alloc((size_t)kGalerkinTiers + 1, &tier_count));
+    ORC_TRY(tmp.alloc((size_t)kGalerkinTiers * ncs, &tier_list));
     ORC_HIP(hipMemsetAsync(tier_count, 0, (kGalerkinTiers + 1) * sizeof(int), st));
     hipLaunchKernelGGL(galerkin_bound_k, dim3((unsigned)std::min<int64_t>(n_slices, 8192)), dim3(64), 0, st, A.P, choice, nc, flags, counters + 1, intra_off,
                        slice_tot, tier_count, tier_list, use_sort ? 1 : 0);
@@ -1793,8 +1835,8 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
     const long long scratch_cap = (long long)std::max<unsigned long long>(2ull * hcount[1], 64ull);
     int *s_col;
     double *s_val;
-    ORC_TRY(arena.alloc((size_t)scratch_cap, &s_col));
-    ORC_TRY(arena.alloc((size_t)scratch_cap, &s_val));
+    ORC_TRY(tmp.alloc((size_t)scratch_cap, &s_col));
+    ORC_TRY(tmp.alloc((size_t)scratch_cap, &s_val));
     lap("galerkin bounds");
     static std::once_flag attr_once;  // several lane threads reach this concurrently
     std::call_once(attr_once, [] {
@@ -1829,8 +1871,8 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
     lap("galerkin product");
     int64_t *pk_ptr, *w_sell, *w_pk;
     ORC_TRY(arena.alloc((size_t)n_slices + 1, &pk_ptr));
-    ORC_TRY(arena.alloc((size_t)n_slices + 1, &w_sell));
-    ORC_TRY(arena.alloc((size_t)n_slices + 1, &w_pk));
+    ORC_TRY(tmp.alloc((size_t)n_slices + 1, &w_sell));
+    ORC_TRY(tmp.alloc((size_t)n_slices + 1, &w_pk));
     hipLaunchKernelGGL(slice_sizes_k, dim3((unsigned)std::min<int64_t>(((int64_t)n_slices + 3) / 4, 4096)), dim3(kBlock), 0, st, row_len, nc, n_slices, w_sell, w_pk);
     hipLaunchKernelGGL(scan2_i64_k, dim3(1), dim3(1024), 0, st, (const int64_t *)w_sell, (const int64_t *)w_pk, n_slices, slice_ptr, pk_ptr);
     ORC_HIP(hipGetLastError());
@@ -1867,7 +1909,18 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
     L.xw = XWinDev();
     L.rows = RowsDev();
     static const bool rows_enabled = !(getenv("ORC_AMG_ROWS_MIRROR") && atoi(getenv("ORC_AMG_ROWS_MIRROR")) == 0);
-    if (rows_enabled) { L.rows.slice_base = slice_base; L.rows.intra_off = intra_off; L.rows.col = s_col; L.rows.val = s_val; }
+    if (rows_enabled && !scratch) { L.rows.slice_base = slice_base; L.rows.intra_off = intra_off; L.rows.col = s_col; L.rows.val = s_val; }
+    if (rows_enabled && scratch && packed_total > 0 && !last_level) {  // exact-size copy; the slices start where the packed mirror's do (pk_ptr); the last level is never aggregated
+        int *r_col, *r_intra;
+        double *r_val;
+        ORC_TRY(arena.alloc((size_t)packed_total, &r_col));
+        ORC_TRY(arena.alloc((size_t)packed_total, &r_val));
+        ORC_TRY(arena.alloc(ncs, &r_intra));
+        hipLaunchKernelGGL(rows_compact_k, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(n_slices, 256 * 16))), dim3(64), 0, st, (const int *)row_len, nc, n_slices,
+                           (const long long *)slice_base, (const int *)intra_off, (const int *)s_col, (const double *)s_val, (const int64_t *)pk_ptr, r_intra, r_col, r_val);
+        ORC_HIP(hipGetLastError());
+        L.rows.slice_base = reinterpret_cast<const long long *>(pk_ptr); L.rows.intra_off = r_intra; L.rows.col = r_col; L.rows.val = r_val;
+    }
     if (mirror) {
         L.pk.ptr = pk_ptr; L.pk.col = pk_col; L.pk.val = pk_val; L.pk.total = packed_total;
         const int64_t n_blocks = ((int64_t)n_slices + 3) / 4;
@@ -1881,6 +1934,7 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
         L.xw.wcol = wcol; L.xw.wsize = wsize; L.xw.lidx = lidx;
     }
     lap("galerkin mirrors");
+    if (!scratch) tmp_scope.mark = tmp.mark();  // the scratch rows ARE the mirror: everything stays
     return ORC_OK;
 }
 
@@ -2024,10 +2078,12 @@ static int multigrid_solve_dev(const MatView &A, const double *r, uint64_t level
 
 // The set-up half of the Multigrid arm on its own: levels 1..3 of the hierarchy for `A_in` seen through the arm's
 // preconditioner (linear_algebra.rs:159-166 then :80, :84 per level, recursion rule of :109).
-int multigrid_prepare_dev(const MatView &A_in, int preconditioner, Arena &arena, AmgHierarchy &H, SiblingPairing *sibling, int sibling_role) {
+int multigrid_prepare_dev(const MatView &A_in, int preconditioner, Arena &arena, AmgHierarchy &H, SiblingPairing *sibling, int sibling_role, Arena *scratch) {
     H = AmgHierarchy();
     const int64_t n = A_in.P.n;
     H.n_fine = n;
+    static const bool scratch_on = !(getenv("ORC_AMG_SCRATCH") && atoi(getenv("ORC_AMG_SCRATCH")) == 0);  // 0: everything in `arena` (round 2)
+    if (!scratch_on) scratch = nullptr;
     if (n == 0) return ORC_OK;
     MatView views[4];
     views[0] = A_in;
@@ -2049,13 +2105,17 @@ int multigrid_prepare_dev(const MatView &A_in, int preconditioner, Arena &arena,
         CoarseLevel L;
         const int *warm = nullptr;
         if (sibling && sibling_role == 2 && level == 1) warm = sibling->wait((int)level, nf, ctx().stream);
-        const int agg_st = aggregate(A, arena, h.choice, h.chooser, &L.rounds, warm, 2);
+        // the aggregation's work lists (48 bytes per row) are dead when it returns: they live in `scratch` when there is one
+        Arena &agg_arena = scratch ? *scratch : arena;
+        const Arena::Mark agg_mark = agg_arena.mark();
+        const int agg_st = aggregate(A, agg_arena, h.choice, h.chooser, &L.rounds, warm, 2);
+        if (scratch) scratch->release(agg_mark);
         if (sibling && sibling_role == 1 && level == 1) {
             if (agg_st == ORC_OK) ORC_TRY(sibling->publish((int)level, h.choice, nf, ctx().stream));
             sibling->finish();
         }
         ORC_TRY(agg_st);
-        ORC_TRY(galerkin(A, h.choice, h.chooser, arena, L));
+        ORC_TRY(galerkin(A, h.choice, h.chooser, arena, L, scratch, level == max_levels));
         h.P = L.P; h.val = L.val; h.pk = L.pk; h.xw = L.xw; h.rows = L.rows; h.n = L.n; h.padded = L.padded; h.rounds = L.rounds;
         H.n_levels = (int)level;
         if (!(level < max_levels && L.n > 16)) break;  // :109
@@ -2162,7 +2222,11 @@ int multigrid_arm3_dev(const MatView3 &A3, const double *const b[3], double *con
         if (hipSetDevice(local[k].device) != hipSuccess) { st_prep[k] = set_error(ORC_ERR_HIP, "hipSetDevice failed in a set-up thread"); return; }
         lanes[k].hier_arena->release(Arena::Mark{0, 0});
         int stp = lanes[k].hier_arena->empty() ? lanes[k].hier_arena->reset() : ORC_OK;
-        if (stp == ORC_OK) stp = multigrid_prepare_dev(plain[k], preconditioner, *lanes[k].hier_arena, lanes[k].hierarchy, sibling, k == 0 ? 1 : 2);
+        if (stp == ORC_OK && lanes[k].scratch_arena) {
+            lanes[k].scratch_arena->release(Arena::Mark{0, 0});
+            stp = lanes[k].scratch_arena->reset();  // nothing of the previous set-up is alive: a fragmented reservation becomes one chunk
+        }
+        if (stp == ORC_OK) stp = multigrid_prepare_dev(plain[k], preconditioner, *lanes[k].hier_arena, lanes[k].hierarchy, sibling, k == 0 ? 1 : 2, lanes[k].scratch_arena);
         if (k == 0 && sibling) sibling->finish();  // whatever happened to u: v and w must not wait for a level that will not come
         if (hipStreamSynchronize(local[k].stream) != hipSuccess && stp == ORC_OK) stp = set_error(ORC_ERR_HIP, "stream synchronisation failed in a set-up thread");
         st_prep[k] = stp;

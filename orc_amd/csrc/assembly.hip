@@ -1174,7 +1174,12 @@ static int prepare_p_hierarchy(SolverState &s) {
     A.halo = m.halo.active() ? &m.halo : nullptr;  // level 1 pairs owned rows only; nothing is exchanged
     A.persistent_pattern = true;
     ORC_TRY(s.hier_arena.reset());
-    ORC_TRY(multigrid_prepare_dev(A, s.settings.preconditioner, s.hier_arena, s.p_hierarchy));
+    // transient set-up storage: its own arena; when the momentum set-ups are through (lock-step schedule: this thread starts
+    // after them) lane 0's is free and big enough
+    Arena &scratch = s.p_scratch_shared ? s.lanes[0].scratch_arena : s.hier_scratch;
+    scratch.release(Arena::Mark{0, 0});
+    ORC_TRY(scratch.reset());
+    ORC_TRY(multigrid_prepare_dev(A, s.settings.preconditioner, s.hier_arena, s.p_hierarchy, nullptr, 0, &scratch));
     ORC_HIP(hipStreamSynchronize(st));
     return ORC_OK;
 }
@@ -1284,7 +1289,9 @@ static int solve_momentum_partitioned(SolverState &s) {
         CtxScope scope(&local[k]);
         if (hipSetDevice(local[k].device) != hipSuccess) { st_lane[k] = set_error(ORC_ERR_HIP, "hipSetDevice failed in a solve thread"); return; }
         L.arena.release(Arena::Mark{0, 0});
-        int st = multigrid_prepare_dev(plain[k], t.preconditioner, L.arena, L.hierarchy);  // (2)
+        L.scratch_arena.release(Arena::Mark{0, 0});
+        (void)L.scratch_arena.reset();
+        int st = multigrid_prepare_dev(plain[k], t.preconditioner, L.arena, L.hierarchy, nullptr, 0, &L.scratch_arena);  // (2)
         if (st == ORC_OK && hipStreamSynchronize(local[k].stream) != hipSuccess) st = set_error(ORC_ERR_HIP, "stream synchronisation failed in a solve thread");
         // test hook (tests/mp_worker.py, mode gpu_lane_error): ORC_DEBUG_INJECT_LANE_ERROR="rank:lane" makes that rank's lane fail
         // locally after its set-up — every rank must still leave the solve with the same verdict and nobody may hang
@@ -1407,7 +1414,9 @@ static int solve_momentum_concurrently(SolverState &s, bool setup_first, Prepare
             A.symmetric = s.mesh->pat.symmetric;
             A.persistent_pattern = true;
             L.arena.release(Arena::Mark{0, 0});
-            st[k] = multigrid_prepare_dev(A, s.settings.preconditioner, L.arena, L.hierarchy);
+            L.scratch_arena.release(Arena::Mark{0, 0});
+            (void)L.scratch_arena.reset();
+            st[k] = multigrid_prepare_dev(A, s.settings.preconditioner, L.arena, L.hierarchy, nullptr, 0, &L.scratch_arena);
             if (hipStreamSynchronize(local[k].stream) != hipSuccess && st[k] == ORC_OK) st[k] = set_error(ORC_ERR_HIP, "stream synchronisation failed in a set-up thread");
         };
         run_lanes(prepare);
@@ -1480,6 +1489,7 @@ static int solve_momentum_triple(SolverState &s, const std::function<void()> &on
         s.triple[k].solve_stream = L.side.stream;
         s.triple[k].hier_arena = &L.arena;
         s.triple[k].vec_arena = &L.side_arena;
+        s.triple[k].scratch_arena = &L.scratch_arena;
         s.triple[k].symmetric = s.mesh->pat.symmetric;
     }
     int st3[3] = {ORC_OK, ORC_OK, ORC_OK};
@@ -1533,6 +1543,7 @@ int solver_iterate(SolverState &s, uint64_t iterations, double *report) {
         // level-0 solve runs beside them), so it starts when they are through and runs beside the bandwidth-bound coarse levels.
         static const int p_late_env = getenv("ORC_P_HIERARCHY_LATE") ? atoi(getenv("ORC_P_HIERARCHY_LATE")) : 1;
         const bool p_late = early_p && triple_ok && method == ORC_SOLVER_MULTIGRID && p_late_env != 0;
+        s.p_scratch_shared = p_late;
         if (early_p && !p_late) {
             ORC_HIP(hipStreamSynchronize(ctx().stream));  // the diagonals (and their ghosts) are in place
             prep.start(s);

@@ -83,6 +83,7 @@ struct SolverState {
         SolveStats stats;
         SolveSide side;   // second stream of the lane's Multigrid solves (set-up beside smoothing, linalg.hpp)
         Arena side_arena;
+        Arena scratch_arena;  // transient storage of a hierarchy set-up ahead of its solve (multigrid_prepare_dev's `scratch`)
         AmgHierarchy hierarchy;        // partitioned runs: built by the lane while the library stream does the level-0 work
         hipEvent_t level0_done = nullptr;
     } lanes[3];
@@ -95,9 +96,10 @@ struct SolverState {
     // the new velocities enter its RHS), so its Multigrid hierarchy is built on a stream of its own while the momentum
     // systems are being solved, and the p' solve finds it ready.
     AmgHierarchy p_hierarchy;
-    Arena hier_arena;
+    Arena hier_arena, hier_scratch;
     hipStream_t prep_stream = nullptr;
     bool early_p_hierarchy = true;
+    bool p_scratch_shared = false;  // this iteration's p' set-up borrows lane 0's scratch arena (it starts when the momentum set-ups are through)
     bool sibling_pairing = true;  // v and w take u's fine-level pairing when it verifies as theirs (ORC_AMG_SIBLING=0: off)
     SolveSide side;       // the same for the solves on the library stream (p', or all four when the lanes are off)
     Arena side_arena;

@@ -107,9 +107,9 @@ struct DevBuf {
 class Arena {
   public:
     ~Arena();
-    struct Mark { size_t chunk, off; };
-    Mark mark() const { return {cur_, off_}; }
-    void release(Mark m) { cur_ = m.chunk; off_ = m.off; }
+    struct Mark { size_t chunk, off, live = 0; };
+    Mark mark() const { return {cur_, off_, live_}; }
+    void release(Mark m) { cur_ = m.chunk; off_ = m.off; live_ = m.live; }
     // Everything the arena holds is dead (no stream reads it any more): unwind to empty and, when the reservation has
     // become fragmented (several chunks, or far more than was ever in use at once), replace it by ONE chunk of the
     // high-water size.  hipFree synchronises the device, so this happens in the first iterations only: once one chunk
@@ -125,7 +125,8 @@ class Arena {
     struct Chunk { char *p; size_t size; };
     std::vector<Chunk> chunks_;
     size_t cur_ = 0, off_ = 0;
-    size_t high_ = 0;  // most bytes in use at once since the last reset, counting the skipped tails of earlier chunks as used
+    size_t live_ = 0;  // bytes handed out and not released (what ONE chunk would have to hold: the skipped tails of exhausted chunks do not count)
+    size_t high_ = 0;  // most live bytes at once since the last reset
     size_t peak_ = 0;  // the largest high_ of any cycle so far
 };
 

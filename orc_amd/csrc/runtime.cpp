@@ -42,6 +42,7 @@ Arena::~Arena() {
 int Arena::reset() {
     cur_ = 0;
     off_ = 0;
+    live_ = 0;
     static const bool compact = !(getenv("ORC_ARENA_COMPACT") && atoi(getenv("ORC_ARENA_COMPACT")) == 0);
     // the most any cycle since the last compaction needed: an arena that serves solves of very different footprints in turn
     // (u, v, w, p' on one stream) must be sized for the largest, not for whichever came last — or it would shrink after a
@@ -81,9 +82,8 @@ int Arena::alloc_bytes(size_t bytes, void **out) {
             if (off_ + bytes <= c.size) {
                 *out = c.p + off_;
                 off_ += bytes;
-                size_t used = off_;
-                for (size_t q = 0; q < cur_; ++q) used += chunks_[q].size;
-                if (used > high_) high_ = used;
+                live_ += bytes;
+                if (live_ > high_) high_ = live_;
                 return ORC_OK;
             }
             // current chunk exhausted: move on (the tail stays unused until release())
