@@ -47,6 +47,11 @@ def lib():
     return _lib
 
 
+def last_error():
+    """orc_last_error(): the library's text for the last failure (or note) of this thread's context"""
+    return lib().orc_last_error().decode()
+
+
 def check(status):
     if status != 0:
         L = lib()

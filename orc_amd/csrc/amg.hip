@@ -202,6 +202,72 @@ __device__ __forceinline__ int group_eval_row(const MatView &A, const int *__res
     return bj;
 }
 
+// ---- the slice sweep with a group of G lanes per slice [r03].  agg_sweep_k gives a slice to ONE thread, which walks its 64 rows
+// in order and every row entry by entry: fine for 7 entries per row (10.24 M rows: 4 ms), but the coarse levels have few
+// slices and long rows — 40 000 threads (2.4 wavefronts per CU) each chasing 64 x 34 dependent loads took 7 ms on level 2, more
+// than level 0.  Here the 64 rows of a slice are still visited in order (that is the point of the sweep: chains inside a slice
+// resolve in one pass), but the entries of a row are read G at a time (coalesced from the row-contiguous mirror where the level
+// has one) and reduced by (value, position), exactly the sequential "strict <, first wins" scan; lane 0 commits.  Like the
+// thread sweep this is a relaxation whose result only has to be a good starting state: the lock-step rounds certify the pairing.
+template <int G>
+__device__ __forceinline__ int group_eval_row_g(const MatView &A, const int *__restrict__ taken_by, int64_t i, int gl) {
+    const int len = A.P.row_len[i];
+    const RowWalk W(A, i);
+    double best = 1.7976931348623157e308;  // Float::MAX
+    int bk = 0x7fffffff, bj = -1;
+    for (int k = gl; k < len; k += G) {
+        const int j = W.column(k);
+        if (j == i || j >= A.P.n) continue;
+        if (taken_by[j] < i) continue;
+        const double a = W.value(A, i, k);
+        if (a < best) { best = a; bk = k; bj = j; }
+    }
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) {
+        const double ob = __shfl_xor(best, off, G);
+        const int ok = __shfl_xor(bk, off, G);
+        const int oj = __shfl_xor(bj, off, G);
+        if (ob < best || (ob == best && ok < bk)) { best = ob; bk = ok; bj = oj; }
+    }
+    return bj;
+}
+
+template <int G>
+__global__ __launch_bounds__(kBlock) void agg_sweep_group_k(MatView A, int *__restrict__ choice, int *__restrict__ taken_by, const unsigned char *__restrict__ active,
+                                                            unsigned char *__restrict__ active_next, AggCounters *C, int all_active) {
+    const int64_t n = A.P.n;
+    const int gl = threadIdx.x & (G - 1);
+    const int64_t groups = ((int64_t)gridDim.x * blockDim.x) / G;
+    int changed = 0;
+    for (int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G; s < A.P.n_slices; s += groups) {
+        if (!all_active && !active[s]) continue;
+        const int64_t lo = s * 64, hi = lo + 64 < n ? lo + 64 : n;
+        for (int64_t i = lo; i < hi; ++i) {
+            const int nv = group_eval_row_g<G>(A, taken_by, i, gl);
+            const int old = choice[i];
+            if (nv == old) continue;
+            if (gl == 0) {
+                ++changed;
+                choice[i] = nv;
+                if (nv >= 0) atomicMin(&taken_by[nv], (int)i);
+            }
+            // rows that can see the change: those holding old / nv in their pattern (symmetric: the columns of rows old / nv), after i
+            const int js[2] = {old, nv};
+            for (int t = 0; t < 2; ++t) {
+                const int j = js[t];
+                if (j < 0) continue;
+                const int lj = A.P.row_len[j];
+                const RowWalk Wj(A, j);
+                for (int kk = gl; kk < lj; kk += G) {
+                    const int m = Wj.column(kk);
+                    if (m > i && m < n) active_next[m >> 6] = 1;
+                }
+            }
+        }
+    }
+    if (changed) atomicAdd(&C->changed, changed);
+}
+
 __global__ void tail_eval_k(MatView A, const int *__restrict__ choice, const int *__restrict__ taken_by, const int *__restrict__ list_a,
                             const int *__restrict__ list_b, TailCounters *T, int *__restrict__ flag, int *__restrict__ ch_row, int *__restrict__ ch_new) {
     if (T->finished) return;
@@ -1586,7 +1652,15 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
         for (int b = 0; b < kBulk; ++b) {
             hipLaunchKernelGGL(agg_reset_k, dim3(g), dim3(kBlock), 0, st, taken_by, n);
             hipLaunchKernelGGL(agg_scatter_k, dim3(g), dim3(kBlock), 0, st, choice, taken_by, n);
-            hipLaunchKernelGGL(agg_sweep_k, dim3(gs), dim3(64), 0, st, A, choice, taken_by, cur, nxt, C, all_active);
+            // lanes per slice by row length (host-known padded size / rows); 0 = one thread per slice (round 2, ORC_AMG_SWEEP_GROUP=0)
+            static const int group_env = getenv("ORC_AMG_SWEEP_GROUP") ? atoi(getenv("ORC_AMG_SWEEP_GROUP")) : -1;
+            const double avg = (A.P.padded > 0 && n > 0) ? (double)A.P.padded / (double)n : 0.;
+            const int G = group_env >= 0 ? group_env : (avg <= 0. ? 0 : (avg <= 10. ? 8 : (avg <= 22. ? 16 : 32)));
+            const int gg = grid_for((int64_t)A.P.n_slices * std::max(G, 1));
+            if (G == 8) hipLaunchKernelGGL(agg_sweep_group_k<8>, dim3(gg), dim3(kBlock), 0, st, A, choice, taken_by, cur, nxt, C, all_active);
+            else if (G == 16) hipLaunchKernelGGL(agg_sweep_group_k<16>, dim3(gg), dim3(kBlock), 0, st, A, choice, taken_by, cur, nxt, C, all_active);
+            else if (G == 32) hipLaunchKernelGGL(agg_sweep_group_k<32>, dim3(gg), dim3(kBlock), 0, st, A, choice, taken_by, cur, nxt, C, all_active);
+            else hipLaunchKernelGGL(agg_sweep_k, dim3(gs), dim3(64), 0, st, A, choice, taken_by, cur, nxt, C, all_active);
             hipLaunchKernelGGL(agg_rotate_k, dim3(1), dim3(1), 0, st, C, snap + b);
             ORC_HIP(hipMemsetAsync(cur, 0, (size_t)A.P.n_slices, st));
             std::swap(cur, nxt);

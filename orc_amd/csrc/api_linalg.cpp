@@ -73,7 +73,17 @@ int orc_iterative_solve3(int64_t n, const int64_t *row_ptr, const int64_t *col_i
     Arena arena;
     int st = ORC_OK;
     int st3[3] = {ORC_OK, ORC_OK, ORC_OK};
-    if (method == ORC_SOLVER_BICGSTAB) {
+    if (!triple_supported()) {
+        // reference reduction order (one wavefront per dot product) or a multi-rank context: one solve per system, same results
+        for (int k = 0; k < 3; ++k) {
+            MatView A;
+            A.P = pat.dev();
+            A.val = vals[k].p;
+            A.symmetric = pat.symmetric;
+            SolveStats stats;
+            st3[k] = iterative_solve_dev(A, db[k].p, dx[k].p, iteration_count, method, relaxation_factor, convergence_threshold, preconditioner, arena, &stats);
+        }
+    } else if (method == ORC_SOLVER_BICGSTAB) {
         double *b3, *x3;
         ORC_TRY(arena.alloc(3 * nn, &b3));
         ORC_TRY(arena.alloc(3 * nn, &x3));

@@ -1117,6 +1117,13 @@ static int solve_field_on(SolverState &s, DevBuf<double> &a, DevBuf<double> &b, 
     const OrcSettings &t = s.settings;
     if (arena.empty()) ORC_TRY(arena.reset());  // nothing of the previous solve is alive: a fragmented reservation is folded into one chunk
     if (side_arena && side_arena->empty()) ORC_TRY(side_arena->reset());
+    struct RestoreDefaults {  // this solver's guard and reduction order for the solve, the process-wide defaults back afterwards
+        Ctx &c;
+        bool guard;
+        int order;
+        explicit RestoreDefaults(Ctx &cc) : c(cc), guard(cc.breakdown_guard), order(cc.reduction_order) {}
+        ~RestoreDefaults() { c.breakdown_guard = guard; c.reduction_order = order; }
+    } restore_defaults(ctx());
     ctx().breakdown_guard = t.breakdown_guard != 0;
     ctx().reduction_order = t.reduction_order;
     stats.cache = &s.amg_cache[eq];
@@ -1513,6 +1520,15 @@ static void debug_field(SolverState &s, const char *name, const DevBuf<double> &
 // One pass of solver.rs:60-222 per iteration.  In a partitioned run (mesh.halo active) the ghost entries of every
 // field a face kernel reads are refreshed first (C1); the solves exchange their own work vectors.
 int solver_iterate(SolverState &s, uint64_t iterations, double *report) {
+    // the solves below run with THIS solver's guard and reduction order; the process-wide defaults (orc_set_breakdown_guard,
+    // orc_set_reduction_order: what orc_iterative_solve uses) are put back on every exit
+    struct RestoreDefaults {
+        Ctx &c;
+        bool guard;
+        int order;
+        explicit RestoreDefaults(Ctx &cc) : c(cc), guard(cc.breakdown_guard), order(cc.reduction_order) {}
+        ~RestoreDefaults() { c.breakdown_guard = guard; c.reduction_order = order; }
+    } restore_defaults(ctx());
     const bool tvd = is_tvd(s.settings.momentum);
     const bool dbg = getenv("ORC_DEBUG_NAN") != nullptr;
     HaloPlan &H = s.mesh->halo;

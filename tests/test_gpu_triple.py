@@ -46,11 +46,12 @@ def three_systems(shape, distinct_pairings=False, seed=1):
 @pytest.mark.parametrize("precond", [PRE_NONE, PRE_JACOBI])
 @pytest.mark.parametrize("iters", [1, 7, 50])
 def test_bicgstab_three_systems_bit_identical_to_one_at_a_time(gpu, shape, precond, iters):
+    from orc_amd._lib import last_error
     from orc_amd.linear_algebra import iterative_solve, iterative_solve3
     mats, bs, xs = three_systems(shape)
     x3 = [x.copy() for x in xs]
     st, st3 = iterative_solve3(mats, bs, x3, iters, BICGSTAB, 0.5, 1e-3, precond)
-    assert st == 0 and st3 == [0, 0, 0]
+    assert st == 0 and st3 == [0, 0, 0], (st, st3, last_error())
     for k in range(3):
         x1 = xs[k].copy()
         assert iterative_solve(mats[k], bs[k], x1, iters, BICGSTAB, 0.5, 1e-3, precond, raise_on_error=False) == 0
