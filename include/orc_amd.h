@@ -289,6 +289,8 @@ int orc_debug_set_spmv_variant(int variant);
 /* Test hook: how many level-0 products of partitioned operators this thread has run in the overlapped form (interior rows
  * on a second stream beside the halo exchange, rows along the cuts after it) since orc_init. */
 long long orc_debug_halo_overlaps(void);
+/* test hook: products launched on a length-sorted image of a coarse level (XSortDev) since the process started */
+long long orc_debug_xsort_products(void);
 /* kernel-level timers accumulated inside orc_solver_iterate when enabled: name/ms pairs */
 int orc_profile_enable(int on);
 int orc_profile_report(char *buf, int64_t buf_len);

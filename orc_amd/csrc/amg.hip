@@ -1520,6 +1520,104 @@ __global__ __launch_bounds__(kBlock) void xwin_build_k(SellDev P, PackedDev pk, 
     }
 }
 
+// ---- length-sorted image of the packed mirror (XSortDev, linalg.hpp): one workgroup per block of 256 rows.
+// sorted rank of a row = rows of the block that are longer + equally long rows before it; rank r -> wave r & 3, lane r >> 2.
+// R(q) = rows longer than q, so wave w owns cnt_w(q) = ceil((R(q) - w) / 4) entries at depth q, a prefix of its lanes.
+__global__ __launch_bounds__(kBlock) void xsort_build_k(SellDev P, PackedDev pk, const unsigned short *__restrict__ lidx_packed, int *__restrict__ perm,
+                                                        int *__restrict__ slen, int64_t *__restrict__ sptr, double *__restrict__ sval,
+                                                        unsigned short *__restrict__ slidx, unsigned char *__restrict__ ok, int64_t n_blocks) {
+    __shared__ int lens[kBlock];
+    __shared__ int longer[kXSortMaxLen + 1];   // hist, then R(q) = rows with length > q
+    __shared__ int offp[4][kXSortMaxLen + 1];  // exclusive prefix over the depths of cnt_w
+    __shared__ long long sb[4];
+    __shared__ int s_bad;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int64_t b = blockIdx.x; b < n_blocks; b += gridDim.x) {
+        const int64_t row = b * kXWinRows + tid;
+        const bool live = row < P.n;
+        const int len = live ? P.row_len[row] : 0;
+        lens[tid] = len;
+        for (int q = tid; q <= kXSortMaxLen; q += kBlock) longer[q] = 0;
+        if (tid == 0) s_bad = 0;
+        __syncthreads();
+        if (len > kXSortMaxLen) s_bad = 1;
+        else atomicAdd(&longer[len], 1);
+        __syncthreads();
+        if (s_bad) {  // a row too long for the tables: this block keeps the packed order
+            if (tid == 0) ok[b] = 0;
+            perm[b * kXWinRows + tid] = live ? (int)row : -1;
+            slen[b * kXWinRows + tid] = len;
+            if (tid < 4) sptr[b * 4 + tid] = (b * 4 + tid < P.n_slices) ? pk.ptr[b * 4 + tid] : 0;
+            __syncthreads();
+            continue;
+        }
+        // R(q) = sum_{l > q} hist[l]: suffix sums, two depths per thread (hist is read-only in this step)
+        int rq[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int q = tid + t * kBlock;
+            int acc = 0;
+            if (q <= kXSortMaxLen)
+                for (int l = q + 1; l <= kXSortMaxLen; ++l) acc += longer[l];
+            rq[t] = acc;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+            if (tid + t * kBlock <= kXSortMaxLen) longer[tid + t * kBlock] = rq[t];
+        __syncthreads();
+        int rank = longer[len];
+        for (int u = 0; u < tid; ++u) rank += lens[u] == len;
+        const int sw = rank & 3, sl = rank >> 2;
+        perm[b * kXWinRows + sw * 64 + sl] = live ? (int)row : -1;
+        slen[b * kXWinRows + sw * 64 + sl] = len;
+        // offp[w][q] = sum_{q' < q} cnt_w(q'), cnt_w(q) = max(0, ceil((R(q) - w) / 4)): wave w scans its own row of the table
+        {
+            int carry = 0;
+            for (int q0 = 0; q0 <= kXSortMaxLen; q0 += 64) {
+                const int q = q0 + lane;
+                const int r_ = q <= kXSortMaxLen ? longer[q] : 0;
+                const int c = r_ > wave ? (r_ - wave + 3) >> 2 : 0;
+                int x = c;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int y = __shfl_up(x, off, 64);
+                    if (lane >= off) x += y;
+                }
+                if (q <= kXSortMaxLen) offp[wave][q] = carry + x - c;
+                carry += __shfl(x, 63, 64);
+            }
+            if (lane == 0) sb[wave] = carry;  // this wave's share of the block's entries
+        }
+        __syncthreads();
+        if (tid == 0) {
+            long long base = (long long)pk.ptr[b * 4];
+            for (int w = 0; w < 4; ++w) { const long long t = sb[w]; sb[w] = base; sptr[b * 4 + w] = base; base += t; }
+            ok[b] = 1;
+        }
+        __syncthreads();
+        // copy: the wave walks its slice in packed order (lane = row), every lane writes to its row's sorted place
+        const int64_t slice = b * 4 + wave;
+        if (slice < P.n_slices) {
+            const int64_t sbase = P.slice_ptr[slice];
+            const int width = (int)((P.slice_ptr[slice + 1] - sbase) >> 6);
+            int64_t off = pk.ptr[slice];
+            for (int q = 0; q < width; ++q) {
+                const bool in = q < len;
+                const unsigned long long m = __ballot(in);
+                const int rk = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                if (in) {
+                    const long long dst = sb[sw] + offp[sw][q] + sl;
+                    sval[dst] = pk.val[off + rk];
+                    slidx[dst] = lidx_packed[off + rk];
+                }
+                off += __popcll(m);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 __global__ void nan_to_status_k(const double *__restrict__ value, int *status, int code) {
     if (threadIdx.x == 0 && blockIdx.x == 0 && isnan(value[0])) atomicCAS(status, 0, code);
 }
@@ -1530,6 +1628,7 @@ struct CoarseLevel {
     double *val = nullptr;
     PackedDev pk;
     XWinDev xw;
+    XSortDev xs;
     RowsDev rows;
     int64_t n = 0, padded = 0;
     int *choice = nullptr, *chooser = nullptr;  // of the FINE level this was built from
@@ -1981,6 +2080,7 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
     L.P = Pc; L.val = val; L.n = nc; L.padded = padded;
     L.pk = PackedDev();
     L.xw = XWinDev();
+    L.xs = XSortDev();
     L.rows = RowsDev();
     static const bool rows_enabled = !(getenv("ORC_AMG_ROWS_MIRROR") && atoi(getenv("ORC_AMG_ROWS_MIRROR")) == 0);
     if (rows_enabled && !scratch) { L.rows.slice_base = slice_base; L.rows.intra_off = intra_off; L.rows.col = s_col; L.rows.val = s_val; }
@@ -2006,6 +2106,28 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
         hipLaunchKernelGGL(xwin_build_k, dim3((unsigned)std::min<int64_t>(n_blocks, 2048)), dim3(kBlock), 0, st, Pc, L.pk, wcol, wsize, lidx, n_blocks);
         ORC_HIP(hipGetLastError());
         L.xw.wcol = wcol; L.xw.wsize = wsize; L.xw.lidx = lidx;
+        // Length-sorted image (XSortDev): OFF by default.  Measured at 10.24 M cells: the sorted product needs a third of the vector
+        // instructions per entry of the packed one and is NOT faster (level 2: 229-236 us against 235-237, level 3: 239-247 against
+        // 227-244, same box), while building the image costs +45-65 ms and 11 GB per SIMPLE iteration — the window product is not
+        // bound by instruction issue after all.  Kept behind the switch with its exactness test.  (read per call: the test switches it)
+        const bool xsort_on = getenv("ORC_SPMV_XSORT") && atoi(getenv("ORC_SPMV_XSORT")) != 0;
+        if (xsort_on) {
+            int *perm, *slen;
+            int64_t *sptr;
+            double *sval;
+            unsigned short *slidx;
+            unsigned char *ok;
+            ORC_TRY(arena.alloc((size_t)n_blocks * kXWinRows, &perm));
+            ORC_TRY(arena.alloc((size_t)n_blocks * kXWinRows, &slen));
+            ORC_TRY(arena.alloc((size_t)n_blocks * 4, &sptr));
+            ORC_TRY(arena.alloc((size_t)packed_total, &sval));
+            ORC_TRY(arena.alloc((size_t)packed_total, &slidx));
+            ORC_TRY(arena.alloc((size_t)n_blocks, &ok));
+            hipLaunchKernelGGL(xsort_build_k, dim3((unsigned)std::min<int64_t>(n_blocks, 4096)), dim3(kBlock), 0, st, Pc, L.pk, (const unsigned short *)lidx, perm, slen, sptr, sval,
+                               slidx, ok, n_blocks);
+            ORC_HIP(hipGetLastError());
+            L.xs.perm = perm; L.xs.slen = slen; L.xs.sptr = sptr; L.xs.val = sval; L.xs.lidx = slidx; L.xs.ok = ok;
+        }
     }
     lap("galerkin mirrors");
     if (!scratch) tmp_scope.mark = tmp.mark();  // the scratch rows ARE the mirror: everything stays
@@ -2075,7 +2197,7 @@ static int multigrid_solve_dev(const MatView &A, const double *r, uint64_t level
         // :80, :84 were done ahead of time (multigrid_prepare_dev) for exactly this matrix
         const AmgHierarchy::Level &h = hier->level[level - 1];
         choice = h.choice; chooser = h.chooser;
-        L.P = h.P; L.val = h.val; L.pk = h.pk; L.xw = h.xw; L.rows = h.rows; L.n = h.n; L.padded = h.padded; L.rounds = h.rounds;
+        L.P = h.P; L.val = h.val; L.pk = h.pk; L.xw = h.xw; L.xs = h.xs; L.rows = h.rows; L.n = h.n; L.padded = h.padded; L.rounds = h.rounds;
     } else {
         ORC_TRY(arena.alloc((size_t)std::max<int64_t>(n, 1), &choice));
         ORC_TRY(arena.alloc((size_t)std::max<int64_t>(n, 1), &chooser));
@@ -2113,6 +2235,7 @@ static int multigrid_solve_dev(const MatView &A, const double *r, uint64_t level
     Ac.val = L.val;
     Ac.pk = L.pk;
     Ac.xw = L.xw;
+    Ac.xs = L.xs;
     Ac.rows = L.rows;
     Ac.symmetric = A.symmetric;  // halo stays null: coarse levels are solved per rank
     double *r_prime, *e_prime, *partials, *scal;
@@ -2190,7 +2313,7 @@ int multigrid_prepare_dev(const MatView &A_in, int preconditioner, Arena &arena,
         }
         ORC_TRY(agg_st);
         ORC_TRY(galerkin(A, h.choice, h.chooser, arena, L, scratch, level == max_levels));
-        h.P = L.P; h.val = L.val; h.pk = L.pk; h.xw = L.xw; h.rows = L.rows; h.n = L.n; h.padded = L.padded; h.rounds = L.rounds;
+        h.P = L.P; h.val = L.val; h.pk = L.pk; h.xw = L.xw; h.xs = L.xs; h.rows = L.rows; h.n = L.n; h.padded = L.padded; h.rounds = L.rounds;
         H.n_levels = (int)level;
         if (!(level < max_levels && L.n > 16)) break;  // :109
         MatView Ac;
@@ -2198,6 +2321,7 @@ int multigrid_prepare_dev(const MatView &A_in, int preconditioner, Arena &arena,
         Ac.val = L.val;
         Ac.pk = L.pk;
         Ac.xw = L.xw;
+        Ac.xs = L.xs;
         Ac.rows = L.rows;
         Ac.symmetric = A.symmetric;
         views[level] = Ac;
@@ -2458,7 +2582,8 @@ int multigrid_arm3_dev(const MatView3 &A3, const double *const b[3], double *con
             ORC_HIP(hipEventRecord(ev_main, st));
             for (int k = 0; k < 3; ++k) {
                 MatView Ak;
-                Ak.P = H[k]->level[0].P; Ak.val = H[k]->level[0].val; Ak.pk = H[k]->level[0].pk; Ak.xw = H[k]->level[0].xw; Ak.rows = H[k]->level[0].rows;
+                Ak.P = H[k]->level[0].P; Ak.val = H[k]->level[0].val; Ak.pk = H[k]->level[0].pk; Ak.xw = H[k]->level[0].xw; Ak.xs = H[k]->level[0].xs;
+                Ak.rows = H[k]->level[0].rows;
                 Ak.symmetric = plain[k].symmetric;
                 ORC_HIP(hipStreamWaitEvent(lanes[k].solve_stream, ev_main, 0));
                 ORC_TRY(on_lane(k, [&] {

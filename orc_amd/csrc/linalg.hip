@@ -6,6 +6,7 @@
 // Compiled with -ffp-contract=off: rustc never fuses a*b+c, and bit-parity of y = A x with the
 // CPU oracle depends on that.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 
 #include "linalg_kernels.hpp"
@@ -121,6 +122,9 @@ int dot_reference(const double *a, const double *b, int64_t n, double *out, cons
     ORC_HIP(hipGetLastError());
     return ORC_OK;
 }
+
+static std::atomic<long long> g_xsort_products{0};  // products launched on a length-sorted image, any thread (test hook)
+long long debug_xsort_products() { return g_xsort_products.load(std::memory_order_relaxed); }
 
 static inline bool reference_order(const MatView &A) { return ctx().reduction_order == ORC_REDUCTION_REFERENCE && A.halo == nullptr; }
 
@@ -370,6 +374,8 @@ static int launch_spmv(const MatView &A, const double *x, const Epi &epi, double
     if (xwin) {
         if (variant == 21) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_xwin_k<Epi, 1>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
         else if (variant == 22) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_xwin_k<Epi, 2>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
+        else if (A.xs.val && variant == 0 && !A.s1 && !A.s2) { hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_xsort_k<Epi, false>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags); g_xsort_products.fetch_add(1, std::memory_order_relaxed); }
+        else if (A.xs.val && variant == 0) { hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_xsort_k<Epi, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags); g_xsort_products.fetch_add(1, std::memory_order_relaxed); }
         else if (!A.s1 && !A.s2) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_xwin_k<Epi, 0, false>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_xwin_k<Epi>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
         ORC_HIP(hipGetLastError());
@@ -696,6 +702,33 @@ __global__ __launch_bounds__(kBlock) void scale_packed_k(MatView A, double *__re
     }
 }
 
+// the same over the length-sorted image (XSortDev): slot (block, wave, lane) owns entry k at its wave's running offset + lane
+__global__ __launch_bounds__(kBlock) void scale_xsort_k(MatView A, double *__restrict__ out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t n_blocks = ((int64_t)A.P.n_slices + 3) >> 2;
+    for (int64_t b = blockIdx.x; b < n_blocks; b += gridDim.x) {
+        if (!A.xs.ok[b]) continue;  // packed order: its products read the packed mirror (scale_packed_k)
+        const int64_t slot = b * kXWinRows + threadIdx.x;
+        const int row = A.xs.perm[slot];
+        const int len = A.xs.slen[slot];
+        const double s1 = (A.s1 && row >= 0) ? A.s1[row] : 1.;
+        const double s2 = (A.s2 && row >= 0) ? A.s2[row] : 1.;
+        const int width = __builtin_amdgcn_readfirstlane(len);
+        int64_t off = A.xs.sptr[b * 4 + wave];
+        for (int k = 0; k < width; ++k) {
+            const bool in = k < len;
+            const int cnt = __popcll(__ballot(in));
+            if (in) {
+                double t = A.xs.val[off + lane];
+                if (A.s1) t = s1 * t;
+                if (A.s2) t = s2 * t;
+                out[off + lane] = t;
+            }
+            off += cnt;
+        }
+    }
+}
+
 int materialize_scaled_view(MatView &A, uint64_t iteration_count, Arena &arena) {
     if (!((A.s1 || A.s2) && A.P.n > 0 && materialize_scaling(iteration_count))) return ORC_OK;
     if (A.pk.ptr) {
@@ -705,6 +738,14 @@ int materialize_scaled_view(MatView &A, uint64_t iteration_count, Arena &arena) 
         ORC_TRY(arena.alloc((size_t)A.pk.total, &scaled));
         hipLaunchKernelGGL(scale_packed_k, dim3(spmv_grid(A.P.n_slices)), dim3(kBlock), 0, ctx().stream, A, scaled);
         ORC_HIP(hipGetLastError());
+        if (A.xs.val) {
+            double *scaled_sorted;
+            ORC_TRY(arena.alloc((size_t)A.pk.total, &scaled_sorted));
+            const int64_t n_blocks = ((int64_t)A.P.n_slices + 3) >> 2;
+            hipLaunchKernelGGL(scale_xsort_k, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(n_blocks, kMaxGrid))), dim3(kBlock), 0, ctx().stream, A, scaled_sorted);
+            ORC_HIP(hipGetLastError());
+            A.xs.val = scaled_sorted;
+        }
         A.pk.val = scaled;
         A.val = nullptr;  // the padded image keeps the unscaled values: nothing may read it through this view
         A.s1 = A.s2 = nullptr;

@@ -56,6 +56,23 @@ struct XWinDev {
     const uint16_t *lidx = nullptr;  // [packed entries] window position of the entry's column
 };
 
+// Length-sorted image of the packed mirror [r03]: inside every block of kXWinRows rows the rows are sorted by length
+// (descending, ties by row) and dealt round-robin to the block's four wavefronts — sorted rank r sits in wave r & 3, lane r >> 2.
+// Within a wavefront the lengths then descend with the lane, so the lanes that still own an entry at depth k always form a
+// PREFIX: entry k of the wavefront's rows sit back to back at sptr[slice] + sum_{k' < k} cnt(k') + lane.  The product's address
+// is a running scalar offset plus the lane — no v_mbcnt rank, no clamping — and the four wavefronts of a block carry the same
+// share of its entries (they meet at a barrier).  Same entries, same per-row order, same sums per row; rows are handed back to
+// their own index through `perm`.  A block shares its entry range with the packed mirror ([pk.ptr[4 b], pk.ptr[4 b + 4])).
+constexpr int kXSortMaxLen = 512;  // longest row a sorted block may hold; a block with a longer one keeps the packed order (ok = 0)
+struct XSortDev {
+    const int32_t *perm = nullptr;        // [n_blocks * kXWinRows] row of slot (block, wave, lane), -1 = none
+    const int32_t *slen = nullptr;        // [n_blocks * kXWinRows] its length
+    const int64_t *sptr = nullptr;        // [n_blocks * 4] first entry of every wavefront's rows
+    const double *val = nullptr;          // [pk.total]
+    const uint16_t *lidx = nullptr;       // [pk.total] window position of the entry's column
+    const unsigned char *ok = nullptr;    // [n_blocks] 1 = the block is stored in sorted order
+};
+
 // Row-contiguous mirror (the Galerkin product's scratch rows, kept alive with their level): entry k of row r sits at
 // slice_base[r >> 6] + intra_off[r] + k.  The set-up kernels that walk single, scattered rows (aggregation rounds) read
 // a row's columns and values from two or three cache lines here instead of one line per entry in the SELL image.
@@ -76,6 +93,7 @@ struct MatView {
     const double *s2 = nullptr;
     PackedDev pk;           // optional packed mirror (same pattern, same values): what the product streams when present
     XWinDev xw;             // optional LDS x-window description of the packed mirror
+    XSortDev xs;            // optional length-sorted image of the packed mirror (what the window product streams when present)
     RowsDev rows;           // optional row-contiguous mirror for single-row walks
     bool symmetric = true;  // structural symmetry of the pattern (aggregation fast path)
     bool persistent_pattern = false;  // the pattern outlives the solve (mesh pattern): derived data such as a colouring may be cached
@@ -150,6 +168,7 @@ struct AmgHierarchy {
         double *val = nullptr;
         PackedDev pk;
         XWinDev xw;
+        XSortDev xs;
         RowsDev rows;
         int64_t n = 0, padded = 0;
         int rounds = 0;

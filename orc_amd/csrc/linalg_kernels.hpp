@@ -522,6 +522,166 @@ __global__ __launch_bounds__(kBlock) void spmv_xwin_k(MatView A, const double *_
     }
 }
 
+// Product on the length-sorted image (XSortDev) with LDS-staged x windows: spmv_xwin_k's block walk and window load, but the
+// stream phase addresses its entries as "running scalar offset + lane".  A wavefront's lengths descend with the lane, so
+//   * depths below the SHORTEST row (lane 63) are owned by all 64 lanes: entry (k, lane) at base + 64 k + lane — eight loads per
+//     array at compile-time offsets from one chunk base, no masks;
+//   * above it the active lanes form a prefix of cnt(k) = popcount(k < len) lanes: one wave-uniform count per depth.
+// Blocks without a window (wsize < 0) or too long for the sort tables (ok = 0) take spmv_xwin_k's packed path.
+template <class Epi, bool kScaled = true>
+__global__ __launch_bounds__(kBlock) void spmv_xsort_k(MatView A, const double *__restrict__ x, Epi epi, double *__restrict__ partials,
+                                                       const double *__restrict__ skip_flags) {
+    __shared__ double lds[8];
+    __shared__ double xs[kXWinCap];
+    if (skip_flags && (skip_flags[0] != 0. || skip_flags[1] != 0.)) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double r0 = 0., r1 = 0.;
+    const int64_t n_blocks = ((int64_t)A.P.n_slices + 3) >> 2;
+    int64_t b_begin, b_end, b_step;
+    if ((gridDim.x & 7) == 0 && gridDim.x >= 8) {
+        const int xcd = blockIdx.x & 7, bl = blockIdx.x >> 3, nb = gridDim.x >> 3;
+        const int64_t per = (n_blocks + 7) / 8;
+        b_begin = (int64_t)xcd * per + bl;
+        b_end = (int64_t)(xcd + 1) * per < n_blocks ? (int64_t)(xcd + 1) * per : n_blocks;
+        b_step = nb;
+    } else {
+        b_begin = blockIdx.x; b_end = n_blocks; b_step = gridDim.x;
+    }
+    for (int64_t b = b_begin; b < b_end; b += b_step) {
+        const int ws = A.xw.wsize[b];  // workgroup-uniform
+        const bool sorted = ws >= 0 && A.xs.ok[b] != 0;
+        if (ws > 0) {
+            const int32_t *wc = A.xw.wcol + b * kXWinCap;
+            for (int j0 = 0; j0 < ws; j0 += 8 * kBlock) {
+                int wj[8];
+                double xw[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int j = j0 + q * kBlock + (int)threadIdx.x;
+                    wj[q] = wc[j < ws ? j : 0];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) xw[q] = x[wj[q]];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int j = j0 + q * kBlock + (int)threadIdx.x;
+                    if (j < ws) xs[j] = xw[q];
+                }
+            }
+        }
+        __syncthreads();
+        if (sorted) {
+            const int64_t slot = b * kXWinRows + threadIdx.x;
+            const int row = A.xs.perm[slot];
+            const int len = A.xs.slen[slot];
+            const double s1 = (kScaled && A.s1 && row >= 0) ? A.s1[row] : 1.;
+            const double s2 = (kScaled && A.s2 && row >= 0) ? A.s2[row] : 1.;
+            const int width = __builtin_amdgcn_readfirstlane(len);     // lane 0 holds the longest row
+            const int minlen = __builtin_amdgcn_readlane(len, 63);     // lane 63 the shortest
+            const int64_t sbase = A.xs.sptr[b * 4 + wave];
+            const double *__restrict__ vb = A.xs.val + sbase;
+            const unsigned short *__restrict__ lb = A.xs.lidx + sbase;
+            double acc = 0.;
+            int k = 0;
+            // depths owned by every lane
+            for (; k + 8 <= minlen; k += 8) {
+                double v[8];
+                int li[8];
+                const int p0 = k * 64 + lane;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { v[u] = vb[p0 + u * 64]; li[u] = (int)lb[p0 + u * 64]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    double t = v[u];
+                    if (kScaled && A.s1) t = s1 * t;
+                    if (kScaled && A.s2) t = s2 * t;
+                    acc += t * xs[li[u]];
+                }
+            }
+            for (; k < minlen; ++k) {
+                double t = vb[k * 64 + lane];
+                const int li = (int)lb[k * 64 + lane];
+                if (kScaled && A.s1) t = s1 * t;
+                if (kScaled && A.s2) t = s2 * t;
+                acc += t * xs[li];
+            }
+            // prefix depths: four at a time, every load clamped to an entry that is being read anyway
+            int off = minlen * 64;
+            for (; k < width; k += 4) {
+                double v[4];
+                int li[4];
+                bool in[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    in[u] = k + u < len;
+                    const int cnt = __popcll(__ballot(in[u]));
+                    const int p = in[u] ? off + lane : (cnt > 0 ? off : off - 1);
+                    v[u] = vb[p];
+                    li[u] = (int)lb[p];
+                    off += cnt;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    double t = v[u];
+                    if (kScaled && A.s1) t = s1 * t;
+                    if (kScaled && A.s2) t = s2 * t;
+                    const double next = acc + t * xs[li[u]];
+                    acc = in[u] ? next : acc;
+                }
+            }
+            if (row >= 0) epi.apply(row, acc, r0, r1);
+        } else {
+            // packed order (spmv_xwin_k): blocks without a window gather from global memory
+            const int64_t slice = b * 4 + wave;
+            if (slice < A.P.n_slices) {
+                const int64_t row = slice * 64 + lane;
+                const int64_t base = A.P.slice_ptr[slice];
+                const int width = (int)((A.P.slice_ptr[slice + 1] - base) >> 6);
+                const bool live = row < A.P.n;
+                const int len = live ? A.P.row_len[row] : 0;
+                const double s1 = (kScaled && A.s1 && live) ? A.s1[row] : 1.;
+                const double s2 = (kScaled && A.s2 && live) ? A.s2[row] : 1.;
+                double acc = 0.;
+                int64_t pk_off = A.pk.ptr[slice];
+                for (int k0 = 0; k0 < width; k0 += 8) {
+                    int c[8];
+                    double v[8], xv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const bool in = k0 + u < len;
+                        const unsigned long long m = __ballot(in);
+                        const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                        const int64_t p = in ? pk_off + rank : (m != 0ull ? pk_off : pk_off - 1);
+                        c[u] = ws >= 0 ? (int)A.xw.lidx[p] : A.pk.col[p];
+                        v[u] = A.pk.val[p];
+                        pk_off += __popcll(m);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) xv[u] = ws >= 0 ? xs[c[u]] : x[c[u]];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        double t = v[u];
+                        if (kScaled && A.s1) t = s1 * t;
+                        if (kScaled && A.s2) t = s2 * t;
+                        const double next = acc + t * xv[u];
+                        acc = (k0 + u < len) ? next : acc;
+                    }
+                }
+                if (live) epi.apply(row, acc, r0, r1);
+            }
+        }
+        __syncthreads();  // the next block overwrites the window
+    }
+    if (Epi::kReductions > 0) {
+        double t = block_sum(r0, lds);
+        if (threadIdx.x == 0) partials[blockIdx.x] = t;
+    }
+    if (Epi::kReductions > 1) {
+        double t = block_sum(r1, lds);
+        if (threadIdx.x == 0) partials[gridDim.x + blockIdx.x] = t;
+    }
+}
+
 // Folds nq partial arrays of `count` entries each (fixed order => reproducible) into out[q].
 // One workgroup; launched after every kernel that produces partials.  In a multi-GPU run the
 // caller follows it with an RCCL all-reduce of out[0..nq).

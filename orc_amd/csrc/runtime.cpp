@@ -5,6 +5,7 @@
 #include "common.hpp"
 
 namespace orc {
+long long debug_xsort_products();  // linalg.hip
 
 static thread_local Ctx *t_ctx_override = nullptr;
 
@@ -218,6 +219,7 @@ int orc_debug_set_spmv_variant(int variant) {
 }
 
 long long orc_debug_halo_overlaps(void) { return orc::ctx().halo_overlaps; }
+long long orc_debug_xsort_products(void) { return orc::debug_xsort_products(); }
 
 int orc_profile_enable(int on) {
     orc::ctx().profile = on != 0;

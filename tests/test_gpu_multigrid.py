@@ -239,3 +239,36 @@ def test_last_slice_dead_lanes_regression(gpu, oracle, mesh_path):
         out.append(s.get_fields())
     for x, y in zip(*out):
         assert np.isfinite(x).all() and np.array_equal(x, y)
+
+
+def test_length_sorted_window_products_are_exercised_and_exact(gpu, oracle, monkeypatch):
+    """ORC_SPMV_XSORT=1 (off by default: measured no faster): levels whose rows average 24 entries or more stream
+    a length-sorted image of their packed mirror (XSortDev: rows of a 256-row block sorted by length and dealt round-robin to
+    the four wavefronts, active lanes of every depth a prefix).  Every row is still summed in ascending-column order, so with
+    the reference's reduction order the whole Multigrid arm stays bit-identical to the oracle — and the hook says the sorted
+    products really ran."""
+    import ctypes
+    from conftest import fv_like_matrix, splitmix64_uniform
+    from orc_amd._lib import lib
+    from orc_amd.linear_algebra import iterative_solve, set_breakdown_guard, set_reduction_order
+    L = lib()
+    L.orc_debug_xsort_products.restype = ctypes.c_longlong
+    a = fv_like_matrix(64, 40, 12)
+    n = a.shape[0]
+    b = a @ splitmix64_uniform(n, 7)
+    x0 = 0.1 * splitmix64_uniform(n, 8)
+    monkeypatch.setenv("ORC_SPMV_XSORT", "1")
+    set_reduction_order(1)
+    set_breakdown_guard(False)
+    try:
+        xo = x0.copy()
+        sto = oracle.iterative_solve(oracle.Csr.from_scipy(a), b, xo, 50, MULTIGRID, 0.5, 1e-3, 1)
+        before = L.orc_debug_xsort_products()
+        x = x0.copy()
+        st = iterative_solve(a, b, x, 50, MULTIGRID, 0.5, 1e-3, 1, raise_on_error=False)
+        ran = L.orc_debug_xsort_products() - before
+        assert st == sto and ran > 0, (st, sto, ran)
+        assert np.array_equal(x.view(np.uint64), xo.view(np.uint64))
+    finally:
+        set_reduction_order(0)
+        set_breakdown_guard(True)
