@@ -277,7 +277,8 @@ def main():
     # --pmc passes: scripts/gpu_pmc_r02.sh; equal to FETCH_SIZE x 2 + WRITE_SIZE of MI355X_MICROARCH.md §HBM for this
     # kernel): bench.py cannot collect counters itself, so it quotes the committed profile of the same kernel on the same
     # matrix when one exists, else null.
-    KERNEL = "spmv_uniform_k<EpiStoreSum, false, true> / <EpiTs, false, true>"
+    variant = getattr(solver, "inloop_variant", "false, true")  # "<narrow columns>, <scaled on the fly>" as launched
+    KERNEL = "spmv_uniform_k<EpiStoreSum, false, true, %s> / <EpiTs, false, true, %s>" % (variant, variant)
     traffic, traffic_source = None, None
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
@@ -340,9 +341,10 @@ def main():
                 "avg_launch_ms_by_epilogue": {"EpiStoreSum": inloop[0], "EpiTs": inloop[1]},
                 "algorithmic_bytes_per_launch": spmv_bytes,
                 "algorithmic_bytes_definition": "SURVEY 8(d): 12 nnz + 20 n per system (f64 value + i32 column per entry; row length, x, y per row); the "
-                                                "epilogue's operand (8 n, EpiTs) the in-loop kernel also reads is NOT counted",
+                                                "epilogue's operand (8 n, EpiTs) the in-loop kernel also reads is NOT counted; with the narrow column image "
+                                                "(template argument 4 = true) the launch streams 2-byte columns, so `frac` is algorithmic throughput",
                 "three_systems_per_launch": None if triple_ms is None else {
-                    "kernel": "spmv3_uniform_k<EpiStoreSum3, 4, true> / <EpiTs3, 4, true>",
+                    "kernel": "spmv3_uniform_k<EpiStoreSum3, 4, true, %s> / <EpiTs3, 4, true, %s>" % (variant, variant),
                     "avg_launch_ms": triple_ms,
                     "avg_launch_ms_by_epilogue": {"EpiStoreSum3": inloop[2], "EpiTs3": inloop[3]},
                     "algorithmic_bytes_per_launch": 3.0 * spmv_bytes,
@@ -351,7 +353,7 @@ def main():
                     "note": "u, v, w momentum products in one launch: 3 SpMV units of SURVEY 8(d); the launch itself moves 28 nnz + 60 n bytes (one "
                             "column stream for three value streams), so `frac` is algorithmic throughput, not traffic",
                 },
-                "plain_product": {"kernel": "spmv_uniform_k<EpiStore, false, true>", "avg_launch_ms": spmv_ms,
+                "plain_product": {"kernel": "spmv_uniform_k<EpiStore, false, true, %s, false>" % variant.split(",")[0], "avg_launch_ms": spmv_ms,
                                   "frac": spmv_bytes / (spmv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
                 "bicgstab_iteration_ms": bicg_ms,
                 "bicgstab_iteration_GBs": bicg_bytes / (bicg_ms * 1e-3) / 1e9,

@@ -278,6 +278,9 @@ int orc_bench_bicgstab_iteration(OrcSolver *s, int reps, double *avg_ms);
  * Multigrid arm (two Jacobi scalings, reduction epilogues), timed with HIP events on the library stream.  avg_ms[0], [1]: one
  * system per launch (nu = A p with sum(nu); t = A s with t.s, t.t); avg_ms[2], [3]: u, v, w in one launch (0 when unsupported). */
 int orc_bench_inloop_products(OrcSolver *s, int reps, double avg_ms[4]);
+/* "<narrow>, <scaled>": the last two template arguments of the kernels orc_bench_inloop_products has just launched
+ * (spmv_uniform_k<Epi, false, true, narrow, scaled>), so that bench.py names the kernel as a kernel trace does */
+const char *orc_bench_inloop_variant(void);
 /* one multicolour Gauss-Seidel sweep over a_u (extension; BASELINE configs[2]): n_colors launches of the colour-sorted
  * kernel per sweep, average ms per sweep over `reps` sweeps */
 int orc_bench_gs_sweep(OrcSolver *s, int reps, double *avg_ms, int *n_colors);

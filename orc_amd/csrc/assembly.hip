@@ -1117,13 +1117,7 @@ static int solve_field_on(SolverState &s, DevBuf<double> &a, DevBuf<double> &b, 
     const OrcSettings &t = s.settings;
     if (arena.empty()) ORC_TRY(arena.reset());  // nothing of the previous solve is alive: a fragmented reservation is folded into one chunk
     if (side_arena && side_arena->empty()) ORC_TRY(side_arena->reset());
-    struct RestoreDefaults {  // this solver's guard and reduction order for the solve, the process-wide defaults back afterwards
-        Ctx &c;
-        bool guard;
-        int order;
-        explicit RestoreDefaults(Ctx &cc) : c(cc), guard(cc.breakdown_guard), order(cc.reduction_order) {}
-        ~RestoreDefaults() { c.breakdown_guard = guard; c.reduction_order = order; }
-    } restore_defaults(ctx());
+    CtxDefaultsScope restore_defaults(ctx());  // this solver's guard and reduction order for the solve only
     ctx().breakdown_guard = t.breakdown_guard != 0;
     ctx().reduction_order = t.reduction_order;
     stats.cache = &s.amg_cache[eq];
@@ -1522,13 +1516,7 @@ static void debug_field(SolverState &s, const char *name, const DevBuf<double> &
 int solver_iterate(SolverState &s, uint64_t iterations, double *report) {
     // the solves below run with THIS solver's guard and reduction order; the process-wide defaults (orc_set_breakdown_guard,
     // orc_set_reduction_order: what orc_iterative_solve uses) are put back on every exit
-    struct RestoreDefaults {
-        Ctx &c;
-        bool guard;
-        int order;
-        explicit RestoreDefaults(Ctx &cc) : c(cc), guard(cc.breakdown_guard), order(cc.reduction_order) {}
-        ~RestoreDefaults() { c.breakdown_guard = guard; c.reduction_order = order; }
-    } restore_defaults(ctx());
+    CtxDefaultsScope restore_defaults(ctx());
     const bool tvd = is_tvd(s.settings.momentum);
     const bool dbg = getenv("ORC_DEBUG_NAN") != nullptr;
     HaloPlan &H = s.mesh->halo;
@@ -1667,6 +1655,7 @@ int initialize_velocity_field_dev(SolverState &s) {
     hipLaunchKernelGGL(psi_system_k, dim3(grid_for(s.n)), dim3(kBlock), 0, ctx().stream, m.dev(), m.pat.dev(), s.a_p.p, s.b_p.p, s.dev_status.p);
     ORC_HIP(hipGetLastError());
     ORC_TRY(vec_fill(s.p_prime.p, 0., s.n));
+    CtxDefaultsScope restore_defaults(ctx());
     ctx().breakdown_guard = s.settings.breakdown_guard != 0;
     ctx().reduction_order = s.settings.reduction_order;
     s.stats.cache = nullptr;
@@ -1701,6 +1690,7 @@ int initialize_flow_dev(SolverState &s, uint64_t iteration_count) {
     if (H.active()) { double *g3[3] = {s.gp.p, s.gp.p + n, s.gp.p + 2 * n}; ORC_TRY(H.exchange(g3, 3)); }
     ORC_TRY(k_face_flux(s, true));
     ORC_TRY(k_momentum(s, nullptr));  // :288-309 (b += b_di inside)
+    CtxDefaultsScope restore_defaults(ctx());
     ctx().breakdown_guard = s.settings.breakdown_guard != 0;
     ctx().reduction_order = s.settings.reduction_order;
     const int64_t len = std::max<int64_t>(s.mesh->pat.padded, 1);

@@ -42,6 +42,18 @@ struct CtxScope {
     ~CtxScope();
 };
 
+// A solver runs its solves with ITS guard and reduction order; the process-wide defaults (orc_set_breakdown_guard,
+// orc_set_reduction_order: what orc_iterative_solve uses) come back on every exit.
+struct CtxDefaultsScope {
+    Ctx &c;
+    bool guard;
+    int order;
+    explicit CtxDefaultsScope(Ctx &cc) : c(cc), guard(cc.breakdown_guard), order(cc.reduction_order) {}
+    ~CtxDefaultsScope() { c.breakdown_guard = guard; c.reduction_order = order; }
+    CtxDefaultsScope(const CtxDefaultsScope &) = delete;
+    CtxDefaultsScope &operator=(const CtxDefaultsScope &) = delete;
+};
+
 int set_error(int code, const char *fmt, ...);
 
 #define ORC_HIP(call)                                                                                     \

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstdint>
 
 #include "linalg_kernels.hpp"
 
@@ -180,6 +181,33 @@ int sell_from_csr_host(int64_t n, int64_t ncols, const int64_t *row_ptr, const i
     ORC_TRY(out.slice_ptr.upload(slice_ptr.data(), slice_ptr.size()));
     ORC_TRY(out.row_len.upload(row_len.data(), (size_t)n));
     ORC_TRY(out.col.upload(scol.data(), (size_t)padded));
+    // narrow column image (SellDev): per slice and depth the smallest column among the rows that reach that depth + 16-bit offsets
+    static const bool narrow_on = !(getenv("ORC_SPMV_NARROW_COLS") && atoi(getenv("ORC_SPMV_NARROW_COLS")) == 0);
+    if (narrow_on && padded > 0) {
+        std::vector<uint16_t> c16((size_t)padded, 0);
+        std::vector<int32_t> cbase((size_t)(padded / 64), 0);
+        bool all_fit = true;
+        for (int32_t s_ = 0; s_ < n_slices && all_fit; ++s_) {
+            const int64_t sb = slice_ptr[s_], w = (slice_ptr[s_ + 1] - sb) / 64;
+            const int64_t r0 = (int64_t)s_ * 64, r1 = std::min<int64_t>(n, r0 + 64);
+            bool fits = true;
+            for (int64_t k = 0; k < w && fits; ++k) {
+                int64_t lo = INT64_MAX, hi = -1;
+                for (int64_t r = r0; r < r1; ++r)
+                    if (k < row_len[r]) { const int64_t c = scol[sb + k * 64 + (r - r0)]; lo = std::min(lo, c); hi = std::max(hi, c); }
+                if (hi < 0) { cbase[(size_t)(sb / 64 + k)] = 0; continue; }
+                if (hi - lo > 65535) { fits = false; break; }
+                cbase[(size_t)(sb / 64 + k)] = (int32_t)lo;
+                for (int64_t r = r0; r < r1; ++r)
+                    if (k < row_len[r]) c16[(size_t)(sb + k * 64 + (r - r0))] = (uint16_t)(scol[sb + k * 64 + (r - r0)] - lo);
+            }
+            all_fit = fits;
+        }
+        if (all_fit) {  // all or nothing: the product kernels have no per-slice branch (scalar registers, see spmv_uniform_k)
+            ORC_TRY(out.col16.upload(c16.data(), c16.size()));
+            ORC_TRY(out.colbase.upload(cbase.data(), cbase.size()));
+        }
+    }
     ORC_TRY(out.diag_pos.upload(diag.data(), (size_t)n));
     ORC_TRY(out.csr_row_ptr.upload(row_ptr, (size_t)n + 1));
     return ORC_OK;
@@ -401,9 +429,16 @@ static int launch_spmv(const MatView &A, const double *x, const Epi &epi, double
         hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi, kSpmvPacked>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
     else if (ragged_enabled && A.P.ragged == 1)  // long ragged rows without a mirror: every slot clamped, nothing skipped
         hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi, kSpmvRagged>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
-    else if (A.persistent_pattern)  // mesh-pattern matrices (level 0): wave-uniform loads, predicated gathers
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_uniform_k<Epi, false, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
-    else  // short ragged rows (first coarse level): the same kernel under its own name
+    else if (A.persistent_pattern) {  // mesh-pattern matrices (level 0): wave-uniform loads, predicated gathers
+        const bool narrow = A.P.col16 != nullptr, scaled = A.s1 || A.s2;
+        if (narrow && !scaled) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_uniform_k<Epi, false, true, true, false>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
+        else if (narrow) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_uniform_k<Epi, false, true, true, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
+        else if (!scaled) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_uniform_k<Epi, false, true, false, false>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_uniform_k<Epi, false, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
+    }
+    else if (!(A.s1 || A.s2))  // short ragged rows (first coarse level): the same kernel under its own name; scaled values materialised
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_uniform_k<Epi, false, false, false, false>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
+    else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_uniform_k<Epi, false>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
     ORC_HIP(hipGetLastError());
     return ORC_OK;
@@ -893,7 +928,13 @@ static int launch_spmv3(const MatView3 &A, const double *x3, const Epi3 &epi, do
     static const int chunk = getenv("ORC_SPMV3_CHUNK") ? atoi(getenv("ORC_SPMV3_CHUNK")) : 4;
     if (chunk == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 8>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
     else if (chunk == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 2>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
-    else if (A.mesh_pattern) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
+    else if (A.mesh_pattern) {
+        const bool narrow = A.P.col16 != nullptr, scaled = A.s1 || A.s2;
+        if (narrow && !scaled) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4, true, true, false>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
+        else if (narrow) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4, true, true, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
+        else if (!scaled) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4, true, false, false>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
+    } else if (!(A.s1 || A.s2)) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4, false, false, false>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
     ORC_HIP(hipGetLastError());
     return ORC_OK;

@@ -23,6 +23,12 @@ struct SellDev {
     const int32_t *row_len = nullptr;    // [n]
     const int32_t *col = nullptr;        // [padded]
     const int32_t *diag_pos = nullptr;   // [n] element offset of the stored diagonal, -1 if absent
+    // Narrow column image [r03] (host-built patterns: the mesh pattern and user matrices): the columns of one depth of one slice
+    // lie within a few tens of each other on a mesh (neighbours of 64 consecutive cells); a pattern whose every slice and depth spans
+    // < 65 536 stores them as colbase[slot / 64] + col16[slot]: 2 instead of 4 bytes per entry in the product's stream — the
+    // level-0 product is bandwidth-bound at the copy ceiling, bytes are what is left.  Other kernels keep `col`.
+    const uint16_t *col16 = nullptr;     // [padded]; present only if EVERY depth of EVERY slice spans < 65 536 (all or nothing: no per-slice branch)
+    const int32_t *colbase = nullptr;    // [padded / 64]: smallest column of that depth of that slice
 };
 
 // Zero-padding mirror of a SELL-64 matrix for the wave-cooperative product (coarse AMG levels, whose rows are ragged:
@@ -126,11 +132,13 @@ struct SellMatrix {
     bool symmetric = true;
     int ragged = 0;
     DevBuf<int64_t> slice_ptr;
-    DevBuf<int32_t> row_len, col, diag_pos;
+    DevBuf<int32_t> row_len, col, diag_pos, colbase;
+    DevBuf<uint16_t> col16;
     DevBuf<int64_t> csr_row_ptr;  // for value import/export in CSR (ORC) order
     SellDev dev() const {
         SellDev d;
         d.n = n; d.ncols = ncols; d.n_slices = n_slices; d.ragged = ragged; d.padded = padded; d.slice_ptr = slice_ptr.p; d.row_len = row_len.p; d.col = col.p; d.diag_pos = diag_pos.p;
+        d.col16 = col16.p; d.colbase = colbase.p;
         return d;
     }
 };

@@ -141,7 +141,11 @@ __global__ __launch_bounds__(kBlock) void spmv_k(MatView A, const double *__rest
 // partials[q * gridDim.x + blockIdx.x] and are folded by reduce_partials_k.
 // kMesh: a tag, no code — products on the mesh pattern (level 0: a_u, a_v, a_w, A_p) get a kernel name of their own, so that a
 // kernel trace separates them from the first coarse level's (profiles/: the roofline of bench.py is about level 0).
-template <class Epi, bool kRagged = false, bool kMesh = false>
+// kNarrow: the pattern has a narrow column image for EVERY slice (SellDev::col16) and the product streams that; kScaled = false:
+// the view carries no row scaling (materialised), so neither the scaling vectors nor the multiplications are compiled in.
+// Both keep the kernel's scalar-register count under 81 — at 81-96 only seven wavefronts per SIMD are resident, and a launch of
+// eight workgroups per CU then runs a second, nearly empty round (measured: 213 -> 273 us).
+template <class Epi, bool kRagged = false, bool kMesh = false, bool kNarrow = false, bool kScaled = true>
 __global__ __launch_bounds__(kBlock) void spmv_uniform_k(MatView A, const double *__restrict__ x, Epi epi, double *__restrict__ partials,
                                                  const double *__restrict__ skip_flags /* 2 doubles or null: non-zero = no-op */) {
     __shared__ double lds[8];
@@ -155,16 +159,25 @@ __global__ __launch_bounds__(kBlock) void spmv_uniform_k(MatView A, const double
         const int width = (int)((A.P.slice_ptr[slice + 1] - base) >> 6);
         const bool live = row < A.P.n;
         const int len = live ? A.P.row_len[row] : 0;
-        const double s1 = (A.s1 && live) ? A.s1[row] : 1.;
-        const double s2 = (A.s2 && live) ? A.s2[row] : 1.;
+        const double s1 = (kScaled && A.s1 && live) ? A.s1[row] : 1.;
+        const double s2 = (kScaled && A.s2 && live) ? A.s2[row] : 1.;
         double acc = 0.;
         // chunks of 8 entries: all column and value loads are issued first, then the dependent x gathers, then the
         // products are added in ascending k — the association of the CPU product, just with the loads in flight together.
         // Padding slots hold a valid column (the row itself) and are masked out of the sum.
+        const int32_t *__restrict__ cb = kNarrow ? A.P.colbase + (base >> 6) : nullptr;  // narrow column image: the 32-bit columns are never touched
         for (int k0 = 0; k0 < width; k0 += 8) {
             int c[8];
             double v[8], xv[8];
             const int64_t p0 = base + (int64_t)k0 * 64 + lane;
+            if (kNarrow) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const bool in = k0 + u < width;
+                    c[u] = in ? cb[k0 + u] + (int)A.P.col16[p0 + (int64_t)u * 64] : 0;
+                    v[u] = in ? A.val[p0 + (int64_t)u * 64] : 0.;
+                }
+            } else {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 // kRagged (coarse AMG levels, 11-49 % padding): padding slots are not fetched, so a cache line whose lanes
@@ -173,14 +186,15 @@ __global__ __launch_bounds__(kBlock) void spmv_uniform_k(MatView A, const double
                 c[u] = in ? A.P.col[p0 + (int64_t)u * 64] : 0;
                 v[u] = in ? A.val[p0 + (int64_t)u * 64] : 0.;
             }
+            }
 #pragma unroll
             for (int u = 0; u < 8; ++u) xv[u] = (k0 + u < len) ? x[c[u]] : 0.;
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 if (k0 + u < len) {
                     double t = v[u];
-                    if (A.s1) t = s1 * t;
-                    if (A.s2) t = s2 * t;
+                    if (kScaled && A.s1) t = s1 * t;
+                    if (kScaled && A.s2) t = s2 * t;
                     acc += t * xv[u];
                 }
             }
@@ -205,7 +219,7 @@ __global__ __launch_bounds__(kBlock) void spmv_uniform_k(MatView A, const double
 // spmv_uniform_k, so every system's row sums AND partial sums are those of its own one-system product.
 struct __attribute__((aligned(8))) Vec3d { double a, b, c; };
 
-template <class Epi3, int kChunk = 4, bool kMesh = false>
+template <class Epi3, int kChunk = 4, bool kMesh = false, bool kNarrow = false, bool kScaled = true>
 __global__ __launch_bounds__(kBlock) void spmv3_uniform_k(MatView3 A, const double *__restrict__ x3, Epi3 epi, double *__restrict__ partials) {
     __shared__ double lds[8];
     const int lane = threadIdx.x & 63;
@@ -221,9 +235,10 @@ __global__ __launch_bounds__(kBlock) void spmv3_uniform_k(MatView3 A, const doub
         const bool live = row < A.P.n;
         const int len = live ? A.P.row_len[row] : 0;
         Vec3d s1 = {1., 1., 1.}, s2 = {1., 1., 1.};
-        if (A.s1 && live) s1 = s1v[row];
-        if (A.s2 && live) s2 = s2v[row];
+        if (kScaled && A.s1 && live) s1 = s1v[row];
+        if (kScaled && A.s2 && live) s2 = s2v[row];
         double acc0 = 0., acc1 = 0., acc2 = 0.;
+        const int32_t *__restrict__ cb = kNarrow ? A.P.colbase + (base >> 6) : nullptr;  // narrow column image (SellDev)
         for (int k0 = 0; k0 < width; k0 += kChunk) {
             int c[kChunk];
             double v0[kChunk], v1[kChunk], v2[kChunk];
@@ -232,7 +247,8 @@ __global__ __launch_bounds__(kBlock) void spmv3_uniform_k(MatView3 A, const doub
 #pragma unroll
             for (int u = 0; u < kChunk; ++u) {  // wave-uniform matrix loads at compile-time offsets from one chunk base
                 const bool in = k0 + u < width;
-                c[u] = in ? A.P.col[p0 + (int64_t)u * 64] : 0;
+                if (kNarrow) c[u] = in ? cb[k0 + u] + (int)A.P.col16[p0 + (int64_t)u * 64] : 0;
+                else c[u] = in ? A.P.col[p0 + (int64_t)u * 64] : 0;
                 v0[u] = in ? A.val[0][p0 + (int64_t)u * 64] : 0.;
                 v1[u] = in ? A.val[1][p0 + (int64_t)u * 64] : 0.;
                 v2[u] = in ? A.val[2][p0 + (int64_t)u * 64] : 0.;
@@ -246,8 +262,8 @@ __global__ __launch_bounds__(kBlock) void spmv3_uniform_k(MatView3 A, const doub
             for (int u = 0; u < kChunk; ++u) {
                 if (k0 + u < len) {
                     double t0 = v0[u], t1 = v1[u], t2 = v2[u];
-                    if (A.s1) { t0 = s1.a * t0; t1 = s1.b * t1; t2 = s1.c * t2; }
-                    if (A.s2) { t0 = s2.a * t0; t1 = s2.b * t1; t2 = s2.c * t2; }
+                    if (kScaled && A.s1) { t0 = s1.a * t0; t1 = s1.b * t1; t2 = s1.c * t2; }
+                    if (kScaled && A.s2) { t0 = s2.a * t0; t1 = s2.b * t1; t2 = s2.c * t2; }
                     acc0 += t0 * xv[u].a;
                     acc1 += t1 * xv[u].b;
                     acc2 += t2 * xv[u].c;

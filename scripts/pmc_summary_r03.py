@@ -77,16 +77,19 @@ ks = os.path.join(base, "kernel_stats.csv")
 if os.path.exists(ks):
     shutil.copyfile(ks, os.path.join(root, "profiles", "r03_products_kernel_stats.csv"))
 # the kernel bench.py's roofline names: the two in-loop launches of one system, averaged (one of each per BiCGSTAB iteration)
-pair = [r for r in rows if r["kernel"] in ("spmv_uniform_k<EpiStoreSum, false, true>", "spmv_uniform_k<EpiTs, false, true>")]
+# the in-loop launches of one system on level 0: spmv_uniform_k<EpiStoreSum | EpiTs, false, true, narrow, scaled>
+pair = [r for r in rows if r["kernel"].startswith(("spmv_uniform_k<EpiStoreSum, false, true", "spmv_uniform_k<EpiTs, false, true"))]
 if len(pair) == 2:
+    names = [r["kernel"] for r in sorted(pair, key=lambda r: "EpiTs" in r["kernel"])]
+    kernel_name = names[0] + " / " + names[1].replace("spmv_uniform_k", "")
     avg = lambda key: sum(r[key] for r in pair) / 2.  # noqa: E731
     doc = {"workload": "hex channel 400x160x160, a_u through two Jacobi scalings (scripts/profile_products.py)", "n": N, "nnz": NNZ,
-           "kernel": "spmv_uniform_k<EpiStoreSum, false, true> / <EpiTs, false, true>", "avg_us": avg("avg_us"),
+           "kernel": kernel_name, "avg_us": avg("avg_us"),
            "hbm_read_bytes_per_launch": avg("hbm_read_bytes"), "hbm_write_bytes_per_launch": avg("hbm_write_bytes"),
            "hbm_bytes_per_launch": avg("hbm_read_bytes") + avg("hbm_write_bytes"),
            "bytes_by_request_size_per_launch": avg("read_bytes_by_request_size") + avg("write_bytes_by_request_size"),
            "algorithmic_bytes_per_launch": 12.0 * NNZ + 20.0 * N,
-           "bytes_the_launch_must_move": 12.0 * NNZ + 20.0 * N + 16.0 * N + 4.0 * N,  # + two scaling vectors; EpiTs also re-reads s (8 n): 4 n on average
+           "bytes_the_launch_must_move_with_4_byte_columns": 12.0 * NNZ + 20.0 * N + 4.0 * N,  # EpiTs also re-reads s (8 n): 4 n on average
            "per_epilogue": {r["kernel"]: {"avg_us": r["avg_us"], "hbm_bytes": r["hbm_read_bytes"] + r["hbm_write_bytes"]} for r in pair},
            "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, KiB; reads doubled: gfx950 tallies 128-byte requests at 64 bytes, "
                      "MI355X_MICROARCH.md HBM); scripts/gpu_pmc_r03.sh + scripts/pmc_summary_r03.py"}
