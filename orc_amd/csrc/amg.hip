@@ -1520,6 +1520,34 @@ __global__ __launch_bounds__(kBlock) void xwin_build_k(SellDev P, PackedDev pk, 
     }
 }
 
+// ---- narrow column image of a coarse operator (SellDev::col16 / colbase, linalg.hpp): one wavefront per slice; per depth the
+// smallest column among the rows that reach it and 16-bit offsets from it; *too_wide is raised if a depth spans 65 536 or more
+__global__ __launch_bounds__(64) void narrow_build_k(SellDev P, unsigned short *__restrict__ col16, int *__restrict__ colbase, int *__restrict__ too_wide) {
+    const int lane = threadIdx.x;
+    for (int64_t slice = blockIdx.x; slice < P.n_slices; slice += gridDim.x) {
+        const int64_t row = slice * 64 + lane;
+        const int64_t sb = P.slice_ptr[slice];
+        const int width = (int)((P.slice_ptr[slice + 1] - sb) >> 6);
+        const int len = row < P.n ? P.row_len[row] : 0;
+        for (int k = 0; k < width; ++k) {
+            const bool in = k < len;
+            const int c = in ? P.col[sb + (int64_t)k * 64 + lane] : 0;
+            int lo = in ? c : 0x7fffffff, hi = in ? c : -1;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                lo = min(lo, __shfl_xor(lo, off, 64));
+                hi = max(hi, __shfl_xor(hi, off, 64));
+            }
+            if (hi < 0) lo = 0;  // nobody reaches this depth
+            if (lane == 0) {
+                colbase[(sb >> 6) + k] = lo;
+                if (hi >= 0 && hi - lo > 65535) atomicOr(too_wide, 1);
+            }
+            col16[sb + (int64_t)k * 64 + lane] = in ? (unsigned short)(c - lo) : (unsigned short)0;
+        }
+    }
+}
+
 // ---- length-sorted image of the packed mirror (XSortDev, linalg.hpp): one workgroup per block of 256 rows.
 // sorted rank of a row = rows of the block that are longer + equally long rows before it; rank r -> wave r & 3, lane r >> 2.
 // R(q) = rows longer than q, so wave w owns cnt_w(q) = ceil((R(q) - w) / 4) entries at depth q, a prefix of its lanes.
@@ -2077,6 +2105,23 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
                        s_col, s_val, col, val, diag, mirror ? (const int64_t *)pk_ptr : (const int64_t *)nullptr, pk_col, pk_val);
     ORC_HIP(hipGetLastError());
     lap("galerkin pack");
+    // narrow column image for the levels the uniform kernels multiply (no packed mirror: the first coarse level): 2-byte columns in
+    // their products' stream; all or nothing, decided on the host (the kernel variant is a template argument)
+    static const bool narrow_on = !(getenv("ORC_SPMV_NARROW_COLS") && atoi(getenv("ORC_SPMV_NARROW_COLS")) == 0);
+    if (narrow_on && !mirror && padded > 0) {
+        unsigned short *c16;
+        int *cbase, *wide;
+        ORC_TRY(arena.alloc((size_t)padded, &c16));
+        ORC_TRY(arena.alloc((size_t)(padded / 64) + 1, &cbase));
+        ORC_TRY(tmp.alloc((size_t)1, &wide));
+        ORC_HIP(hipMemsetAsync(wide, 0, sizeof(int), st));
+        hipLaunchKernelGGL(narrow_build_k, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(n_slices, 256 * 32))), dim3(64), 0, st, Pc, c16, cbase, wide);
+        ORC_HIP(hipGetLastError());
+        int h_wide = 1;
+        ORC_HIP(hipMemcpyAsync(&h_wide, wide, sizeof(int), hipMemcpyDeviceToHost, st));
+        ORC_HIP(hipStreamSynchronize(st));
+        if (!h_wide) { Pc.col16 = c16; Pc.colbase = cbase; }
+    }
     L.P = Pc; L.val = val; L.n = nc; L.padded = padded;
     L.pk = PackedDev();
     L.xw = XWinDev();

@@ -436,6 +436,8 @@ static int launch_spmv(const MatView &A, const double *x, const Epi &epi, double
         else if (!scaled) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_uniform_k<Epi, false, true, false, false>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_uniform_k<Epi, false, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
     }
+    else if (!(A.s1 || A.s2) && A.P.col16)  // first coarse level, scaled values materialised, narrow column image
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_uniform_k<Epi, false, false, true, false>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
     else if (!(A.s1 || A.s2))  // short ragged rows (first coarse level): the same kernel under its own name; scaled values materialised
         hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_uniform_k<Epi, false, false, false, false>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
     else
@@ -934,7 +936,8 @@ static int launch_spmv3(const MatView3 &A, const double *x3, const Epi3 &epi, do
         else if (narrow) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4, true, true, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
         else if (!scaled) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4, true, false, false>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
-    } else if (!(A.s1 || A.s2)) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4, false, false, false>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
+    } else if (!(A.s1 || A.s2) && A.P.col16) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4, false, true, false>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
+    else if (!(A.s1 || A.s2)) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4, false, false, false>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
     ORC_HIP(hipGetLastError());
     return ORC_OK;
