@@ -20,7 +20,12 @@ def short(name):
 
 # per kernel: counter -> list of (dispatch id, value)
 per = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in sorted(glob.glob(os.path.join(base, "p*", "*", "*counter_collection.csv"))):
+# gpurun MERGES what a call wrote into gpurun_out/: files of an earlier run of the script stay beside the new ones — per pass only the
+# newest counter file counts
+passes = collections.defaultdict(list)
+for f in glob.glob(os.path.join(base, "p*", "*", "*counter_collection.csv")):
+    passes[os.path.dirname(f)].append(f)
+for f in sorted(max(v, key=os.path.getmtime) for v in passes.values()):
     disp = collections.defaultdict(float)
     for r in csv.DictReader(open(f)):
         disp[(int(r["Dispatch_Id"]), short(r["Kernel_Name"]), r["Counter_Name"])] += float(r["Counter_Value"])
