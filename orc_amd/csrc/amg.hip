@@ -1520,6 +1520,31 @@ __global__ __launch_bounds__(kBlock) void xwin_build_k(SellDev P, PackedDev pk, 
     }
 }
 
+// ORC_XWIN_STATS=1 (measurement): how the windows of a level are made up — entries, maximal runs of consecutive columns, runs of
+// eight or more, blocks whose columns span fewer than 65 536
+__global__ __launch_bounds__(kBlock) void xwin_stats_k(const int *__restrict__ wcol, const int *__restrict__ wsize, int64_t n_blocks, unsigned long long *__restrict__ out) {
+    for (int64_t b = blockIdx.x; b < n_blocks; b += gridDim.x) {
+        const int ws = wsize[b];
+        if (ws <= 0) { if (threadIdx.x == 0 && ws < 0) atomicAdd(out + 4, 1ull); continue; }
+        const int *wc = wcol + b * kXWinCap;
+        unsigned long long runs = 0, long_entries = 0;
+        for (int j = threadIdx.x; j < ws; j += kBlock) {
+            if (j == 0 || wc[j] != wc[j - 1] + 1) {
+                ++runs;
+                int e = j + 1;
+                while (e < ws && wc[e] == wc[e - 1] + 1) ++e;
+                if (e - j >= 8) long_entries += (unsigned long long)(e - j);
+            }
+        }
+        atomicAdd(out + 1, runs);
+        atomicAdd(out + 2, long_entries);
+        if (threadIdx.x == 0) {
+            atomicAdd(out + 0, (unsigned long long)ws);
+            if (wc[ws - 1] - wc[0] < 65536) atomicAdd(out + 3, 1ull);
+        }
+    }
+}
+
 // ---- narrow column image of a coarse operator (SellDev::col16 / colbase, linalg.hpp): one wavefront per slice; per depth the
 // smallest column among the rows that reach it and 16-bit offsets from it; *too_wide is raised if a depth spans 65 536 or more
 __global__ __launch_bounds__(64) void narrow_build_k(SellDev P, unsigned short *__restrict__ col16, int *__restrict__ colbase, int *__restrict__ too_wide) {
@@ -1658,6 +1683,7 @@ struct CoarseLevel {
     XWinDev xw;
     XSortDev xs;
     RowsDev rows;
+    bool rows_transient = false;  // `rows` lives in the set-up's companion arena: valid until the next level has been built
     int64_t n = 0, padded = 0;
     int *choice = nullptr, *chooser = nullptr;  // of the FINE level this was built from
     int rounds = 0;
@@ -2130,11 +2156,18 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
     static const bool rows_enabled = !(getenv("ORC_AMG_ROWS_MIRROR") && atoi(getenv("ORC_AMG_ROWS_MIRROR")) == 0);
     if (rows_enabled && !scratch) { L.rows.slice_base = slice_base; L.rows.intra_off = intra_off; L.rows.col = s_col; L.rows.val = s_val; }
     if (rows_enabled && scratch && packed_total > 0 && !last_level) {  // exact-size copy; the slices start where the packed mirror's do (pk_ptr); the last level is never aggregated
+        // Only the NEXT level's aggregation and Galerkin product walk it, and the mirror of the level below (A.rows) is dead now
+        // that this product's kernels are queued (same stream): both take turns in the scratch arena's companion, so a hierarchy
+        // keeps no mirror once it is built (2 GB of 10.3 GB per hierarchy at 10.24 M rows).  ORC_AMG_MIRROR_ARENA=0: in `arena`.
+        static const bool mirror_arena_on = !(getenv("ORC_AMG_MIRROR_ARENA") && atoi(getenv("ORC_AMG_MIRROR_ARENA")) == 0);
+        Arena &rows_arena = mirror_arena_on ? scratch->companion() : arena;
+        if (mirror_arena_on) rows_arena.release(Arena::Mark{0, 0});
         int *r_col, *r_intra;
         double *r_val;
-        ORC_TRY(arena.alloc((size_t)packed_total, &r_col));
-        ORC_TRY(arena.alloc((size_t)packed_total, &r_val));
-        ORC_TRY(arena.alloc(ncs, &r_intra));
+        ORC_TRY(rows_arena.alloc((size_t)packed_total, &r_col));
+        ORC_TRY(rows_arena.alloc((size_t)packed_total, &r_val));
+        ORC_TRY(rows_arena.alloc(ncs, &r_intra));
+        L.rows_transient = mirror_arena_on;
         hipLaunchKernelGGL(rows_compact_k, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(n_slices, 256 * 16))), dim3(64), 0, st, (const int *)row_len, nc, n_slices,
                            (const long long *)slice_base, (const int *)intra_off, (const int *)s_col, (const double *)s_val, (const int64_t *)pk_ptr, r_intra, r_col, r_val);
         ORC_HIP(hipGetLastError());
@@ -2151,6 +2184,18 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
         hipLaunchKernelGGL(xwin_build_k, dim3((unsigned)std::min<int64_t>(n_blocks, 2048)), dim3(kBlock), 0, st, Pc, L.pk, wcol, wsize, lidx, n_blocks);
         ORC_HIP(hipGetLastError());
         L.xw.wcol = wcol; L.xw.wsize = wsize; L.xw.lidx = lidx;
+        static const bool xwin_stats = getenv("ORC_XWIN_STATS") && atoi(getenv("ORC_XWIN_STATS")) != 0;
+        if (xwin_stats) {
+            unsigned long long *d_st, h_st[5];
+            ORC_TRY(tmp.alloc((size_t)5, &d_st));
+            ORC_HIP(hipMemsetAsync(d_st, 0, sizeof(h_st), st));
+            hipLaunchKernelGGL(xwin_stats_k, dim3((unsigned)std::min<int64_t>(n_blocks, 4096)), dim3(kBlock), 0, st, (const int *)wcol, (const int *)wsize, n_blocks, d_st);
+            ORC_HIP(hipMemcpyAsync(h_st, d_st, sizeof(h_st), hipMemcpyDeviceToHost, st));
+            ORC_HIP(hipStreamSynchronize(st));
+            fprintf(stderr, "[orc xwin] rows %lld nnz %lld blocks %lld: window entries %llu (%.1f per row), runs %llu (%.1f entries per run), in runs >= 8: %.1f %%, span < 65536: %llu blocks, no window: %llu\n",
+                    (long long)nc, (long long)packed_total, (long long)n_blocks, h_st[0], (double)h_st[0] / (double)nc, h_st[1], (double)h_st[0] / (double)std::max<unsigned long long>(h_st[1], 1),
+                    100. * (double)h_st[2] / (double)std::max<unsigned long long>(h_st[0], 1), h_st[3], h_st[4]);
+        }
         // Length-sorted image (XSortDev): OFF by default.  Measured at 10.24 M cells: the sorted product needs a third of the vector
         // instructions per entry of the packed one and is NOT faster (level 2: 229-236 us against 235-237, level 3: 239-247 against
         // 227-244, same box), while building the image costs +45-65 ms and 11 GB per SIMPLE iteration — the window product is not
@@ -2327,6 +2372,10 @@ int multigrid_prepare_dev(const MatView &A_in, int preconditioner, Arena &arena,
     static const bool scratch_on = !(getenv("ORC_AMG_SCRATCH") && atoi(getenv("ORC_AMG_SCRATCH")) == 0);  // 0: everything in `arena` (round 2)
     if (!scratch_on) scratch = nullptr;
     if (n == 0) return ORC_OK;
+    if (scratch) {  // nothing of an earlier set-up's mirrors is alive
+        scratch->companion().release(Arena::Mark{0, 0});
+        ORC_TRY(scratch->companion().reset());
+    }
     MatView views[4];
     views[0] = A_in;
     if (preconditioner == ORC_PRECOND_JACOBI) {
@@ -2358,7 +2407,8 @@ int multigrid_prepare_dev(const MatView &A_in, int preconditioner, Arena &arena,
         }
         ORC_TRY(agg_st);
         ORC_TRY(galerkin(A, h.choice, h.chooser, arena, L, scratch, level == max_levels));
-        h.P = L.P; h.val = L.val; h.pk = L.pk; h.xw = L.xw; h.xs = L.xs; h.rows = L.rows; h.n = L.n; h.padded = L.padded; h.rounds = L.rounds;
+        // a mirror in the companion arena lives until the next level is built: the hierarchy does not carry it
+        h.P = L.P; h.val = L.val; h.pk = L.pk; h.xw = L.xw; h.xs = L.xs; h.rows = L.rows_transient ? RowsDev() : L.rows; h.n = L.n; h.padded = L.padded; h.rounds = L.rounds;
         H.n_levels = (int)level;
         if (!(level < max_levels && L.n > 16)) break;  // :109
         MatView Ac;

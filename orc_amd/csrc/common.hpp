@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -132,8 +133,13 @@ class Arena {
     template <class T>
     int alloc(size_t count, T **out) { return alloc_bytes(count * sizeof(T), (void **)out); }
     size_t reserved() const;
+    // A second stack with its own life cycle that travels with this one (created on first use): a hierarchy set-up keeps the
+    // row-contiguous mirror of the level it is aggregating there — needed until the next level's Galerkin product has run, no
+    // longer — while its other transient storage unwinds level by level on this stack.
+    Arena &companion() { if (!companion_) companion_.reset(new Arena()); return *companion_; }
 
   private:
+    std::unique_ptr<Arena> companion_;
     struct Chunk { char *p; size_t size; };
     std::vector<Chunk> chunks_;
     size_t cur_ = 0, off_ = 0;
