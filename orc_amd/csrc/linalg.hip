@@ -400,10 +400,12 @@ static int launch_spmv(const MatView &A, const double *x, const Epi &epi, double
     if (A.P.n == 0) return ORC_OK;
     if (A.halo) ORC_TRY(A.halo->exchange(const_cast<double *>(x)));  // C1: refresh the ghost entries of x
     if (xwin) {
+        static const bool xwin_early = getenv("ORC_XWIN_EARLY") && atoi(getenv("ORC_XWIN_EARLY")) != 0;
         if (variant == 21) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_xwin_k<Epi, 1>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
         else if (variant == 22) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_xwin_k<Epi, 2>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
         else if (A.xs.val && variant == 0 && !A.s1 && !A.s2) { hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_xsort_k<Epi, false>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags); g_xsort_products.fetch_add(1, std::memory_order_relaxed); }
         else if (A.xs.val && variant == 0) { hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_xsort_k<Epi, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags); g_xsort_products.fetch_add(1, std::memory_order_relaxed); }
+        else if (!A.s1 && !A.s2 && xwin_early) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_xwin_k<Epi, 3, false>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
         else if (!A.s1 && !A.s2) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_xwin_k<Epi, 0, false>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_xwin_k<Epi>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
         ORC_HIP(hipGetLastError());

@@ -397,7 +397,7 @@ __global__ __launch_bounds__(kBlock) void spmv_pipe_k(MatView A, const double *_
 
 // Product on the packed mirror with LDS-staged x windows (XWinDev): one workgroup per block of 256 rows, its 4 waves on
 // the block's 4 slices.  Workgroups b and b + 8 share an XCD, so XCD g walks a contiguous eighth of the blocks.
-// kDebug (measurement only): 1 = window loads skipped, 2 = stream phase skipped
+// kDebug (measurement only): 1 = window loads skipped, 2 = stream phase skipped, 3 = first chunk of the stream requested before the window
 // kScaled = false: the view carries no row scaling (a smoothing solve has materialised its scaled values, materialize_scaled_view):
 // the two scaling multiplications per entry and their selects are not compiled in — the stream loop of this kernel is bound by
 // instruction issue as much as by memory (39 vector instructions per entry and wavefront, profiles/r03_pmc_products.csv)
@@ -422,6 +422,41 @@ __global__ __launch_bounds__(kBlock) void spmv_xwin_k(MatView A, const double *_
     }
     for (int64_t b = b_begin; b < b_end; b += b_step) {
         const int ws = A.xw.wsize[b];  // workgroup-uniform
+        // the slice's own stream does not depend on the window: its descriptors — and with kDebug == 3 (experiment,
+        // ORC_XWIN_EARLY=1) its first chunk — are requested before the window is loaded
+        const int64_t slice = b * 4 + wave;
+        const bool has_slice = slice < A.P.n_slices && kDebug != 2;
+        const int64_t row = slice * 64 + lane;
+        const bool live = has_slice && row < A.P.n;
+        int width = 0, len = 0;
+        int64_t pk_off = 0;
+        if (has_slice) {
+            const int64_t base = A.P.slice_ptr[slice];
+            width = (int)((A.P.slice_ptr[slice + 1] - base) >> 6);
+            len = live ? A.P.row_len[row] : 0;
+            pk_off = A.pk.ptr[slice];
+        }
+        // Addresses are a wave-uniform slice base (scalar registers) plus a 32-bit in-slice offset: no 64-bit vector arithmetic
+        // per entry.
+        const int64_t sb = __builtin_amdgcn_readfirstlane((int)(pk_off & 0xffffffff)) | ((int64_t)__builtin_amdgcn_readfirstlane((int)(pk_off >> 32)) << 32);
+        const unsigned short *s_lidx = A.xw.lidx + sb;
+        const double *s_val = A.pk.val + sb;
+        int off32 = 0;  // wave-uniform running offset of the chunk inside the slice
+        int c[8], cn[8];
+        double v[8], vn[8];
+        auto issue = [&](int k0, int (&cc)[8], double (&vv)[8]) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {  // branch-free loads, see spmv_k
+                const bool in = k0 + u < len;
+                const unsigned long long m = __ballot(in);
+                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                const int p = in ? off32 + rank : (m != 0ull ? off32 : off32 - 1);
+                cc[u] = (int)s_lidx[p];
+                vv[u] = s_val[p];
+                off32 += __popcll(m);
+            }
+        };
+        if (kDebug == 3 && has_slice && ws >= 0 && width > 0) issue(0, c, v);
         if (ws > 0 && kDebug != 1) {
             // window -> LDS: all column loads of a pass are issued before the x gathers, those before the LDS writes
             // (a rolled loop would cost two dependent round trips per element)
@@ -444,41 +479,14 @@ __global__ __launch_bounds__(kBlock) void spmv_xwin_k(MatView A, const double *_
             }
         }
         __syncthreads();
-        const int64_t slice = b * 4 + wave;
-        if (slice < A.P.n_slices && kDebug != 2) {
-            const int64_t row = slice * 64 + lane;
-            const int64_t base = A.P.slice_ptr[slice];
-            const int width = (int)((A.P.slice_ptr[slice + 1] - base) >> 6);
-            const bool live = row < A.P.n;
-            const int len = live ? A.P.row_len[row] : 0;
+        if (has_slice) {
             const double s1 = (kScaled && A.s1 && live) ? A.s1[row] : 1.;
             const double s2 = (kScaled && A.s2 && live) ? A.s2[row] : 1.;
             double acc = 0.;
-            int64_t pk_off = A.pk.ptr[slice];
             if (ws >= 0) {
-                // two chunks in flight: the loads of chunk k0 + 8 are issued before chunk k0 is consumed (with 32 KB of LDS
-                // per workgroup only 20 waves fit a CU, so each has to keep more bytes in flight).  Addresses are a
-                // wave-uniform slice base (scalar registers) plus a 32-bit in-slice offset: no 64-bit vector arithmetic
-                // per entry.
-                const int64_t sb = __builtin_amdgcn_readfirstlane((int)(pk_off & 0xffffffff)) | ((int64_t)__builtin_amdgcn_readfirstlane((int)(pk_off >> 32)) << 32);
-                const unsigned short *s_lidx = A.xw.lidx + sb;
-                const double *s_val = A.pk.val + sb;
-                int off32 = 0;  // wave-uniform running offset of the chunk inside the slice
-                int c[8], cn[8];
-                double v[8], vn[8];
-                auto issue = [&](int k0, int (&cc)[8], double (&vv)[8]) {
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {  // branch-free loads, see spmv_k
-                        const bool in = k0 + u < len;
-                        const unsigned long long m = __ballot(in);
-                        const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                        const int p = in ? off32 + rank : (m != 0ull ? off32 : off32 - 1);
-                        cc[u] = (int)s_lidx[p];
-                        vv[u] = s_val[p];
-                        off32 += __popcll(m);
-                    }
-                };
-                if (width > 0) issue(0, c, v);
+                // two chunks in flight: the loads of chunk k0 + 8 are issued before chunk k0 is consumed (with 40 KB of LDS
+                // per workgroup only 16 waves fit a CU, so each has to keep more bytes in flight)
+                if (kDebug != 3 && width > 0) issue(0, c, v);
                 for (int k0 = 0; k0 < width; k0 += 8) {
                     const bool more = k0 + 8 < width;
                     if (more) issue(k0 + 8, cn, vn);
@@ -500,23 +508,23 @@ __global__ __launch_bounds__(kBlock) void spmv_xwin_k(MatView A, const double *_
                 }
             } else {
                 for (int k0 = 0; k0 < width; k0 += 8) {
-                    int c[8];
-                    double v[8], xv[8];
+                    int cg[8];
+                    double vg[8], xv[8];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         const bool in = k0 + u < len;
                         const unsigned long long m = __ballot(in);
                         const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
                         const int64_t p = in ? pk_off + rank : (m != 0ull ? pk_off : pk_off - 1);
-                        c[u] = A.pk.col[p];
-                        v[u] = A.pk.val[p];
+                        cg[u] = A.pk.col[p];
+                        vg[u] = A.pk.val[p];
                         pk_off += __popcll(m);
                     }
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) xv[u] = x[c[u]];
+                    for (int u = 0; u < 8; ++u) xv[u] = x[cg[u]];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
-                        double t = v[u];
+                        double t = vg[u];
                         if (kScaled && A.s1) t = s1 * t;
                         if (kScaled && A.s2) t = s2 * t;
                         const double next = acc + t * xv[u];
