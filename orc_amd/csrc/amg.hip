@@ -728,17 +728,12 @@ struct RRow {
 };
 // Every array index below is a compile-time constant (fixed sorting network, unrolled merges), so the row lives in
 // registers; a dynamically indexed idx[]/w[] would be spilled to scratch memory.
-__device__ __forceinline__ RRow restriction_row(const int *__restrict__ choice, int64_t I, int64_t n_fine) {
+// (pair0, pair1 = choice[2I], choice[2I + 1], -1 where the fine row does not exist: loaded by the caller, ahead of time)
+__device__ __forceinline__ RRow restriction_row_from(int64_t I, int pair0, int pair1) {
     constexpr int kNone = 0x7fffffff;
     int v[4] = {kNone, kNone, kNone, kNone};
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int64_t i = 2 * I + t;
-        if (i < n_fine) {
-            const int c = choice[i];
-            if (c >= 0) { v[2 * t] = (int)i; v[2 * t + 1] = c; }
-        }
-    }
+    if (pair0 >= 0) { v[0] = (int)(2 * I); v[1] = pair0; }
+    if (pair1 >= 0) { v[2] = (int)(2 * I + 1); v[3] = pair1; }
     // sorting network for 4 keys (absent entries sort last)
 #define ORC_CSWAP(x, y) { const int lo__ = min(v[x], v[y]), hi__ = max(v[x], v[y]); v[x] = lo__; v[y] = hi__; }
     ORC_CSWAP(0, 1) ORC_CSWAP(2, 3) ORC_CSWAP(0, 2) ORC_CSWAP(1, 3) ORC_CSWAP(1, 2)
@@ -764,6 +759,11 @@ __device__ __forceinline__ RRow restriction_row(const int *__restrict__ choice, 
         }
     }
     return r;
+}
+__device__ __forceinline__ RRow restriction_row(const int *__restrict__ choice, int64_t I, int64_t n_fine) {
+    const int pair0 = 2 * I < n_fine ? choice[2 * I] : -1;
+    const int pair1 = 2 * I + 1 < n_fine ? choice[2 * I + 1] : -1;
+    return restriction_row_from(I, pair0, pair1);
 }
 
 // r' = R r (:82)
@@ -1081,12 +1081,21 @@ __device__ __forceinline__ int group_excl_scan(int v, int &total) {
 }
 
 // G lanes per coarse row (64 / G rows per wavefront): the passes of a narrow row (<= 32 candidates on the first coarse
-// level) fill half a wavefront, and the kernel is bound by instruction issue, not by memory.
-template <int G>
+// level) fill half a wavefront.
+// [r03] Step 1 used to walk the <= 4 fine rows one after the other — descriptor -> columns -> values, twelve dependent global
+// round trips per coarse row, 43 % of the kernel on the widest tier (ORC_GALERKIN_STAGES=1 launches the kernel cut short
+// after step 1 and after step 4: 3.6 of 8.4 ms).  Now the descriptors of all fine rows are requested together, then their
+// first G entries together, from the row-contiguous mirror where the matrix has one, and the next coarse row's index and
+// pairing travel while the current row is merged: step 1 3.6 -> 1.5 ms, the kernel 8.4 -> 7.7 ms (the later steps slow down
+// as the first one stops pacing them: the kernel as a whole moves ~800 scattered cache-line requests per coarse row).
+// Batching the pairing look-ups of step 4 (speculative second-level loads) and running the LDS searches of a step side by
+// side were measured too: +1.2 ms and +2.1 ms.  Same LDS passes, same order of every sum and output entry: bit-identical.
+// kStop (measurement only): 1 / 4 = leave a row after that step (nothing but a row length is written; the real launch follows)
+template <int G, int kStop = 0>
 __global__ __launch_bounds__(64) void galerkin_merge_k(MatView A, const int *__restrict__ choice, const int *__restrict__ chooser, int64_t n_coarse,
-                                                       int cap /* power of two >= 2 * candidates */, int *__restrict__ row_len_c,
-                                                       const long long *__restrict__ slice_base, const int *__restrict__ intra_off, int *__restrict__ s_col,
-                                                       double *__restrict__ s_val, const int *__restrict__ list, const int *__restrict__ list_count) {
+                                                        int cap /* power of two >= 2 * candidates */, int *__restrict__ row_len_c,
+                                                        const long long *__restrict__ slice_base, const int *__restrict__ intra_off, int *__restrict__ s_col,
+                                                        double *__restrict__ s_val, const int *__restrict__ list, const int *__restrict__ list_count) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int kRows = 64 / G;  // coarse rows in flight per wavefront
     const int h = cap >> 1;
@@ -1098,33 +1107,70 @@ __global__ __launch_bounds__(64) void galerkin_merge_k(MatView A, const int *__r
     int *U = m_col + h;  // [cap] distinct coarse columns, unsorted
     const int n_fine = (int)A.P.n;
     const int64_t total_rows = list ? (int64_t)*list_count : n_coarse;
-    for (int64_t it0 = (int64_t)blockIdx.x * kRows; it0 < total_rows; it0 += (int64_t)gridDim.x * kRows) {
-        const int64_t it = it0 + grp;
-        const bool active = it < total_rows;  // the barriers below are reached by every group the same number of times
-        const int64_t I = active ? (list ? (int64_t)list[it] : it) : 0;
+    const int64_t it_step = (int64_t)gridDim.x * kRows;
+    // entry k of fine row i: the row-contiguous mirror where the matrix has one (RowWalk)
+    const bool mirror = A.rows.col != nullptr;
+    const int32_t *colp = mirror ? A.rows.col : A.P.col;
+    const double *valp = mirror ? A.rows.val : A.val;
+    const int64_t stride = mirror ? 1 : 64;
+    // this iteration's row, loaded one iteration ahead
+    int64_t it0 = (int64_t)blockIdx.x * kRows;
+    bool active = it0 + grp < total_rows;
+    int64_t I = active ? (list ? (int64_t)list[it0 + grp] : it0 + grp) : 0;
+    int pair0 = (active && 2 * I < n_fine) ? choice[2 * I] : -1;
+    int pair1 = (active && 2 * I + 1 < n_fine) ? choice[2 * I + 1] : -1;
+    for (; it0 < total_rows; it0 += it_step) {
+        // (the barriers below are reached by every group the same number of times)
+        const int64_t it_n = it0 + it_step + grp;
+        const bool active_n = it_n < total_rows;
+        const int64_t I_n = active_n ? (list ? (int64_t)list[it_n] : it_n) : 0;  // in flight during steps 1-3
         RRow R;
         R.n = 0;
-        if (active) R = restriction_row(choice, I, A.P.n);
+        if (active) R = restriction_row_from(I, pair0, pair1);
         // ---- 1. candidates, list after list (ghost columns dropped: coarse levels are per rank)
         int b1 = 0, b2 = 0, b3 = 0, b4 = 0;
         {
+            int len[4];
+            int64_t rb[4];
+            double sc1[4], sc2[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {  // descriptors of all fine rows at once
+                const bool on = a < R.n;
+                const int i = on ? R.idx[a] : 0;
+                len[a] = on ? A.P.row_len[i] : 0;
+                rb[a] = mirror ? (int64_t)A.rows.slice_base[i >> 6] + A.rows.intra_off[i] : A.P.slice_ptr[i >> 6] + (i & 63);
+                sc1[a] = A.s1 ? A.s1[i] : 1.;
+                sc2[a] = A.s2 ? A.s2[i] : 1.;
+            }
+            int c0[4];
+            double v0[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {  // their first G entries at once
+                const bool in = lane < len[a];
+                const int64_t pos = rb[a] + (int64_t)(in ? lane : 0) * stride;
+                c0[a] = in ? colp[pos] : -1;
+                v0[a] = in ? valp[pos] : 0.;
+            }
             int base = 0;
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
                 if (a < R.n) {
-                    const int i = R.idx[a];
                     const double w = R.w[a];
-                    const int len = A.P.row_len[i];
-                    const int64_t rb = A.P.slice_ptr[i >> 6] + (i & 63);
-                    for (int k0 = 0; k0 < len; k0 += G) {
+                    for (int k0 = 0; k0 < len[a]; k0 += G) {
                         const int k = k0 + lane;
                         int c = -1;
-                        int64_t pos = 0;
-                        if (k < len) { pos = rb + (int64_t)k * 64; c = A.P.col[pos]; }
+                        double v = 0.;
+                        if (k0 == 0) { c = c0[a]; v = v0[a]; }
+                        else if (k < len[a]) { const int64_t pos = rb[a] + (int64_t)k * stride; c = colp[pos]; v = valp[pos]; }
                         const int valid = (c >= 0 && c < n_fine) ? 1 : 0;
                         int tot;
                         const int slot = base + group_excl_scan<G>(valid, tot);
-                        if (valid) { src_col[slot] = c; src_val[slot] = w * view_value(A, i, pos); }
+                        if (valid) {
+                            if (A.s1) v = sc1[a] * v;  // view_value's order
+                            if (A.s2) v = sc2[a] * v;
+                            src_col[slot] = c;
+                            src_val[slot] = w * v;
+                        }
                         base += tot;
                     }
                 }
@@ -1136,6 +1182,7 @@ __global__ __launch_bounds__(64) void galerkin_merge_k(MatView A, const int *__r
         }
         const int cnt = b4;
         __syncthreads();
+        if (kStop == 1) { if (active && lane == 0) row_len_c[I] = cnt; __syncthreads(); active = active_n; I = I_n; pair0 = (active_n && 2 * I_n < n_fine) ? choice[2 * I_n] : -1; pair1 = (active_n && 2 * I_n + 1 < n_fine) ? choice[2 * I_n + 1] : -1; continue; }
         // ---- 2. merge: rank = own position + entries of earlier lists with column <= c + entries of later lists with column < c
         for (int e = lane; e < cnt; e += G) {
             const int a = (e >= b1) + (e >= b2) + (e >= b3);
@@ -1168,6 +1215,9 @@ __global__ __launch_bounds__(64) void galerkin_merge_k(MatView A, const int *__r
             cntT += tot;
         }
         __syncthreads();
+        // the next row's pairing (its index has arrived by now): in flight during steps 4-5
+        const int pair0_n = (active_n && 2 * I_n < n_fine) ? choice[2 * I_n] : -1;
+        const int pair1_n = (active_n && 2 * I_n + 1 < n_fine) ? choice[2 * I_n + 1] : -1;
         const int *tj = src_col;
         const double *tv = src_val;
         // ---- 4. the distinct coarse columns, first occurrence only
@@ -1214,6 +1264,7 @@ __global__ __launch_bounds__(64) void galerkin_merge_k(MatView A, const int *__r
             nU += tot;
         }
         __syncthreads();
+        if (kStop == 4) { if (active && lane == 0) row_len_c[I] = nU > 0 ? U[nU - 1] : 0; __syncthreads(); active = active_n; I = I_n; pair0 = pair0_n; pair1 = pair1_n; continue; }
         // ---- 5. every distinct J: position by counting, value from the <= 4 fine indices of row J of R (ascending)
         const long long off = active ? slice_base[I >> 6] + intra_off[I] : 0;
         for (int e = lane; e < nU; e += G) {
@@ -1234,6 +1285,7 @@ __global__ __launch_bounds__(64) void galerkin_merge_k(MatView A, const int *__r
         }
         if (active && lane == 0) row_len_c[I] = nU;
         __syncthreads();
+        active = active_n; I = I_n; pair0 = pair0_n; pair1 = pair1_n;
     }
 }
 
@@ -2068,7 +2120,9 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
     static std::once_flag attr_once;  // several lane threads reach this concurrently
     std::call_once(attr_once, [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&galerkin_wave_k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&galerkin_merge_k<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&galerkin_merge_k<64, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&galerkin_merge_k<64, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&galerkin_merge_k<64, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     // LDS tiers (32 B per list slot): every row was assigned to the narrowest list that is guaranteed to hold it
     if ((size_t)2 * max_cand > (size_t)(64 << (kGalerkinTiers - 1))) return set_error(ORC_ERR_BAD_ARGUMENT, "Galerkin row too long for LDS (%d candidates)", max_cand);
@@ -2078,13 +2132,23 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
         const int G = tier_group[t];  // narrow rows: two or four coarse rows per wavefront
         const int rows_per_wave = 64 / G;
         const size_t smem = (size_t)cap * 16 * (size_t)rows_per_wave;
-        static const int merge_waves = getenv("ORC_GALERKIN_WAVES") ? atoi(getenv("ORC_GALERKIN_WAVES")) : 16;
+        // 83-88 VGPRs: five wavefronts per SIMD are resident.  Measured (one stream, all tiers of six SIMPLE iterations): 16 per CU 407 ms,
+        // 20: 372 ms, 24: 410 ms (the launch no longer fits and its tail runs alone); round 2's kernel at 16: 438 ms
+        static const int merge_waves = getenv("ORC_GALERKIN_WAVES") ? atoi(getenv("ORC_GALERKIN_WAVES")) : 20;
         const int waves_per_cu = (int)std::max<size_t>(1, std::min<size_t>((size_t)merge_waves, (size_t)(150 * 1024) / smem));
         const int g = (int)std::min<int64_t>(((int64_t)htier[t] + rows_per_wave - 1) / rows_per_wave, (int64_t)256 * waves_per_cu);
         const int *tl = tier_list + (int64_t)t * nc, *tc = tier_count + t;
-        if (G == 16) hipLaunchKernelGGL(galerkin_merge_k<16>, dim3(g), dim3(64), smem, st, A, choice, chooser, nc, cap, row_len, slice_base, intra_off, s_col, s_val, tl, tc);
-        else if (G == 32) hipLaunchKernelGGL(galerkin_merge_k<32>, dim3(g), dim3(64), smem, st, A, choice, chooser, nc, cap, row_len, slice_base, intra_off, s_col, s_val, tl, tc);
-        else hipLaunchKernelGGL(galerkin_merge_k<64>, dim3(g), dim3(64), smem, st, A, choice, chooser, nc, cap, row_len, slice_base, intra_off, s_col, s_val, tl, tc);
+        static const bool stages = getenv("ORC_GALERKIN_STAGES") && atoi(getenv("ORC_GALERKIN_STAGES")) != 0;
+#define ORC_MERGE(GG, SS) hipLaunchKernelGGL(HIP_KERNEL_NAME(galerkin_merge_k<GG, SS>), dim3(g), dim3(64), smem, st, A, choice, chooser, nc, cap, row_len, slice_base, intra_off, s_col, s_val, tl, tc)
+        if (stages) {  // measurement: the kernel cut short after steps 1 and 4, then the real launch
+            if (G == 16) { ORC_MERGE(16, 1); ORC_MERGE(16, 4); }
+            else if (G == 32) { ORC_MERGE(32, 1); ORC_MERGE(32, 4); }
+            else { ORC_MERGE(64, 1); ORC_MERGE(64, 4); }
+        }
+        if (G == 16) ORC_MERGE(16, 0);
+        else if (G == 32) ORC_MERGE(32, 0);
+        else ORC_MERGE(64, 0);
+#undef ORC_MERGE
     }
     for (int t = 0; t < kGalerkinTiers && use_sort; ++t) {
         if (htier[t] == 0) continue;
