@@ -268,16 +268,21 @@ __global__ __launch_bounds__(kBlock) void agg_sweep_group_k(MatView A, int *__re
     if (changed) atomicAdd(&C->changed, changed);
 }
 
+// G lanes per row [r03]: a row's evaluation is a chain of dependent round trips (length -> start -> columns -> first takers), a
+// group walks its rows one after the other, and the launch is as large as the chip holds — so the time of a whole-level round is
+// (rows per group) x (trips per row), and narrower groups mean more rows in flight: 8 lanes on the levels of 7 and 15 entries per
+// row, 16 beyond — was the first guess; measured, 4 lanes are the fastest on every level (ORC_AMG_EVAL_GROUP overrides).
+template <int G>
 __global__ void tail_eval_k(MatView A, const int *__restrict__ choice, const int *__restrict__ taken_by, const int *__restrict__ list_a,
                             const int *__restrict__ list_b, TailCounters *T, int *__restrict__ flag, int *__restrict__ ch_row, int *__restrict__ ch_new) {
     if (T->finished) return;
     const int count = T->cur;
     const int *__restrict__ list = T->first ? nullptr : (T->parity ? list_b : list_a);
-    const int gl = threadIdx.x & (kG - 1);
-    const int64_t groups = ((int64_t)gridDim.x * blockDim.x) / kG;
-    for (int64_t idx = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kG; idx < count; idx += groups) {
+    const int gl = threadIdx.x & (G - 1);
+    const int64_t groups = ((int64_t)gridDim.x * blockDim.x) / G;
+    for (int64_t idx = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G; idx < count; idx += groups) {
         const int i = list ? list[idx] : (int)idx;
-        const int nv = group_eval_row(A, taken_by, i, gl);
+        const int nv = group_eval_row_g<G>(A, taken_by, i, gl);
         bool changed = false;
         if (gl == 0) {
             flag[i] = 0;
@@ -1860,9 +1865,12 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
             // lanes per slice by row length (host-known padded size / rows); 0 = one thread per slice (round 2, ORC_AMG_SWEEP_GROUP=0)
             static const int group_env = getenv("ORC_AMG_SWEEP_GROUP") ? atoi(getenv("ORC_AMG_SWEEP_GROUP")) : -1;
             const double avg = (A.P.padded > 0 && n > 0) ? (double)A.P.padded / (double)n : 0.;
-            const int G = group_env >= 0 ? group_env : (avg <= 0. ? 0 : (avg <= 10. ? 8 : (avg <= 22. ? 16 : 32)));
+            // (8 / 16 / 32 lanes by row length was the first choice: 103 ms over the sweeps of six iterations on one stream; 8 on every
+            // level: 90 ms; 4: 101 ms; 16: 98 ms — more slices in flight beat fewer passes per row)
+            const int G = group_env >= 0 ? group_env : (avg <= 0. ? 0 : 8);
             const int gg = grid_for((int64_t)A.P.n_slices * std::max(G, 1));
-            if (G == 8) hipLaunchKernelGGL(agg_sweep_group_k<8>, dim3(gg), dim3(kBlock), 0, st, A, choice, taken_by, cur, nxt, C, all_active);
+            if (G == 4) hipLaunchKernelGGL(agg_sweep_group_k<4>, dim3(gg), dim3(kBlock), 0, st, A, choice, taken_by, cur, nxt, C, all_active);
+            else if (G == 8) hipLaunchKernelGGL(agg_sweep_group_k<8>, dim3(gg), dim3(kBlock), 0, st, A, choice, taken_by, cur, nxt, C, all_active);
             else if (G == 16) hipLaunchKernelGGL(agg_sweep_group_k<16>, dim3(gg), dim3(kBlock), 0, st, A, choice, taken_by, cur, nxt, C, all_active);
             else if (G == 32) hipLaunchKernelGGL(agg_sweep_group_k<32>, dim3(gg), dim3(kBlock), 0, st, A, choice, taken_by, cur, nxt, C, all_active);
             else hipLaunchKernelGGL(agg_sweep_k, dim3(gs), dim3(64), 0, st, A, choice, taken_by, cur, nxt, C, all_active);
@@ -1908,6 +1916,16 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
         const int kBatch = small_enabled ? big_batch : 16;  // four-kernel rounds per host round trip; a round past the fixed point is a no-op
         bool first = true, fin = false;
         TailCounters h;
+        static const int eval_group_env = getenv("ORC_AMG_EVAL_GROUP") ? atoi(getenv("ORC_AMG_EVAL_GROUP")) : 0;
+        const double eval_avg = (A.P.padded > 0 && n > 0) ? (double)A.P.padded / (double)n : 0.;
+        (void)eval_avg;
+        const int eval_group = eval_group_env ? eval_group_env : 4;  // one stream, all levels of six iterations: 16 lanes 95 ms, 8: 67 ms, 4: 58 ms
+        auto launch_eval = [&](int ge) {
+            if (eval_group == 4) hipLaunchKernelGGL(tail_eval_k<4>, dim3(ge), dim3(kBlock), 0, st, A, choice, taken_by, (const int *)listA, (const int *)listB, T, flag, ch_row, ch_new);
+            else if (eval_group == 8) hipLaunchKernelGGL(tail_eval_k<8>, dim3(ge), dim3(kBlock), 0, st, A, choice, taken_by, (const int *)listA, (const int *)listB, T, flag, ch_row, ch_new);
+            else if (eval_group == 32) hipLaunchKernelGGL(tail_eval_k<32>, dim3(ge), dim3(kBlock), 0, st, A, choice, taken_by, (const int *)listA, (const int *)listB, T, flag, ch_row, ch_new);
+            else hipLaunchKernelGGL(tail_eval_k<16>, dim3(ge), dim3(kBlock), 0, st, A, choice, taken_by, (const int *)listA, (const int *)listB, T, flag, ch_row, ch_new);
+        };
         // (read per call, not cached: the tests run one process through the lock-step-only form, a starved cascade phase
         // that hands over to the lock-step rounds unfinished, and the default)
         const int chase_enabled = getenv("ORC_AMG_CHASE") ? atoi(getenv("ORC_AMG_CHASE")) : 1;
@@ -1923,7 +1941,7 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
             // one lock-step round over every row, the cascades it leaves followed asynchronously, then the lock-step rounds
             // again from scratch: they certify the fixed point (one round that changes nothing) or finish the job
             const int ge = g;
-            hipLaunchKernelGGL(tail_eval_k, dim3(ge), dim3(kBlock), 0, st, A, choice, taken_by, (const int *)listA, (const int *)listB, T, flag, ch_row, ch_new);
+            launch_eval(ge);
             hipLaunchKernelGGL(tail_commit_k, dim3(ge), dim3(kBlock), 0, st, choice, taken_by, T, ch_row, ch_new, ch_old, ch_t_old, ch_t_new);
             hipLaunchKernelGGL(tail_update_k, dim3(ge), dim3(kBlock), 0, st, A, choice, taken_by, T, ch_row, ch_new, ch_old, ch_t_old, ch_t_new, flag, listA, listB);
             hipLaunchKernelGGL(tail_rotate_k, dim3(1), dim3(1), 0, st, T);
@@ -1937,11 +1955,16 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
             lap("first lock-step round");
             // lanes per cascade: the narrowest group that covers a typical row in one pass
             const int group_env = getenv("ORC_AMG_CHASE_GROUP") ? atoi(getenv("ORC_AMG_CHASE_GROUP")) : 0;
-            int64_t stored = 0;  // padded entries: an upper bound of the mean row length is all that is needed
-            ORC_HIP(hipMemcpyAsync(&stored, A.P.slice_ptr + A.P.n_slices, sizeof(int64_t), hipMemcpyDeviceToHost, st));
-            ORC_HIP(hipStreamSynchronize(st));
-            const double avg_len = n > 0 ? (double)stored / (double)n : 0.;
-            const int group = group_env ? group_env : (avg_len <= 14. ? 16 : (avg_len <= 28. ? 32 : 64));
+            // (r02: 16 / 32 / 64 by row length, one pass per row = ORC_AMG_CHASE_GROUP=-1.  All cascades of six iterations on one stream:
+            // that choice 494 ms, 16 lanes on every level 477 ms, 32: 526 ms, 8: 554 ms)
+            int group = group_env > 0 ? group_env : 16;
+            if (group_env < 0) {
+                int64_t stored = 0;  // padded entries: an upper bound of the mean row length is all that is needed
+                ORC_HIP(hipMemcpyAsync(&stored, A.P.slice_ptr + A.P.n_slices, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+                ORC_HIP(hipStreamSynchronize(st));
+                const double avg_len = n > 0 ? (double)stored / (double)n : 0.;
+                group = avg_len <= 14. ? 16 : (avg_len <= 28. ? 32 : 64);
+            }
             int launches = 0, first_list = -1;
             for (;;) {
                 for (int b = 0; b < chase_batch; ++b) {
@@ -1985,7 +2008,7 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
             for (int b = 0; b < batch; ++b) {
                 static const int tail_grid = getenv("ORC_AMG_TAIL_GRID") ? atoi(getenv("ORC_AMG_TAIL_GRID")) : 1024;
                 const int ge = first ? g : tail_grid;
-                hipLaunchKernelGGL(tail_eval_k, dim3(ge), dim3(kBlock), 0, st, A, choice, taken_by, (const int *)listA, (const int *)listB, T, flag, ch_row, ch_new);
+                launch_eval(ge);
                 hipLaunchKernelGGL(tail_commit_k, dim3(ge), dim3(kBlock), 0, st, choice, taken_by, T, ch_row, ch_new, ch_old, ch_t_old, ch_t_new);
                 hipLaunchKernelGGL(tail_update_k, dim3(ge), dim3(kBlock), 0, st, A, choice, taken_by, T, ch_row, ch_new, ch_old, ch_t_old, ch_t_new, flag, listA, listB);
                 hipLaunchKernelGGL(tail_rotate_k, dim3(1), dim3(1), 0, st, T);
