@@ -1863,7 +1863,7 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
             hipLaunchKernelGGL(agg_reset_k, dim3(g), dim3(kBlock), 0, st, taken_by, n);
             hipLaunchKernelGGL(agg_scatter_k, dim3(g), dim3(kBlock), 0, st, choice, taken_by, n);
             // lanes per slice by row length (host-known padded size / rows); 0 = one thread per slice (round 2, ORC_AMG_SWEEP_GROUP=0)
-            static const int group_env = getenv("ORC_AMG_SWEEP_GROUP") ? atoi(getenv("ORC_AMG_SWEEP_GROUP")) : -1;
+            const int group_env = getenv("ORC_AMG_SWEEP_GROUP") ? atoi(getenv("ORC_AMG_SWEEP_GROUP")) : -1;  // (per call: the forms test switches it)
             const double avg = (A.P.padded > 0 && n > 0) ? (double)A.P.padded / (double)n : 0.;
             // (8 / 16 / 32 lanes by row length was the first choice: 103 ms over the sweeps of six iterations on one stream; 8 on every
             // level: 90 ms; 4: 101 ms; 16: 98 ms — more slices in flight beat fewer passes per row)
@@ -1916,7 +1916,7 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
         const int kBatch = small_enabled ? big_batch : 16;  // four-kernel rounds per host round trip; a round past the fixed point is a no-op
         bool first = true, fin = false;
         TailCounters h;
-        static const int eval_group_env = getenv("ORC_AMG_EVAL_GROUP") ? atoi(getenv("ORC_AMG_EVAL_GROUP")) : 0;
+        const int eval_group_env = getenv("ORC_AMG_EVAL_GROUP") ? atoi(getenv("ORC_AMG_EVAL_GROUP")) : 0;  // (per call: the forms test switches it)
         const double eval_avg = (A.P.padded > 0 && n > 0) ? (double)A.P.padded / (double)n : 0.;
         (void)eval_avg;
         const int eval_group = eval_group_env ? eval_group_env : 4;  // one stream, all levels of six iterations: 16 lanes 95 ms, 8: 67 ms, 4: 58 ms

@@ -53,12 +53,16 @@ def test_aggregation_and_galerkin_bit_exact(gpu, oracle, shape):
 @pytest.mark.parametrize("env", [{"ORC_AMG_CHASE": "0"}, {"ORC_AMG_CHASE_STEPS": "2", "ORC_AMG_CHASE_LAUNCHES": "2"},
                                  {"ORC_AMG_CHASE_GROUP": "16"}, {"ORC_AMG_CHASE_GROUP": "64", "ORC_AMG_CHASE_GRID": "8"},
                                  {"ORC_AMG_CHASE_STEPS": "1", "ORC_AMG_CHASE_GRID": "8", "ORC_AMG_CHASE_LAUNCHES": "100000"},
-                                 {"ORC_GALERKIN_SORT": "1"}, {"ORC_GALERKIN_GROUPS": "64,64,64,64"}, {"ORC_GALERKIN_GROUPS": "16,16,16,32"}])
+                                 {"ORC_GALERKIN_SORT": "1"}, {"ORC_GALERKIN_GROUPS": "64,64,64,64"}, {"ORC_GALERKIN_GROUPS": "16,16,16,32"},
+                                 {"ORC_AMG_EVAL_GROUP": "16", "ORC_AMG_SWEEP_GROUP": "32"}, {"ORC_AMG_EVAL_GROUP": "8", "ORC_AMG_SWEEP_GROUP": "0"},
+                                 {"ORC_AMG_CHASE_GROUP": "-1", "ORC_AMG_SWEEP_GROUP": "4"}])
 def test_set_up_forms_agree(gpu, monkeypatch, env):
     """Every form of the set-up lands on the same pairing and the same coarse operator, bit for bit: lock-step rounds only;
     a cascade phase cut off after two steps and two launches (the lock-step rounds finish the job); cascades followed by
     16- and by 64-lane groups on a tiny grid; one step per wavefront and launch on a tiny grid (every launch carries
-    unclaimed rows and continuations over to the next); the Galerkin product by sorting and by merging with every group size."""
+    unclaimed rows and continuations over to the next); the Galerkin product by sorting and by merging with every group size;
+    the lock-step evaluation with 16 and 8 lanes per row (default 4), the slice sweeps with 32, 4 and one lane per slice (default
+    8), cascade groups chosen by row length as in round 2 (default 16)."""
     from orc_amd.linear_algebra import amg_coarsen
     results = []
     for form in ({}, env):
