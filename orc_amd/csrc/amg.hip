@@ -1409,26 +1409,38 @@ __global__ __launch_bounds__(64) void galerkin_bound_k(SellDev P, const int *__r
 }
 
 // exclusive scan of n int64 values by one workgroup (n = number of slices: tens of thousands)
-__global__ __launch_bounds__(1024) void scan_i64_k(const long long *__restrict__ in, int64_t n, long long *__restrict__ out) {
-    __shared__ long long carry;
-    __shared__ long long buf[1024];
-    if (threadIdx.x == 0) carry = 0;
+// [r03] every thread owns a contiguous share: it sums it, the workgroup's sums are scanned in LDS, it writes its share's running
+// sums — three round trips of independent loads instead of one per 1024-element chunk behind twenty barriers (80 chunks at 5 M
+// coarse rows).  And 256 threads, not 1024: beside the products of another stream a 16-wavefront workgroup waits for a CU with
+// four free slots on every SIMD (100 us alone, 0.6-1.2 ms in the concurrent schedule, most of it before its first instruction).
+constexpr int kScanThreads = 256;
+__device__ __forceinline__ long long block_excl_scan(long long v, long long *buf /*[kScanThreads]*/, long long &total) {
+    const int t = threadIdx.x;
+    buf[t] = v;
     __syncthreads();
-    for (int64_t base = 0; base < n; base += 1024) {
-        const int64_t e = base + threadIdx.x;
-        const long long v = e < n ? in[e] : 0;
-        buf[threadIdx.x] = v;
+    for (int off = 1; off < kScanThreads; off <<= 1) {
+        const long long x = t >= off ? buf[t - off] : 0;
         __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {
-            const long long t = threadIdx.x >= off ? buf[threadIdx.x - off] : 0;
-            __syncthreads();
-            buf[threadIdx.x] += t;
-            __syncthreads();
-        }
-        if (e < n) out[e] = carry + buf[threadIdx.x] - v;
+        buf[t] += x;
         __syncthreads();
-        if (threadIdx.x == 1023) carry += buf[1023];
-        __syncthreads();
+    }
+    total = buf[kScanThreads - 1];
+    const long long r = buf[t] - v;
+    __syncthreads();
+    return r;
+}
+__global__ __launch_bounds__(kScanThreads) void scan_i64_k(const long long *__restrict__ in, int64_t n, long long *__restrict__ out) {
+    __shared__ long long buf[kScanThreads];
+    const int64_t per = (n + kScanThreads - 1) / kScanThreads;
+    const int64_t lo = std::min<int64_t>(n, (int64_t)threadIdx.x * per), hi = std::min<int64_t>(n, lo + per);
+    long long s = 0;
+    for (int64_t e = lo; e < hi; ++e) s += in[e];
+    long long total;
+    long long run = block_excl_scan(s, buf, total);
+    for (int64_t e = lo; e < hi; ++e) {
+        const long long v = in[e];
+        out[e] = run;
+        run += v;
     }
 }
 
@@ -1452,33 +1464,25 @@ __global__ __launch_bounds__(kBlock) void slice_sizes_k(const int *__restrict__ 
         if (lane == 0) { w_sell[s] = (int64_t)mx * 64; w_pk[s] = ((int64_t)sum + 15) & ~(int64_t)15; }
     }
 }
-// exclusive scans of two tables at once, totals in out[n]; wave shuffles inside a 1024-element tile, one LDS hop across waves
-__global__ __launch_bounds__(1024) void scan2_i64_k(const int64_t *__restrict__ in_a, const int64_t *__restrict__ in_b, int n, int64_t *__restrict__ out_a,
+// exclusive scans of two tables at once, totals in out[n]; contiguous shares per thread as in scan_i64_k
+__global__ __launch_bounds__(kScanThreads) void scan2_i64_k(const int64_t *__restrict__ in_a, const int64_t *__restrict__ in_b, int n, int64_t *__restrict__ out_a,
                                                     int64_t *__restrict__ out_b) {
-    __shared__ long long wave_tot[2][16];
-    __shared__ long long carry[2];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (threadIdx.x < 2) carry[threadIdx.x] = 0;
-    __syncthreads();
-    for (int base = 0; base < n; base += 1024) {
-        const int e = base + threadIdx.x;
-        const long long va = e < n ? (long long)in_a[e] : 0, vb = e < n ? (long long)in_b[e] : 0;
-        long long xa = va, xb = vb;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const long long ya = __shfl_up(xa, off, 64), yb = __shfl_up(xb, off, 64);
-            if (lane >= off) { xa += ya; xb += yb; }
-        }
-        if (lane == 63) { wave_tot[0][w] = xa; wave_tot[1][w] = xb; }
-        __syncthreads();
-        long long pa = carry[0], pb = carry[1];
-        for (int q = 0; q < w; ++q) { pa += wave_tot[0][q]; pb += wave_tot[1][q]; }
-        if (e < n) { out_a[e] = (int64_t)(pa + xa - va); out_b[e] = (int64_t)(pb + xb - vb); }
-        __syncthreads();
-        if (threadIdx.x == 1023) { carry[0] = pa + xa; carry[1] = pb + xb; }
-        __syncthreads();
+    __shared__ long long buf[kScanThreads];
+    const int per = (n + kScanThreads - 1) / kScanThreads;
+    const int lo = min(n, (int)threadIdx.x * per), hi = min(n, lo + per);
+    long long sa = 0, sb = 0;
+    for (int e = lo; e < hi; ++e) { sa += (long long)in_a[e]; sb += (long long)in_b[e]; }
+    long long ta, tb;
+    long long ra = block_excl_scan(sa, buf, ta);
+    long long rb = block_excl_scan(sb, buf, tb);
+    for (int e = lo; e < hi; ++e) {
+        const long long va = (long long)in_a[e], vb = (long long)in_b[e];
+        out_a[e] = (int64_t)ra;
+        out_b[e] = (int64_t)rb;
+        ra += va;
+        rb += vb;
     }
-    if (threadIdx.x == 0) { out_a[n] = (int64_t)carry[0]; out_b[n] = (int64_t)carry[1]; }
+    if (threadIdx.x == 0) { out_a[n] = (int64_t)ta; out_b[n] = (int64_t)tb; }
 }
 
 // ---- packed mirror of the coarse operator (PackedDev, linalg.hpp): what the level's ~200 products stream
@@ -2125,7 +2129,7 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
     ORC_HIP(hipMemsetAsync(tier_count, 0, (kGalerkinTiers + 1) * sizeof(int), st));
     hipLaunchKernelGGL(galerkin_bound_k, dim3((unsigned)std::min<int64_t>(n_slices, 8192)), dim3(64), 0, st, A.P, choice, nc, flags, counters + 1, intra_off,
                        slice_tot, tier_count, tier_list, use_sort ? 1 : 0);
-    hipLaunchKernelGGL(scan_i64_k, dim3(1), dim3(1024), 0, st, slice_tot, (int64_t)n_slices, slice_base);
+    hipLaunchKernelGGL(scan_i64_k, dim3(1), dim3(kScanThreads), 0, st, slice_tot, (int64_t)n_slices, slice_base);
     int hflags[4];
     unsigned long long hcount[2];
     ORC_HIP(hipMemcpyAsync(hflags, flags, sizeof(hflags), hipMemcpyDeviceToHost, st));
@@ -2188,7 +2192,7 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
     ORC_TRY(tmp.alloc((size_t)n_slices + 1, &w_sell));
     ORC_TRY(tmp.alloc((size_t)n_slices + 1, &w_pk));
     hipLaunchKernelGGL(slice_sizes_k, dim3((unsigned)std::min<int64_t>(((int64_t)n_slices + 3) / 4, 4096)), dim3(kBlock), 0, st, row_len, nc, n_slices, w_sell, w_pk);
-    hipLaunchKernelGGL(scan2_i64_k, dim3(1), dim3(1024), 0, st, (const int64_t *)w_sell, (const int64_t *)w_pk, n_slices, slice_ptr, pk_ptr);
+    hipLaunchKernelGGL(scan2_i64_k, dim3(1), dim3(kScanThreads), 0, st, (const int64_t *)w_sell, (const int64_t *)w_pk, n_slices, slice_ptr, pk_ptr);
     ORC_HIP(hipGetLastError());
     int64_t padded = 0, packed_total = 0;
     ORC_HIP(hipMemcpyAsync(&packed_total, pk_ptr + n_slices, sizeof(int64_t), hipMemcpyDeviceToHost, st));
