@@ -11,6 +11,22 @@ __device__ __forceinline__ double view_value(const MatView &A, int64_t row, int6
     return v;
 }
 
+// The matrix streams of a product (values, columns, window positions) are read once per launch and are many times the size of
+// the caches: loaded with the non-temporal hint they leave L2 and the Infinity Cache to the vectors.  Measured on the level-0
+// shape (scripts/microbench/stream_floor.hip, 10.24 M rows): plain read 5.2 -> 5.6-6.0 TB/s, value stream 5.05 -> 5.54 TB/s, the
+// whole product 215 -> 194 us.  ORC_MATRIX_LOADS_NT=0 at build time restores ordinary loads.
+#ifndef ORC_MATRIX_LOADS_NT
+#define ORC_MATRIX_LOADS_NT 1
+#endif
+template <class T>
+__device__ __forceinline__ T ld_stream(const T *p) {
+#if ORC_MATRIX_LOADS_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+
 // XCD-aware slice walk: workgroups b and b+8 share an XCD (MI355X_MICROARCH "Workgroup dispatch"),
 // so XCD g = blockIdx%8 sweeps the contiguous slice range [g*spx, (g+1)*spx): the x-vector
 // window a row block needs (i+-1, i+-nx, i+-nx*ny) then stays inside one XCD's 4 MiB L2 instead
@@ -174,8 +190,8 @@ __global__ __launch_bounds__(kBlock) void spmv_uniform_k(MatView A, const double
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const bool in = k0 + u < width;
-                    c[u] = in ? cb[k0 + u] + (int)A.P.col16[p0 + (int64_t)u * 64] : 0;
-                    v[u] = in ? A.val[p0 + (int64_t)u * 64] : 0.;
+                    c[u] = in ? cb[k0 + u] + (int)ld_stream(A.P.col16 + p0 + (int64_t)u * 64) : 0;
+                    v[u] = in ? ld_stream(A.val + p0 + (int64_t)u * 64) : 0.;
                 }
             } else {
 #pragma unroll
@@ -183,8 +199,8 @@ __global__ __launch_bounds__(kBlock) void spmv_uniform_k(MatView A, const double
                 // kRagged (coarse AMG levels, 11-49 % padding): padding slots are not fetched, so a cache line whose lanes
                 // are all past their rows' ends stays in HBM; otherwise the loads stay wave-uniform (cheaper to issue)
                 const bool in = k0 + u < (kRagged ? len : width);
-                c[u] = in ? A.P.col[p0 + (int64_t)u * 64] : 0;
-                v[u] = in ? A.val[p0 + (int64_t)u * 64] : 0.;
+                c[u] = in ? ld_stream(A.P.col + p0 + (int64_t)u * 64) : 0;
+                v[u] = in ? ld_stream(A.val + p0 + (int64_t)u * 64) : 0.;
             }
             }
 #pragma unroll
@@ -247,11 +263,11 @@ __global__ __launch_bounds__(kBlock) void spmv3_uniform_k(MatView3 A, const doub
 #pragma unroll
             for (int u = 0; u < kChunk; ++u) {  // wave-uniform matrix loads at compile-time offsets from one chunk base
                 const bool in = k0 + u < width;
-                if (kNarrow) c[u] = in ? cb[k0 + u] + (int)A.P.col16[p0 + (int64_t)u * 64] : 0;
-                else c[u] = in ? A.P.col[p0 + (int64_t)u * 64] : 0;
-                v0[u] = in ? A.val[0][p0 + (int64_t)u * 64] : 0.;
-                v1[u] = in ? A.val[1][p0 + (int64_t)u * 64] : 0.;
-                v2[u] = in ? A.val[2][p0 + (int64_t)u * 64] : 0.;
+                if (kNarrow) c[u] = in ? cb[k0 + u] + (int)ld_stream(A.P.col16 + p0 + (int64_t)u * 64) : 0;
+                else c[u] = in ? ld_stream(A.P.col + p0 + (int64_t)u * 64) : 0;
+                v0[u] = in ? ld_stream(A.val[0] + p0 + (int64_t)u * 64) : 0.;
+                v1[u] = in ? ld_stream(A.val[1] + p0 + (int64_t)u * 64) : 0.;
+                v2[u] = in ? ld_stream(A.val[2] + p0 + (int64_t)u * 64) : 0.;
             }
 #pragma unroll
             for (int u = 0; u < kChunk; ++u) {
@@ -451,8 +467,8 @@ __global__ __launch_bounds__(kBlock) void spmv_xwin_k(MatView A, const double *_
                 const unsigned long long m = __ballot(in);
                 const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
                 const int p = in ? off32 + rank : (m != 0ull ? off32 : off32 - 1);
-                cc[u] = (int)s_lidx[p];
-                vv[u] = s_val[p];
+                cc[u] = (int)ld_stream(s_lidx + p);
+                vv[u] = ld_stream(s_val + p);
                 off32 += __popcll(m);
             }
         };
@@ -467,7 +483,7 @@ __global__ __launch_bounds__(kBlock) void spmv_xwin_k(MatView A, const double *_
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const int j = j0 + q * kBlock + (int)threadIdx.x;
-                    wj[q] = wc[j < ws ? j : 0];
+                    wj[q] = ld_stream(wc + (j < ws ? j : 0));
                 }
 #pragma unroll
                 for (int q = 0; q < 8; ++q) xw[q] = x[wj[q]];
@@ -516,8 +532,8 @@ __global__ __launch_bounds__(kBlock) void spmv_xwin_k(MatView A, const double *_
                         const unsigned long long m = __ballot(in);
                         const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
                         const int64_t p = in ? pk_off + rank : (m != 0ull ? pk_off : pk_off - 1);
-                        cg[u] = A.pk.col[p];
-                        vg[u] = A.pk.val[p];
+                        cg[u] = ld_stream(A.pk.col + p);
+                        vg[u] = ld_stream(A.pk.val + p);
                         pk_off += __popcll(m);
                     }
 #pragma unroll
