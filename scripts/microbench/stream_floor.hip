@@ -58,6 +58,48 @@ __global__ __launch_bounds__(256) void product(const double *__restrict__ val, c
     }
 }
 
+// three systems on one pattern: three value streams, one column stream, interleaved x (24 bytes per column), CHUNK entries per pass
+struct __attribute__((aligned(8))) V3 { double a, b, c; };
+template <int CHUNK, bool NT, bool NTX>
+__global__ __launch_bounds__(256) void product3(const double *__restrict__ v0p, const double *__restrict__ v1p, const double *__restrict__ v2p,
+                                                const unsigned short *__restrict__ col16, const int *__restrict__ colbase, const double *__restrict__ x3,
+                                                double *__restrict__ y3, int n_slices, int64_t n) {
+    const int lane = threadIdx.x & 63;
+    const int waves = (gridDim.x * blockDim.x) >> 6;
+    const int xcd = blockIdx.x & 7, wg_in_xcd = blockIdx.x >> 3, waves_per_xcd = waves >> 3;
+    const int per = (n_slices + 7) / 8;
+    const int begin = xcd * per + wg_in_xcd * 4 + (threadIdx.x >> 6), end = min(n_slices, (xcd + 1) * per);
+    const V3 *xv3 = reinterpret_cast<const V3 *>(x3);
+    for (int s = begin; s < end; s += waves_per_xcd) {
+        double a0 = 0., a1 = 0., a2 = 0.;
+        for (int k0 = 0; k0 < kW; k0 += CHUNK) {
+            int c[CHUNK];
+            double v0[CHUNK], v1[CHUNK], v2[CHUNK];
+            V3 xv[CHUNK];
+            const int64_t base = ((int64_t)s * kW + k0) * 64 + lane;
+#pragma unroll
+            for (int u = 0; u < CHUNK; ++u) {
+                const bool in = k0 + u < kW;
+                c[u] = in ? colbase[s * kW + k0 + u] + (int)(NT ? __builtin_nontemporal_load(col16 + base + u * 64) : col16[base + u * 64]) : 0;
+                v0[u] = in ? (NT ? __builtin_nontemporal_load(v0p + base + u * 64) : v0p[base + u * 64]) : 0.;
+                v1[u] = in ? (NT ? __builtin_nontemporal_load(v1p + base + u * 64) : v1p[base + u * 64]) : 0.;
+                v2[u] = in ? (NT ? __builtin_nontemporal_load(v2p + base + u * 64) : v2p[base + u * 64]) : 0.;
+            }
+#pragma unroll
+            for (int u = 0; u < CHUNK; ++u) xv[u] = xv3[c[u]];
+#pragma unroll
+            for (int u = 0; u < CHUNK; ++u) {
+                if (k0 + u < kW) { a0 = a0 + v0[u] * xv[u].a; a1 = a1 + v1[u] * xv[u].b; a2 = a2 + v2[u] * xv[u].c; }
+            }
+        }
+        const int64_t row = (int64_t)s * 64 + lane;
+        if (row < n) {
+            if (NTX) { __builtin_nontemporal_store(a0, y3 + 3 * row); __builtin_nontemporal_store(a1, y3 + 3 * row + 1); __builtin_nontemporal_store(a2, y3 + 3 * row + 2); }
+            else { y3[3 * row] = a0; y3[3 * row + 1] = a1; y3[3 * row + 2] = a2; }
+        }
+    }
+}
+
 // plain read of `bytes` (16 bytes per lane and instruction, eight in flight), grid-stride
 template <bool NT>
 __global__ __launch_bounds__(256) void plain_read(const double2 *__restrict__ p, int64_t n16, double *out) {
@@ -167,7 +209,24 @@ int main(int argc, char **argv) {
         RUNNT(3, 1, "product (non-temporal matrix), 1 in flight", b3);
         RUNNT(3, 2, "product (non-temporal matrix), 2 in flight", b3);
     }
-    for (int wgs : {8, 16, 32}) {
+    {
+        double *v1, *v2, *x3, *y3;
+        CK(hipMalloc(&v1, padded * 8)); CK(hipMalloc(&v2, padded * 8)); CK(hipMalloc(&x3, (size_t)n_slices * 64 * 24)); CK(hipMalloc(&y3, (size_t)n_slices * 64 * 24));
+        CK(hipMemcpy(v1, val, padded * 8, hipMemcpyDeviceToDevice)); CK(hipMemcpy(v2, val, padded * 8, hipMemcpyDeviceToDevice));
+        CK(hipMemset(x3, 0, (size_t)n_slices * 64 * 24));
+        const double b = 3. * padded * 8. + padded * 2. + n_slices * kW * 4. + 2. * n * 24.;
+        for (int wgs : {4, 5, 8}) {
+            const int grid = 256 * wgs;
+            printf("-- three systems, %d workgroups per CU\n", wgs);
+#define RUN3(C, NT, NTX, label) report(label, time_ms([&] { hipLaunchKernelGGL((product3<C, NT, NTX>), dim3(grid), dim3(256), 0, 0, val, v1, v2, c16, base, x3, y3, n_slices, n); }, 20), b)
+            RUN3(4, false, false, "three systems, chunks of 4");
+            RUN3(4, true, false, "three systems, chunks of 4, non-temporal matrix");
+            RUN3(4, true, true, "three systems, chunks of 4, nt matrix + nt y");
+            RUN3(2, true, false, "three systems, chunks of 2, non-temporal matrix");
+            RUN3(8, true, false, "three systems, chunks of 8, non-temporal matrix");
+        }
+    }
+    for (int wgs : {8, 32}) {
         const double bytes = padded * 8.;
         char name[64];
         snprintf(name, sizeof name, "plain read of the values, %d workgroups per CU", wgs);
