@@ -277,7 +277,7 @@ def main():
     # --pmc passes: scripts/gpu_pmc_r02.sh; equal to FETCH_SIZE x 2 + WRITE_SIZE of MI355X_MICROARCH.md §HBM for this
     # kernel): bench.py cannot collect counters itself, so it quotes the committed profile of the same kernel on the same
     # matrix when one exists, else null.
-    variant = getattr(solver, "inloop_variant", "false, true")  # "<narrow columns>, <scaled on the fly>" as launched
+    variant = getattr(solver, "inloop_variant", "false, true, false")  # "<narrow columns>, <scaled on the fly>, <non-temporal matrix loads>" as launched
     KERNEL = "spmv_uniform_k<EpiStoreSum, false, true, %s> / <EpiTs, false, true, %s>" % (variant, variant)
     traffic, traffic_source = None, None
     try:

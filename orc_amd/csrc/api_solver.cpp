@@ -556,7 +556,7 @@ int orc_bench_spmv(OrcSolver *s, int reps, double *avg_ms, double *checksum) {
 // solve run); avg_ms[2], [3]: spmv3_uniform_k<EpiStoreSum3, 4, true>, <EpiTs3, 4, true> (u, v, w in one launch).
 // the template arguments the two launches above are made with, as rocprofv3 prints them: "<narrow>, <scaled>" of
 // spmv_uniform_k<Epi, false, true, narrow, scaled> (and of spmv3_uniform_k<Epi3, 4, true, narrow, scaled>)
-static char g_inloop_variant[32] = "false, true";
+static char g_inloop_variant[32] = "false, true, false";
 const char *orc_bench_inloop_variant(void) { return g_inloop_variant; }
 
 int orc_bench_inloop_products(OrcSolver *s, int reps, double avg_ms[4]) {
@@ -583,7 +583,11 @@ int orc_bench_inloop_products(OrcSolver *s, int reps, double avg_ms[4]) {
         A.s2 = d2;
     }
     ORC_TRY(materialize_scaled_view(A, t.settings.iterations, t.arena));  // as a smoothing solve of the configured length does
-    snprintf(g_inloop_variant, sizeof(g_inloop_variant), "%s, %s", A.P.col16 ? "true" : "false", (A.s1 || A.s2) ? "true" : "false");
+    {  // narrow columns, scalings on the fly, non-temporal matrix loads: the last three template arguments of the kernels just timed
+        const bool narrow = A.P.col16 != nullptr, scaled = A.s1 || A.s2;
+        snprintf(g_inloop_variant, sizeof(g_inloop_variant), "%s, %s, %s", narrow ? "true" : "false", scaled ? "true" : "false",
+                 (narrow && !scaled && matview_stream_nt(A)) ? "true" : "false");
+    }
     float ms[2];
     ORC_TRY(bench_inloop_products_dev(A, t.u.p, y, partials, reps, ms));
     avg_ms[0] = ms[0]; avg_ms[1] = ms[1];

@@ -129,6 +129,17 @@ long long debug_xsort_products() { return g_xsort_products.load(std::memory_orde
 
 static inline bool reference_order(const MatView &A) { return ctx().reduction_order == ORC_REDUCTION_REFERENCE && A.halo == nullptr; }
 
+// Non-temporal matrix loads pay where the matrix streams through the caches (10.24 M cells: ~1 GB per product; in-loop level-0
+// product 198 -> 178 us) and cost where it lives in the 256 MB Infinity Cache (1.03 M cells, 62 MB: 0.65 -> 0.60 of peak).
+// ORC_SPMV_NT=0 / 1 forces the policy.
+static inline int stream_nt(int64_t stream_bytes) {
+    static const int forced = getenv("ORC_SPMV_NT") ? atoi(getenv("ORC_SPMV_NT")) : -1;
+    if (forced >= 0) return forced != 0;
+    return stream_bytes > ((int64_t)128 << 20);
+}
+
+int matview_stream_nt(const MatView &A) { return stream_nt(A.pk.ptr && A.xw.lidx ? A.pk.total * 10 : A.P.padded * (A.P.col16 ? 10 : 12)); }
+
 static inline int spmv_grid(int32_t n_slices) {
     int64_t g = ((int64_t)n_slices + 3) / 4;  // 4 waves (slices) per workgroup
     // ORC_SPMV_GRID (measurement): fewer resident workgroups per CU leave wave slots to the set-up kernels of other streams
@@ -327,7 +338,9 @@ struct EpiTs {  // t = A s ; partials t.s, t.t            (linear_algebra.rs:260
 };
 
 template <class Epi>
-static int launch_spmv(const MatView &A, const double *x, const Epi &epi, double *partials, int *grid_out, const double *skip_flags = nullptr) {
+static int launch_spmv(const MatView &A_in, const double *x, const Epi &epi, double *partials, int *grid_out, const double *skip_flags = nullptr) {
+    MatView A = A_in;
+    A.nt = matview_stream_nt(A);
     int g = spmv_grid(A.P.n_slices);
     const int variant = ctx().spmv_variant;  // measurement hook (orc_debug_set_spmv_variant); 0 in production
     const bool xwin = A.xw.lidx != nullptr && A.pk.ptr != nullptr && (variant == 0 || (variant >= 20 && variant <= 22));
@@ -406,6 +419,7 @@ static int launch_spmv(const MatView &A, const double *x, const Epi &epi, double
         else if (A.xs.val && variant == 0 && !A.s1 && !A.s2) { hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_xsort_k<Epi, false>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags); g_xsort_products.fetch_add(1, std::memory_order_relaxed); }
         else if (A.xs.val && variant == 0) { hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_xsort_k<Epi, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags); g_xsort_products.fetch_add(1, std::memory_order_relaxed); }
         else if (!A.s1 && !A.s2 && xwin_early) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_xwin_k<Epi, 3, false>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
+        else if (!A.s1 && !A.s2 && A.nt) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_xwin_k<Epi, 0, false, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
         else if (!A.s1 && !A.s2) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_xwin_k<Epi, 0, false>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_xwin_k<Epi>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
         ORC_HIP(hipGetLastError());
@@ -433,14 +447,16 @@ static int launch_spmv(const MatView &A, const double *x, const Epi &epi, double
         hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi, kSpmvRagged>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
     else if (A.persistent_pattern) {  // mesh-pattern matrices (level 0): wave-uniform loads, predicated gathers
         const bool narrow = A.P.col16 != nullptr, scaled = A.s1 || A.s2;
-        if (narrow && !scaled) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_uniform_k<Epi, false, true, true, false>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
+        if (narrow && !scaled && A.nt) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_uniform_k<Epi, false, true, true, false, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
+        else if (narrow && !scaled) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_uniform_k<Epi, false, true, true, false>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
         else if (narrow) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_uniform_k<Epi, false, true, true, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
         else if (!scaled) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_uniform_k<Epi, false, true, false, false>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_uniform_k<Epi, false, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
     }
-    else if (!(A.s1 || A.s2) && A.P.col16)  // first coarse level, scaled values materialised, narrow column image
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_uniform_k<Epi, false, false, true, false>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
-    else if (!(A.s1 || A.s2))  // short ragged rows (first coarse level): the same kernel under its own name; scaled values materialised
+    else if (!(A.s1 || A.s2) && A.P.col16) {  // first coarse level, scaled values materialised, narrow column image
+        if (A.nt) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_uniform_k<Epi, false, false, true, false, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_uniform_k<Epi, false, false, true, false>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
+    } else if (!(A.s1 || A.s2))  // short ragged rows (first coarse level): the same kernel under its own name; scaled values materialised
         hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_uniform_k<Epi, false, false, false, false>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_uniform_k<Epi, false>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
@@ -925,7 +941,9 @@ struct EpiTs3 {
 };
 
 template <class Epi3>
-static int launch_spmv3(const MatView3 &A, const double *x3, const Epi3 &epi, double *partials, int *grid_out) {
+static int launch_spmv3(const MatView3 &A_in, const double *x3, const Epi3 &epi, double *partials, int *grid_out) {
+    MatView3 A = A_in;
+    A.nt = stream_nt(A.P.padded * (A.P.col16 ? 26 : 28));
     const int g = spmv_grid(A.P.n_slices);  // the one-system grid: same walk, same partial sums
     if (grid_out) *grid_out = g;
     if (A.P.n == 0) return ORC_OK;
@@ -934,11 +952,13 @@ static int launch_spmv3(const MatView3 &A, const double *x3, const Epi3 &epi, do
     else if (chunk == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 2>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
     else if (A.mesh_pattern) {
         const bool narrow = A.P.col16 != nullptr, scaled = A.s1 || A.s2;
-        if (narrow && !scaled) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4, true, true, false>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
+        if (narrow && !scaled && A.nt) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4, true, true, false, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
+        else if (narrow && !scaled) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4, true, true, false>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
         else if (narrow) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4, true, true, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
         else if (!scaled) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4, true, false, false>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
-    } else if (!(A.s1 || A.s2) && A.P.col16) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4, false, true, false>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
+    } else if (!(A.s1 || A.s2) && A.P.col16 && A.nt) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4, false, true, false, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
+    else if (!(A.s1 || A.s2) && A.P.col16) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4, false, true, false>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
     else if (!(A.s1 || A.s2)) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4, false, false, false>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
     ORC_HIP(hipGetLastError());

@@ -97,6 +97,7 @@ struct MatView {
     const double *val = nullptr;
     const double *s1 = nullptr;
     const double *s2 = nullptr;
+    int nt = 0;             // set by the launch: the matrix streams are loaded with the non-temporal hint (launch_spmv)
     PackedDev pk;           // optional packed mirror (same pattern, same values): what the product streams when present
     XWinDev xw;             // optional LDS x-window description of the packed mirror
     XSortDev xs;            // optional length-sorted image of the packed mirror (what the window product streams when present)
@@ -123,6 +124,7 @@ struct MatView3 {
     const double *val[3] = {nullptr, nullptr, nullptr};
     const double *s1 = nullptr, *s2 = nullptr;  // row scalings, interleaved [3 n] (MatView::s1 / s2 per system)
     bool mesh_pattern = false;                  // level 0 (kernel-name tag only, see spmv_uniform_k's kMesh)
+    int nt = 0;                                 // set by the launch (MatView::nt)
 };
 
 // Owning pattern (built on the host from CSR, e.g. the mesh pattern or a user matrix).
@@ -273,6 +275,7 @@ int bench_inloop_products3_dev(const MatView3 &A, const double *x3, double *y3, 
 // A BiCGSTAB solve of at least ORC_MATERIALIZE_SCALING (4) iterations evaluates the view's row scalings once, into values of its own
 // from `arena`: A.val = s2 * (s1 * val), A.s1 = A.s2 = null — the same numbers the product kernels would form entry by entry, 16
 // (one system) / 48 (three systems) fewer bytes per row and product.  No-op when the view has no scaling or no known size.
+int matview_stream_nt(const MatView &A);  // the cache policy launch_spmv picks for this view's matrix streams (MatView::nt)
 int materialize_scaled_view(MatView &A, uint64_t iteration_count, Arena &arena);
 int materialize_scaled_view3(MatView3 &A, uint64_t iteration_count, Arena &arena);
 // is the triple path usable in the calling context (single GPU, tree reductions)?

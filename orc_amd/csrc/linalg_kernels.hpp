@@ -14,17 +14,14 @@ __device__ __forceinline__ double view_value(const MatView &A, int64_t row, int6
 // The matrix streams of a product (values, columns, window positions) are read once per launch and are many times the size of
 // the caches: loaded with the non-temporal hint they leave L2 and the Infinity Cache to the vectors.  Measured on the level-0
 // shape (scripts/microbench/stream_floor.hip, 10.24 M rows): plain read 5.2 -> 5.6-6.0 TB/s, value stream 5.05 -> 5.54 TB/s, the
-// whole product 215 -> 194 us.  ORC_MATRIX_LOADS_NT=0 at build time restores ordinary loads.
-#ifndef ORC_MATRIX_LOADS_NT
-#define ORC_MATRIX_LOADS_NT 1
-#endif
-template <class T>
+// whole product 215 -> 194 us.
+// A matrix that fits the Infinity Cache (a 1 M-cell mesh: 62 MB) is served from it launch after launch and loses with the hint
+// (in-loop product 0.65 -> 0.60 of peak at 1.03 M cells): the launch decides (MatView::nt, launch_spmv) between two instantiations
+// (a scalar branch per chunk inside ONE kernel cost 3 % — it fences the scheduler).
+template <bool NT, class T>
 __device__ __forceinline__ T ld_stream(const T *p) {
-#if ORC_MATRIX_LOADS_NT
-    return __builtin_nontemporal_load(p);
-#else
+    if (NT) return __builtin_nontemporal_load(p);
     return *p;
-#endif
 }
 
 // XCD-aware slice walk: workgroups b and b+8 share an XCD (MI355X_MICROARCH "Workgroup dispatch"),
@@ -161,7 +158,8 @@ __global__ __launch_bounds__(kBlock) void spmv_k(MatView A, const double *__rest
 // the view carries no row scaling (materialised), so neither the scaling vectors nor the multiplications are compiled in.
 // Both keep the kernel's scalar-register count under 81 — at 81-96 only seven wavefronts per SIMD are resident, and a launch of
 // eight workgroups per CU then runs a second, nearly empty round (measured: 213 -> 273 us).
-template <class Epi, bool kRagged = false, bool kMesh = false, bool kNarrow = false, bool kScaled = true>
+// kNT: the matrix streams are loaded with the non-temporal hint (launch_spmv decides by the size of the stream).
+template <class Epi, bool kRagged = false, bool kMesh = false, bool kNarrow = false, bool kScaled = true, bool kNT = false>
 __global__ __launch_bounds__(kBlock) void spmv_uniform_k(MatView A, const double *__restrict__ x, Epi epi, double *__restrict__ partials,
                                                  const double *__restrict__ skip_flags /* 2 doubles or null: non-zero = no-op */) {
     __shared__ double lds[8];
@@ -190,18 +188,18 @@ __global__ __launch_bounds__(kBlock) void spmv_uniform_k(MatView A, const double
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const bool in = k0 + u < width;
-                    c[u] = in ? cb[k0 + u] + (int)ld_stream(A.P.col16 + p0 + (int64_t)u * 64) : 0;
-                    v[u] = in ? ld_stream(A.val + p0 + (int64_t)u * 64) : 0.;
+                    c[u] = in ? cb[k0 + u] + (int)ld_stream<kNT>(A.P.col16 + p0 + (int64_t)u * 64) : 0;
+                    v[u] = in ? ld_stream<kNT>(A.val + p0 + (int64_t)u * 64) : 0.;
                 }
             } else {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                // kRagged (coarse AMG levels, 11-49 % padding): padding slots are not fetched, so a cache line whose lanes
-                // are all past their rows' ends stays in HBM; otherwise the loads stay wave-uniform (cheaper to issue)
-                const bool in = k0 + u < (kRagged ? len : width);
-                c[u] = in ? ld_stream(A.P.col + p0 + (int64_t)u * 64) : 0;
-                v[u] = in ? ld_stream(A.val + p0 + (int64_t)u * 64) : 0.;
-            }
+                for (int u = 0; u < 8; ++u) {
+                    // kRagged (coarse AMG levels, 11-49 % padding): padding slots are not fetched, so a cache line whose lanes
+                    // are all past their rows' ends stays in HBM; otherwise the loads stay wave-uniform (cheaper to issue)
+                    const bool in = k0 + u < (kRagged ? len : width);
+                    c[u] = in ? ld_stream<kNT>(A.P.col + p0 + (int64_t)u * 64) : 0;
+                    v[u] = in ? ld_stream<kNT>(A.val + p0 + (int64_t)u * 64) : 0.;
+                }
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) xv[u] = (k0 + u < len) ? x[c[u]] : 0.;
@@ -235,7 +233,7 @@ __global__ __launch_bounds__(kBlock) void spmv_uniform_k(MatView A, const double
 // spmv_uniform_k, so every system's row sums AND partial sums are those of its own one-system product.
 struct __attribute__((aligned(8))) Vec3d { double a, b, c; };
 
-template <class Epi3, int kChunk = 4, bool kMesh = false, bool kNarrow = false, bool kScaled = true>
+template <class Epi3, int kChunk = 4, bool kMesh = false, bool kNarrow = false, bool kScaled = true, bool kNT = false>
 __global__ __launch_bounds__(kBlock) void spmv3_uniform_k(MatView3 A, const double *__restrict__ x3, Epi3 epi, double *__restrict__ partials) {
     __shared__ double lds[8];
     const int lane = threadIdx.x & 63;
@@ -263,11 +261,11 @@ __global__ __launch_bounds__(kBlock) void spmv3_uniform_k(MatView3 A, const doub
 #pragma unroll
             for (int u = 0; u < kChunk; ++u) {  // wave-uniform matrix loads at compile-time offsets from one chunk base
                 const bool in = k0 + u < width;
-                if (kNarrow) c[u] = in ? cb[k0 + u] + (int)ld_stream(A.P.col16 + p0 + (int64_t)u * 64) : 0;
-                else c[u] = in ? ld_stream(A.P.col + p0 + (int64_t)u * 64) : 0;
-                v0[u] = in ? ld_stream(A.val[0] + p0 + (int64_t)u * 64) : 0.;
-                v1[u] = in ? ld_stream(A.val[1] + p0 + (int64_t)u * 64) : 0.;
-                v2[u] = in ? ld_stream(A.val[2] + p0 + (int64_t)u * 64) : 0.;
+                if (kNarrow) c[u] = in ? cb[k0 + u] + (int)ld_stream<kNT>(A.P.col16 + p0 + (int64_t)u * 64) : 0;
+                else c[u] = in ? ld_stream<kNT>(A.P.col + p0 + (int64_t)u * 64) : 0;
+                v0[u] = in ? ld_stream<kNT>(A.val[0] + p0 + (int64_t)u * 64) : 0.;
+                v1[u] = in ? ld_stream<kNT>(A.val[1] + p0 + (int64_t)u * 64) : 0.;
+                v2[u] = in ? ld_stream<kNT>(A.val[2] + p0 + (int64_t)u * 64) : 0.;
             }
 #pragma unroll
             for (int u = 0; u < kChunk; ++u) {
@@ -417,7 +415,7 @@ __global__ __launch_bounds__(kBlock) void spmv_pipe_k(MatView A, const double *_
 // kScaled = false: the view carries no row scaling (a smoothing solve has materialised its scaled values, materialize_scaled_view):
 // the two scaling multiplications per entry and their selects are not compiled in — the stream loop of this kernel is bound by
 // instruction issue as much as by memory (39 vector instructions per entry and wavefront, profiles/r03_pmc_products.csv)
-template <class Epi, int kDebug = 0, bool kScaled = true>
+template <class Epi, int kDebug = 0, bool kScaled = true, bool kNT = false>
 __global__ __launch_bounds__(kBlock) void spmv_xwin_k(MatView A, const double *__restrict__ x, Epi epi, double *__restrict__ partials,
                                                       const double *__restrict__ skip_flags) {
     __shared__ double lds[8];
@@ -467,8 +465,8 @@ __global__ __launch_bounds__(kBlock) void spmv_xwin_k(MatView A, const double *_
                 const unsigned long long m = __ballot(in);
                 const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
                 const int p = in ? off32 + rank : (m != 0ull ? off32 : off32 - 1);
-                cc[u] = (int)ld_stream(s_lidx + p);
-                vv[u] = ld_stream(s_val + p);
+                cc[u] = (int)ld_stream<kNT>(s_lidx + p);
+                vv[u] = ld_stream<kNT>(s_val + p);
                 off32 += __popcll(m);
             }
         };
@@ -483,7 +481,7 @@ __global__ __launch_bounds__(kBlock) void spmv_xwin_k(MatView A, const double *_
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const int j = j0 + q * kBlock + (int)threadIdx.x;
-                    wj[q] = ld_stream(wc + (j < ws ? j : 0));
+                    wj[q] = wc[j < ws ? j : 0];
                 }
 #pragma unroll
                 for (int q = 0; q < 8; ++q) xw[q] = x[wj[q]];
@@ -532,8 +530,8 @@ __global__ __launch_bounds__(kBlock) void spmv_xwin_k(MatView A, const double *_
                         const unsigned long long m = __ballot(in);
                         const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
                         const int64_t p = in ? pk_off + rank : (m != 0ull ? pk_off : pk_off - 1);
-                        cg[u] = ld_stream(A.pk.col + p);
-                        vg[u] = ld_stream(A.pk.val + p);
+                        cg[u] = A.pk.col[p];
+                        vg[u] = A.pk.val[p];
                         pk_off += __popcll(m);
                     }
 #pragma unroll

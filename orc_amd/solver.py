@@ -123,7 +123,7 @@ class Solver:
         ms = (C.c_double * 4)()
         check(lib().orc_bench_inloop_products(self.ptr, C.c_int(reps), ms))
         lib().orc_bench_inloop_variant.restype = C.c_char_p
-        self.inloop_variant = lib().orc_bench_inloop_variant().decode()  # "<narrow>, <scaled>" template arguments of those launches
+        self.inloop_variant = lib().orc_bench_inloop_variant().decode()  # "<narrow>, <scaled>, <non-temporal>" template arguments of those launches
         return [ms[k] for k in range(4)]
 
     def bench_gs_sweep(self, reps=50):
