@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void product(const double *__restrict__ val, c
 
 // three systems on one pattern: three value streams, one column stream, interleaved x (24 bytes per column), CHUNK entries per pass
 struct __attribute__((aligned(8))) V3 { double a, b, c; };
-template <int CHUNK, bool NT, bool NTX>
+template <int CHUNK, bool NT, bool NTX, bool SOA = false>
 __global__ __launch_bounds__(256) void product3(const double *__restrict__ v0p, const double *__restrict__ v1p, const double *__restrict__ v2p,
                                                 const unsigned short *__restrict__ col16, const int *__restrict__ colbase, const double *__restrict__ x3,
                                                 double *__restrict__ y3, int n_slices, int64_t n) {
@@ -86,14 +86,18 @@ __global__ __launch_bounds__(256) void product3(const double *__restrict__ v0p, 
                 v2[u] = in ? (NT ? __builtin_nontemporal_load(v2p + base + u * 64) : v2p[base + u * 64]) : 0.;
             }
 #pragma unroll
-            for (int u = 0; u < CHUNK; ++u) xv[u] = xv3[c[u]];
+            for (int u = 0; u < CHUNK; ++u) {
+                if (SOA) { xv[u].a = x3[c[u]]; xv[u].b = x3[(int64_t)n_slices * 64 + c[u]]; xv[u].c = x3[(int64_t)n_slices * 128 + c[u]]; }  // three vectors of n
+                else xv[u] = xv3[c[u]];
+            }
 #pragma unroll
             for (int u = 0; u < CHUNK; ++u) {
                 if (k0 + u < kW) { a0 = a0 + v0[u] * xv[u].a; a1 = a1 + v1[u] * xv[u].b; a2 = a2 + v2[u] * xv[u].c; }
             }
         }
         const int64_t row = (int64_t)s * 64 + lane;
-        if (row < n) {
+        if (row < n && SOA) { y3[row] = a0; y3[(int64_t)n_slices * 64 + row] = a1; y3[(int64_t)n_slices * 128 + row] = a2; }
+        else if (row < n) {
             if (NTX) { __builtin_nontemporal_store(a0, y3 + 3 * row); __builtin_nontemporal_store(a1, y3 + 3 * row + 1); __builtin_nontemporal_store(a2, y3 + 3 * row + 2); }
             else { y3[3 * row] = a0; y3[3 * row + 1] = a1; y3[3 * row + 2] = a2; }
         }
@@ -215,15 +219,15 @@ int main(int argc, char **argv) {
         CK(hipMemcpy(v1, val, padded * 8, hipMemcpyDeviceToDevice)); CK(hipMemcpy(v2, val, padded * 8, hipMemcpyDeviceToDevice));
         CK(hipMemset(x3, 0, (size_t)n_slices * 64 * 24));
         const double b = 3. * padded * 8. + padded * 2. + n_slices * kW * 4. + 2. * n * 24.;
-        for (int wgs : {4, 5, 8}) {
+        for (int wgs : {5, 8}) {
             const int grid = 256 * wgs;
             printf("-- three systems, %d workgroups per CU\n", wgs);
 #define RUN3(C, NT, NTX, label) report(label, time_ms([&] { hipLaunchKernelGGL((product3<C, NT, NTX>), dim3(grid), dim3(256), 0, 0, val, v1, v2, c16, base, x3, y3, n_slices, n); }, 20), b)
             RUN3(4, false, false, "three systems, chunks of 4");
             RUN3(4, true, false, "three systems, chunks of 4, non-temporal matrix");
             RUN3(4, true, true, "three systems, chunks of 4, nt matrix + nt y");
-            RUN3(2, true, false, "three systems, chunks of 2, non-temporal matrix");
-            RUN3(8, true, false, "three systems, chunks of 8, non-temporal matrix");
+            report("three systems, separate x / y vectors, nt matrix", time_ms([&] { hipLaunchKernelGGL((product3<4, true, false, true>), dim3(grid), dim3(256), 0, 0, val, v1, v2, c16, base, x3, y3, n_slices, n); }, 20), b);
+            report("three systems, separate x / y vectors", time_ms([&] { hipLaunchKernelGGL((product3<4, false, false, true>), dim3(grid), dim3(256), 0, 0, val, v1, v2, c16, base, x3, y3, n_slices, n); }, 20), b);
         }
     }
     for (int wgs : {8, 32}) {
