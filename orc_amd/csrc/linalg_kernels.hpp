@@ -481,7 +481,7 @@ __global__ __launch_bounds__(kBlock) void spmv_xwin_k(MatView A, const double *_
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const int j = j0 + q * kBlock + (int)threadIdx.x;
-                    wj[q] = wc[j < ws ? j : 0];
+                    wj[q] = ld_stream<kNT>(wc + (j < ws ? j : 0));
                 }
 #pragma unroll
                 for (int q = 0; q < 8; ++q) xw[q] = x[wj[q]];
@@ -530,8 +530,8 @@ __global__ __launch_bounds__(kBlock) void spmv_xwin_k(MatView A, const double *_
                         const unsigned long long m = __ballot(in);
                         const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
                         const int64_t p = in ? pk_off + rank : (m != 0ull ? pk_off : pk_off - 1);
-                        cg[u] = A.pk.col[p];
-                        vg[u] = A.pk.val[p];
+                        cg[u] = ld_stream<kNT>(A.pk.col + p);
+                        vg[u] = ld_stream<kNT>(A.pk.val + p);
                         pk_off += __popcll(m);
                     }
 #pragma unroll
