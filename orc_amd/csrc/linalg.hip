@@ -133,7 +133,8 @@ static inline bool reference_order(const MatView &A) { return ctx().reduction_or
 // product 198 -> 178 us) and cost where it lives in the 256 MB Infinity Cache (1.03 M cells, 62 MB: 0.65 -> 0.60 of peak).
 // ORC_SPMV_NT=0 / 1 forces the policy.
 static inline int stream_nt(int64_t stream_bytes) {
-    static const int forced = getenv("ORC_SPMV_NT") ? atoi(getenv("ORC_SPMV_NT")) : -1;
+    const char *e = getenv("ORC_SPMV_NT");  // per launch: the tests run one process through both policies
+    const int forced = e ? atoi(e) : -1;
     if (forced >= 0) return forced != 0;
     return stream_bytes > ((int64_t)128 << 20);
 }

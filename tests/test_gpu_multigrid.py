@@ -220,6 +220,30 @@ def test_stream_scheduling_does_not_change_a_bit(gpu, oracle, mesh_path, monkeyp
             assert np.array_equal(x, y)
 
 
+@pytest.mark.parametrize("triple", ["1", "0"])
+def test_cache_policy_of_the_matrix_loads_does_not_change_a_bit(gpu, monkeypatch, triple):
+    """The products load their matrix streams with the non-temporal hint when the stream exceeds 128 MB (launch_spmv; kernel
+    instantiations of their own) — a size no other test of this file reaches.  Forced on and forced off on a small channel,
+    lock-step and per-system momentum solves: three default-stack SIMPLE iterations, identical bits."""
+    from orc_amd.mesh import Mesh, hex_channel, set_channel_bcs
+    from orc_amd.settings import NumericalSettings
+    from orc_amd.solver import solve_steady
+    import helpers as H
+    a = set_channel_bcs(hex_channel(40, 24, 16))  # level 2 has 3 840 rows of ~30 entries: window products on the coarse levels
+    s = NumericalSettings.default(momentum=5, solver_type=MULTIGRID, iterations=8, momentum_relaxation=0.1, pressure_relaxation=0.001)
+    monkeypatch.setenv("ORC_TRIPLE_MOMENTUM", triple)
+    out = []
+    for nt in ("0", "1"):
+        monkeypatch.setenv("ORC_SPMV_NT", nt)
+        dm = Mesh(a)
+        u, v, w, p = H.seeded_fields(a, seed=11)
+        solve_steady(dm, u, v, w, p, s, 1000.0, 1e-3, 3)
+        out.append((u, v, w, p))
+    assert np.isfinite(out[0][0]).all()
+    for x, y in zip(*out):
+        assert np.array_equal(x, y)
+
+
 def test_last_slice_dead_lanes_regression(gpu, oracle, mesh_path):
     """Regression (round 2, fix 5d036f6): channel_flow.msh has 1008 = 15 x 64 + 48 cells, so the last slice of every level has
     dead lanes; those lanes once gathered through never-written columns of the device-packed coarse operators and the process
