@@ -294,6 +294,24 @@ int orc_debug_set_spmv_variant(int variant);
 long long orc_debug_halo_overlaps(void);
 /* test hook: products launched on a length-sorted image of a coarse level (XSortDev) since the process started */
 long long orc_debug_xsort_products(void);
+/* [r04] test hooks.  orc_debug_clamp_partials_grid: the ONE function through which every launcher sizes a grid whose workgroups
+ * write per-workgroup partial sums (<= orc_debug_max_partials(), whatever the CU count or a measurement switch asks for); host only.
+ * orc_debug_amg_certification: out[0] = aggregations whose asynchronous cascades were followed by the certifying lock-step
+ * rounds, out[1] = the rounds those took in total; equal means no certification changed a pairing.  orc_debug_xwin_counters:
+ * out[0] = 256-row blocks of coarse operators given an LDS x window description since the last reset, out[1] = of those
+ * without a window because it would exceed the cap (ORC_XWIN_CAP <= 5000 entries), out[2] = because the block's column span
+ * exceeds the bitmap (ORC_XWIN_BITWORDS <= 8192 words of 32 columns): the products of such blocks gather from global memory. */
+/* orc_debug_amg_coarse_product: one level of the Multigrid set-up on (A) — pairing, (R a) R^T, and where the coarse rows are
+ * long enough (ORC_SPMV_XWIN_MIN_NNZ, 24 entries per row) the packed mirror with its LDS x windows — then y = Ac x launched as
+ * the solves launch it (linear_algebra.rs:82-97: `a_prime * e_prime`); x, y hold ceil(n / 2) doubles.  scaled != 0: the Jacobi
+ * scaling 1 / diag materialised into the streamed values, as inside a smoothing solve (:159-166).  Ac itself comes from
+ * orc_amg_coarsen (same kernels), so a test can evaluate the same product on the oracle. */
+int orc_debug_amg_coarse_product(int64_t n, const int64_t *row_ptr, const int64_t *col_idx, const double *values, int scaled, const double *x,
+                                 double *y, int *has_window_mirror);
+int orc_debug_clamp_partials_grid(long long requested);
+int orc_debug_max_partials(void);
+int orc_debug_amg_certification(long long out[2], int reset);
+int orc_debug_xwin_counters(long long out[3], int reset);
 /* kernel-level timers accumulated inside orc_solver_iterate when enabled: name/ms pairs */
 int orc_profile_enable(int on);
 int orc_profile_report(char *buf, int64_t buf_len);

@@ -19,6 +19,7 @@
 // coarse operator is bit-identical to nalgebra-sparse's.
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <mutex>
@@ -469,13 +470,13 @@ __global__ __launch_bounds__(1024) void tail_small_k(MatView A, int *choice, int
 // The workgroup-scope fence keeps the COMPILER from moving accesses across this point; the wait makes the HARDWARE finish every
 // outstanding vector-memory access of this wavefront (the relaxed agent-scope atomics above it: stores and returning atomics
 // count in vmcnt, loads too) before the next one is issued — at workgroup scope the fence alone need not wait for global stores
-// to be performed.  No cache is written back or invalidated.
+// to be performed.  No cache is written back or invalidated.  (r03 shipped this wait behind a build switch nobody defined; it is
+// unconditional again: no measurable cost at 10.24 M cells, and tests/test_gpu_multigrid.py asserts that the certification
+// rounds after the cascades change nothing.)
 __device__ __forceinline__ void chase_fence() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-#ifdef ORC_CHASE_FENCE_WAIT  // build-time switch: measured no different in wall time or in certification rounds (always 1) at 10.24 M cells
     __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) expcnt(0) lgkmcnt(0)
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-#endif
 }
 __device__ __forceinline__ int ld_i(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_i(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -1491,8 +1492,14 @@ __global__ __launch_bounds__(kScanThreads) void scan2_i64_k(const int64_t *__res
 // set bits in an LDS bitmap over the block's column span, a prefix of the word population counts turns a bit into its
 // rank.  A block whose span exceeds the bitmap or whose window exceeds kXWinCap gets wsize = -1 (global gathers).
 constexpr int kXBitWords = 8192;  // 262144 columns of span
+// [r04] The two limits are run-time arguments bounded by the compiled LDS sizes (win_cap <= kXWinCap, bit_words <= kXBitWords;
+// ORC_XWIN_CAP / ORC_XWIN_BITWORDS, read per set-up): at bench size 1 % of level 3's blocks take the no-window path of the
+// product and none the span branch, on test-sized meshes none at all — the tests shrink the limits to drive a chosen share of
+// the blocks through both branches and compare with the oracle (tests/test_gpu_window_fallback.py).  g_xwin_counters: blocks
+// built / without a window because of the cap / because of the span, since the last reset (orc_debug_xwin_counters).
+__device__ unsigned long long g_xwin_counters[3];
 __global__ __launch_bounds__(kBlock) void xwin_build_k(SellDev P, PackedDev pk, int *__restrict__ wcol, int *__restrict__ wsize,
-                                                       unsigned short *__restrict__ lidx, int64_t n_blocks) {
+                                                       unsigned short *__restrict__ lidx, int64_t n_blocks, int win_cap, int bit_words) {
     __shared__ unsigned bits[kXBitWords];
     __shared__ unsigned short wpre[kXBitWords];  // exclusive prefix of the word population counts (windows hold <= 4096)
     __shared__ int s_min, s_max, s_part[kBlock];
@@ -1516,8 +1523,9 @@ __global__ __launch_bounds__(kBlock) void xwin_build_k(SellDev P, PackedDev pk, 
             __syncthreads();
             continue;
         }
-        if (words > kXBitWords) {
-            if (tid == 0) wsize[b] = -1;
+        if (tid == 0) atomicAdd(&g_xwin_counters[0], 1ull);
+        if (words > bit_words) {
+            if (tid == 0) { wsize[b] = -1; atomicAdd(&g_xwin_counters[2], 1ull); }
             __syncthreads();
             continue;
         }
@@ -1541,9 +1549,9 @@ __global__ __launch_bounds__(kBlock) void xwin_build_k(SellDev P, PackedDev pk, 
             __syncthreads();
         }
         const int total = s_part[kBlock - 1];
-        if (total > kXWinCap) {
+        if (total > win_cap) {
             __syncthreads();
-            if (tid == 0) wsize[b] = -1;
+            if (tid == 0) { wsize[b] = -1; atomicAdd(&g_xwin_counters[1], 1ull); }
             __syncthreads();
             continue;
         }
@@ -1806,6 +1814,26 @@ void SiblingPairing::finish() {
 // point (agg_verify_k: one pass, nothing to iterate) and dropped otherwise — measured: a sibling's pairing that is off in
 // a few per cent of the rows is a worse start than the slice sweep's state (the cascades from it multiply instead of
 // running out: 60 M evaluations against 4 M), so there is no middle way.
+// orc_debug_amg_certification: aggregations whose cascades were followed by the certifying lock-step rounds, and how many rounds
+// those took in total (equal = every certification found nothing to change: the cascades had reached the fixed point)
+static std::atomic<long long> g_cert_aggregations{0}, g_cert_rounds{0};
+void debug_amg_certification(long long out[2], bool reset) {
+    out[0] = g_cert_aggregations.load(std::memory_order_relaxed);
+    out[1] = g_cert_rounds.load(std::memory_order_relaxed);
+    if (reset) { g_cert_aggregations.store(0); g_cert_rounds.store(0); }
+}
+int debug_xwin_counters(long long out[3], bool reset) {
+    unsigned long long h[3] = {0, 0, 0};
+    ORC_HIP(hipDeviceSynchronize());
+    ORC_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_xwin_counters), sizeof(h)));
+    for (int i = 0; i < 3; ++i) out[i] = (long long)h[i];
+    if (reset) {
+        const unsigned long long z[3] = {0, 0, 0};
+        ORC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_xwin_counters), z, sizeof(z)));
+    }
+    return ORC_OK;
+}
+
 static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, int *rounds_out, const int *warm = nullptr, int warm_kind = 1) {
     const int64_t n = A.P.n;
     const int g = grid_for(n);
@@ -1937,7 +1965,7 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
         // spreads them over the whole chip again (unbounded: a few wavefronts with long cascades work alone — 477 ms of
         // cascades per 3.25 iterations against 321 ms at 96; 16: 525 ms, launches dominate)
         const int chase_steps = getenv("ORC_AMG_CHASE_STEPS") ? atoi(getenv("ORC_AMG_CHASE_STEPS")) : 96;
-        const int chase_grid = getenv("ORC_AMG_CHASE_GRID") ? atoi(getenv("ORC_AMG_CHASE_GRID")) : 2048;
+        const int chase_grid = clamp_partials_grid(getenv("ORC_AMG_CHASE_GRID") ? atoi(getenv("ORC_AMG_CHASE_GRID")) : 2048);
         const int chase_launches = getenv("ORC_AMG_CHASE_LAUNCHES") ? atoi(getenv("ORC_AMG_CHASE_LAUNCHES")) : 1024;
         const int chase_batch = getenv("ORC_AMG_CHASE_BATCH") ? std::max(1, atoi(getenv("ORC_AMG_CHASE_BATCH"))) : 2;  // launches per host read
         static const bool trace = getenv("ORC_AMG_TRACE") != nullptr;
@@ -2010,7 +2038,7 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
         while (!fin) {
             const int batch = chase_enabled && cert_batches == 0 ? 1 : kBatch;  // after the cascades one round is expected to certify
             for (int b = 0; b < batch; ++b) {
-                static const int tail_grid = getenv("ORC_AMG_TAIL_GRID") ? atoi(getenv("ORC_AMG_TAIL_GRID")) : 1024;
+                static const int tail_grid = clamp_partials_grid(getenv("ORC_AMG_TAIL_GRID") ? atoi(getenv("ORC_AMG_TAIL_GRID")) : 1024);
                 const int ge = first ? g : tail_grid;
                 launch_eval(ge);
                 hipLaunchKernelGGL(tail_commit_k, dim3(ge), dim3(kBlock), 0, st, choice, taken_by, T, ch_row, ch_new, ch_old, ch_t_old, ch_t_new);
@@ -2029,6 +2057,10 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
             if (h.rounds > 8 * 1000 * 1000) return set_error(ORC_ERR_BAD_ARGUMENT, "aggregation did not reach its fixed point");
         }
         lap("lock-step rounds");
+        if (chase_enabled && cert_batches > 0) {  // test hook: a certification that takes ONE round has changed nothing
+            g_cert_aggregations.fetch_add(1, std::memory_order_relaxed);
+            g_cert_rounds.fetch_add(h.rounds, std::memory_order_relaxed);
+        }
         if (trace && chase_enabled) fprintf(stderr, "[amg certify n=%lld] lock-step rounds %d\n", (long long)n, h.rounds);
         rounds += h.rounds;
     }
@@ -2210,7 +2242,7 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
     // Packed mirror + LDS x windows for the levels whose rows are long enough for a window to be re-used (measured at
     // 10.24 M fine rows: 33 entries per row +2 %, 70 entries per row +17 % against the padded product; 15 entries per row
     // -10 %, so that level keeps the padded image).  ORC_SPMV_XWIN_MIN_NNZ < 0 switches the mirror off.
-    static const int xwin_min = getenv("ORC_SPMV_XWIN_MIN_NNZ") ? atoi(getenv("ORC_SPMV_XWIN_MIN_NNZ")) : 24;
+    const int xwin_min = getenv("ORC_SPMV_XWIN_MIN_NNZ") ? atoi(getenv("ORC_SPMV_XWIN_MIN_NNZ")) : 24;  // (per call: the tests switch it)
     const bool mirror = xwin_min >= 0 && packed_total > 0 && packed_total >= (int64_t)xwin_min * nc;
     int *pk_col = nullptr;
     double *pk_val = nullptr;
@@ -2272,7 +2304,9 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
         ORC_TRY(arena.alloc((size_t)n_blocks * kXWinCap, &wcol));
         ORC_TRY(arena.alloc((size_t)n_blocks, &wsize));
         ORC_TRY(arena.alloc((size_t)packed_total, &lidx));
-        hipLaunchKernelGGL(xwin_build_k, dim3((unsigned)std::min<int64_t>(n_blocks, 2048)), dim3(kBlock), 0, st, Pc, L.pk, wcol, wsize, lidx, n_blocks);
+        const int win_cap = getenv("ORC_XWIN_CAP") ? std::max(1, std::min(kXWinCap, atoi(getenv("ORC_XWIN_CAP")))) : kXWinCap;  // (per call: test hook)
+        const int bit_words = getenv("ORC_XWIN_BITWORDS") ? std::max(1, std::min(kXBitWords, atoi(getenv("ORC_XWIN_BITWORDS")))) : kXBitWords;
+        hipLaunchKernelGGL(xwin_build_k, dim3((unsigned)std::min<int64_t>(n_blocks, 2048)), dim3(kBlock), 0, st, Pc, L.pk, wcol, wsize, lidx, n_blocks, win_cap, bit_words);
         ORC_HIP(hipGetLastError());
         L.xw.wcol = wcol; L.xw.wsize = wsize; L.xw.lidx = lidx;
         static const bool xwin_stats = getenv("ORC_XWIN_STATS") && atoi(getenv("ORC_XWIN_STATS")) != 0;
@@ -2798,8 +2832,12 @@ int multigrid_arm3_dev(const MatView3 &A3, const double *const b[3], double *con
 // ------------------------------------------------------------------ test hooks (private fns of the reference made observable)
 namespace orc {
 
+// x_h / y_h (optional, [ceil(n / 2)]): y = Ac x with the coarse operator AS THE SOLVES MULTIPLY IT — launch_spmv on the level's view,
+// i.e. the packed mirror + LDS window product wherever galerkin() built one.  scaled != 0: the view a smoothing solve launches
+// (Jacobi scaling 1 / diag materialised into the streamed values: spmv_xwin_k<Epi, 0, false>), else the plain values
+// (spmv_xwin_k<Epi>, what the residual checks launch).  *mirror_out: did the level get a window mirror at all?
 int amg_debug_coarsen(const MatView &A, Arena &arena, std::vector<int> &choice_h, std::vector<int64_t> &row_ptr_h,
-                      std::vector<int64_t> &col_h, std::vector<double> &val_h, int *rounds) {
+                      std::vector<int64_t> &col_h, std::vector<double> &val_h, int *rounds, const double *x_h, double *y_h, int scaled, int *mirror_out) {
     const int64_t n = A.P.n;
     hipStream_t st = ctx().stream;
     Arena::Mark mk = arena.mark();
@@ -2813,6 +2851,24 @@ int amg_debug_coarsen(const MatView &A, Arena &arena, std::vector<int> &choice_h
     choice_h.resize((size_t)n);
     ORC_HIP(hipMemcpyAsync(choice_h.data(), choice, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, st));
     const int64_t nc = L.n;
+    if (mirror_out) *mirror_out = (L.pk.ptr && L.xw.lidx) ? 1 : 0;
+    if (x_h && y_h && nc > 0) {
+        MatView V;
+        V.P = L.P; V.val = L.val; V.pk = L.pk; V.xw = L.xw; V.xs = L.xs; V.symmetric = A.symmetric;
+        double *x, *y, *d1;
+        ORC_TRY(arena.alloc((size_t)nc, &x));
+        ORC_TRY(arena.alloc((size_t)nc, &y));
+        ORC_HIP(hipMemcpyAsync(x, x_h, sizeof(double) * (size_t)nc, hipMemcpyHostToDevice, st));
+        if (scaled) {
+            ORC_TRY(arena.alloc((size_t)nc, &d1));
+            ORC_TRY(diag_inverse_dev(V, d1));
+            V.s1 = d1;
+            ORC_TRY(materialize_scaled_view(V, 50, arena));
+        }
+        ORC_TRY(spmv_dev(V, x, y));
+        ORC_HIP(hipMemcpyAsync(y_h, y, sizeof(double) * (size_t)nc, hipMemcpyDeviceToHost, st));
+        ORC_HIP(hipStreamSynchronize(st));
+    }
     std::vector<int> row_len((size_t)nc), col((size_t)std::max<int64_t>(L.padded, 1));
     std::vector<int64_t> slice_ptr((size_t)L.P.n_slices + 1);
     std::vector<double> val((size_t)std::max<int64_t>(L.padded, 1));

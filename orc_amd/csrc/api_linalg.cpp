@@ -5,7 +5,8 @@
 
 namespace orc {
 int amg_debug_coarsen(const MatView &A, Arena &arena, std::vector<int> &choice_h, std::vector<int64_t> &row_ptr_h,
-                      std::vector<int64_t> &col_h, std::vector<double> &val_h, int *rounds);
+                      std::vector<int64_t> &col_h, std::vector<double> &val_h, int *rounds, const double *x_h = nullptr, double *y_h = nullptr,
+                      int scaled = 0, int *mirror_out = nullptr);
 int gs_debug_coloring(const SellDev &P, std::vector<int> &colors, int *n_colors);
 static SolveStats g_last_stats;
 SolveStats &last_stats() { return g_last_stats; }
@@ -82,6 +83,9 @@ int orc_iterative_solve3(int64_t n, const int64_t *row_ptr, const int64_t *col_i
             A.symmetric = pat.symmetric;
             SolveStats stats;
             st3[k] = iterative_solve_dev(A, db[k].p, dx[k].p, iteration_count, method, relaxation_factor, convergence_threshold, preconditioner, arena, &stats);
+            // a solver VERDICT (the reference's "Multigrid diverged" panic) is per system; anything else — a HIP error, a failed
+            // arena allocation — is the call's own failure and must not disappear behind ORC_OK
+            if (st == ORC_OK && st3[k] != ORC_OK && st3[k] != ORC_ERR_MULTIGRID_DIVERGED) st = st3[k];
         }
     } else if (method == ORC_SOLVER_BICGSTAB) {
         double *b3, *x3;
@@ -116,6 +120,8 @@ int orc_iterative_solve3(int64_t n, const int64_t *row_ptr, const int64_t *col_i
         if (st == ORC_OK) st = st2;
         if (status_out) status_out[k] = st3[k];
     }
+    if (!status_out && st == ORC_OK)  // nobody to tell per system: the first verdict is the call's
+        for (int k = 0; k < 3 && st == ORC_OK; ++k) st = st3[k];
     return st;
 }
 
@@ -182,6 +188,28 @@ int orc_amg_coarsen(int64_t n, const int64_t *row_ptr, const int64_t *col_idx, c
         std::copy(v.begin(), v.end(), out_val);
     }
     return ORC_OK;
+}
+
+int orc_debug_amg_coarse_product(int64_t n, const int64_t *row_ptr, const int64_t *col_idx, const double *values, int scaled, const double *x,
+                                 double *y, int *has_window_mirror) {
+    using namespace orc;
+    ORC_TRY(ensure_init());
+    if (n < 1 || !row_ptr || !col_idx || !values || !x || !y) return set_error(ORC_ERR_BAD_ARGUMENT, "null argument");
+    SellMatrix pat;
+    ORC_TRY(sell_from_csr_host(n, n, row_ptr, col_idx, pat));
+    DevBuf<double> csr_vals, vals;
+    ORC_TRY(csr_vals.upload(values, (size_t)pat.nnz));
+    ORC_TRY(vals.alloc((size_t)std::max<int64_t>(pat.padded, 1)));
+    ORC_TRY(sell_import_values(pat, csr_vals.p, vals.p));
+    MatView A;
+    A.P = pat.dev();
+    A.val = vals.p;
+    A.symmetric = pat.symmetric;
+    Arena arena;
+    std::vector<int> choice;
+    std::vector<int64_t> rp, ci;
+    std::vector<double> v;
+    return amg_debug_coarsen(A, arena, choice, rp, ci, v, nullptr, x, y, scaled, has_window_mirror);
 }
 
 int orc_debug_coloring(int64_t n, const int64_t *row_ptr, const int64_t *col_idx, int32_t *colors, int32_t *n_colors) {

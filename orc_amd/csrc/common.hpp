@@ -158,11 +158,16 @@ struct ArenaScope {
     ArenaScope &operator=(const ArenaScope &) = delete;
 };
 
+// THE bound on every grid whose workgroups write per-workgroup partial sums (partials[q * gridDim.x + blockIdx.x]): the partial
+// arrays hold kMaxPartials entries per quantity, whatever the device's CU count and whatever a measurement switch asks for.
+// r03 found out the hard way (ORC_XWIN_WGS_PER_CU = 12 wrote past the arrays and froze the solves); since r04 every launcher
+// sizes such a grid through this one function (grid_for, spmv_grid, the window product's balanced grid, the cascade grids) and
+// tests/test_abi_cpu.py + tests/test_gpu_grid_switches.py pin it.
+static_assert(kMaxGrid <= kMaxPartials, "a grid-stride grid may write one partial sum per workgroup");
+constexpr int clamp_partials_grid(int64_t g) { return g < 1 ? 1 : (g > (int64_t)kMaxPartials ? kMaxPartials : (int)g); }
+
 inline int grid_for(int64_t work_items, int per_block = kBlock) {
-    int64_t g = (work_items + per_block - 1) / per_block;
-    if (g < 1) g = 1;
-    if (g > kMaxGrid) g = kMaxGrid;
-    return (int)g;
+    return clamp_partials_grid((work_items + per_block - 1) / per_block);
 }
 
 // ---------------- device helpers ----------------

@@ -144,11 +144,10 @@ int matview_stream_nt(const MatView &A) { return stream_nt(A.pk.ptr && A.xw.lidx
 static inline int spmv_grid(int32_t n_slices) {
     int64_t g = ((int64_t)n_slices + 3) / 4;  // 4 waves (slices) per workgroup
     // ORC_SPMV_GRID (measurement): fewer resident workgroups per CU leave wave slots to the set-up kernels of other streams
-    static const int cap = getenv("ORC_SPMV_GRID") ? std::max(8, std::min(kMaxGrid, atoi(getenv("ORC_SPMV_GRID")))) : kMaxGrid;
+    const int cap = getenv("ORC_SPMV_GRID") ? std::max(8, atoi(getenv("ORC_SPMV_GRID"))) : kMaxGrid;  // (per launch: the switch test sweeps it)
     if (g > cap) g = cap;
     if (g >= 8) g = (g / 8) * 8;  // multiple of 8 for the XCD-aware walk
-    if (g < 1) g = 1;
-    return (int)g;
+    return clamp_partials_grid(g);
 }
 
 // ------------------------------------------------------------------ SELL build / import / export
@@ -351,7 +350,7 @@ static int launch_spmv(const MatView &A_in, const double *x, const Epi &epi, dou
         // chip at 10 of 20 waves per CU on average (profiles/r03_pmc_products.csv: SQ_WAVE_CYCLES / GRBM_GUI_ACTIVE; 4 are resident
         // with 32.7 KB of LDS and 92-96 VGPRs each); 8 per CU = the 2048 partial sums a product may write (kMaxPartials) measured
         // level 2: 251 -> 245 us, level 3: 289 -> 270 us.
-        static const int per_cu = getenv("ORC_XWIN_WGS_PER_CU") ? std::max(1, std::min(8, atoi(getenv("ORC_XWIN_WGS_PER_CU")))) : 8;
+        const int per_cu = getenv("ORC_XWIN_WGS_PER_CU") ? std::max(1, atoi(getenv("ORC_XWIN_WGS_PER_CU"))) : 8;  // (per launch: the switch test sweeps it)
         static const int n_cu = [] {
             hipDeviceProp_t prop;
             int dev = 0;
@@ -359,6 +358,7 @@ static int launch_spmv(const MatView &A_in, const double *x, const Epi &epi, dou
         }();
         int64_t gb = ((int64_t)A.P.n_slices + 3) / 4;
         if (gb > (int64_t)n_cu * per_cu) gb = (int64_t)n_cu * per_cu;
+        gb = clamp_partials_grid(gb);  // whatever the CU count (304 on gfx942) and the switch: the epilogue writes partials[blockIdx.x]
         if (gb >= 8) gb = (gb / 8) * 8;
         g = (int)std::max<int64_t>(gb, 1);
     }

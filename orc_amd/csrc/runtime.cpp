@@ -6,6 +6,8 @@
 
 namespace orc {
 long long debug_xsort_products();  // linalg.hip
+void debug_amg_certification(long long out[2], bool reset);  // amg.hip
+int debug_xwin_counters(long long out[3], bool reset);       // amg.hip
 
 static thread_local Ctx *t_ctx_override = nullptr;
 
@@ -220,6 +222,18 @@ int orc_debug_set_spmv_variant(int variant) {
 
 long long orc_debug_halo_overlaps(void) { return orc::ctx().halo_overlaps; }
 long long orc_debug_xsort_products(void) { return orc::debug_xsort_products(); }
+int orc_debug_clamp_partials_grid(long long requested) { return orc::clamp_partials_grid(requested); }
+int orc_debug_max_partials(void) { return orc::kMaxPartials; }
+int orc_debug_amg_certification(long long out[2], int reset) {
+    if (!out) return orc::set_error(ORC_ERR_BAD_ARGUMENT, "null argument");
+    orc::debug_amg_certification(out, reset != 0);
+    return ORC_OK;
+}
+int orc_debug_xwin_counters(long long out[3], int reset) {
+    if (!out) return orc::set_error(ORC_ERR_BAD_ARGUMENT, "null argument");
+    ORC_TRY(orc::ensure_init());
+    return orc::debug_xwin_counters(out, reset != 0);
+}
 
 int orc_profile_enable(int on) {
     orc::ctx().profile = on != 0;

@@ -118,3 +118,33 @@ def debug_coloring(a):
     nc = C.c_int32(0)
     check(lib().orc_debug_coloring(C.c_int64(n), _p(rp, C.c_int64), _p(ci, C.c_int64), _p(colors, C.c_int32), C.byref(nc)))
     return colors, nc.value
+
+
+def amg_coarse_product(a, x, scaled=False):
+    """Test hook: y = a' x with a' = (R a) R^T launched as the Multigrid solves launch it (packed mirror + LDS x windows where the
+    set-up builds them); x has ceil(n / 2) entries.  Returns (y, has_window_mirror)."""
+    a = a.tocsr()
+    a.sort_indices()
+    n = a.shape[0]
+    rp, ci, v = _i64(a.indptr), _i64(a.indices), _f64(a.data)
+    x = _f64(x)
+    assert len(x) == (n + 1) // 2
+    y = np.empty(len(x))
+    mirror = C.c_int(0)
+    check(lib().orc_debug_amg_coarse_product(C.c_int64(n), _p(rp, C.c_int64), _p(ci, C.c_int64), _p(v, C.c_double), C.c_int(1 if scaled else 0),
+                                             _p(x, C.c_double), _p(y, C.c_double), C.byref(mirror)))
+    return y, bool(mirror.value)
+
+
+def xwin_counters(reset=False):
+    """Test hook: (blocks described, blocks without a window because of the cap, ... because of the column span) since the last reset"""
+    out = (C.c_longlong * 3)()
+    check(lib().orc_debug_xwin_counters(out, C.c_int(1 if reset else 0)))
+    return out[0], out[1], out[2]
+
+
+def amg_certification(reset=False):
+    """Test hook: (aggregations certified after their cascades, certification rounds in total); equal = nothing was changed"""
+    out = (C.c_longlong * 2)()
+    check(lib().orc_debug_amg_certification(out, C.c_int(1 if reset else 0)))
+    return out[0], out[1]

@@ -113,3 +113,17 @@ def test_hex_channel_c4_sizes():
     nc, nf, ncf = C.c_int64(), C.c_int64(), C.c_int64()
     check(lib().orc_hex_channel_sizes(C.c_int64(400), C.c_int64(160), C.c_int64(160), C.byref(nc), C.byref(nf), C.byref(ncf)))
     assert (nc.value, nf.value, ncf.value) == (10240000, 30873600, 61440000)
+
+
+def test_partial_sum_grids_have_one_hard_bound(lib):
+    """VERDICT r03 weak #7 / ADVICE r03: every launcher whose workgroups write partials[q * gridDim.x + blockIdx.x] sizes its grid
+    through ONE function (common.hpp: clamp_partials_grid; grid_for, spmv_grid, the window product's balanced grid and the
+    cascade grids all end in it), so no CU count and no measurement switch can ask for more workgroups than the partial-sum
+    arrays (kMaxPartials entries per quantity) hold.  Host-only: no device needed."""
+    cap = lib.orc_debug_max_partials()
+    assert cap == 2048
+    f = lib.orc_debug_clamp_partials_grid
+    f.argtypes = [C.c_longlong]
+    assert f(0) == 1 and f(-7) == 1 and f(1) == 1
+    assert f(cap - 1) == cap - 1 and f(cap) == cap
+    assert f(cap + 1) == cap and f(304 * 8) == cap and f(256 * 40) == cap and f(1 << 40) == cap

@@ -82,7 +82,7 @@ def test_rccl_overlapped_product_on_a_self_loop_communicator(gpu):
         for name, kw, its, tol in (("bicgstab-1", dict(momentum=5, solver_type=3, iterations=1), 1, 1e-13),
                                    ("multigrid-1", dict(momentum=1, solver_type=2, iterations=1), 1, 1e-9),  # measured 9e-11 (bicgstab-1: 4e-15)
                                    ("bicgstab", dict(momentum=5, solver_type=3, iterations=8), 2, 1e-6),
-                                   ("multigrid", dict(momentum=1, solver_type=2, iterations=20), 2, 0.05)):
+                                   ("multigrid", dict(momentum=1, solver_type=2, iterations=20), 2, 1e-3)):  # measured 1e-5 (r03); 0.05 checked nothing
             runs = {}
             for form in ("overlapped", "plain"):
                 if form == "plain":
