@@ -46,13 +46,20 @@ def initial_fields(cc, dp_dx=5.0, h=1e-3, mu=1e-3, lx=0.002, seed=0x4F5243, x0=0
     return u, v, w, p
 
 
-def cpu_baseline(settings_kw, sample=(100, 40, 40), iters=6):
+def cpu_baseline(settings_kw, sample=(100, 40, 40), iters=6, mixed_ref_cells=None):
     """The CPU oracle (oracle/: single-threaded C restatement of ORC's Rust path) timed on a bounded sample of
-    the same workload: same generator, BCs, settings and initial-field recipe at 1/64 of the cells (about 12 s)."""
+    the same workload: same generator, BCs, settings and initial-field recipe at 1/64 of the cells (about 12 s).
+    mixed_ref_cells: the config-5 workload — a 60 x 30 x 30-block mixed channel, scaled to one GPU's slab of that many cells."""
     from oracle import pyoracle as po
-    from orc_amd.mesh import hex_channel, set_channel_bcs
+    from orc_amd.mesh import hex_channel, set_channel_bcs, set_mixed_channel_bcs
+    if mixed_ref_cells:
+        from orc_amd import parallel
+        sample = (60, 30, 30)
+        _a, _h, _g, a = parallel.mixed_slab_arrays(sample[0], sample[1], sample[2], 0, 1)
+        set_mixed_channel_bcs(a)
+    else:
+        a = set_channel_bcs(hex_channel(*sample))
     nx, ny, nz = sample
-    a = set_channel_bcs(hex_channel(nx, ny, nz))
     om = po.Mesh.from_arrays(a)
     u, v, w, p = initial_fields(np.asarray(a["cell_centroid"]))
     kw = dict(settings_kw)
@@ -67,7 +74,8 @@ def cpu_baseline(settings_kw, sample=(100, 40, 40), iters=6):
     t0 = time.perf_counter()
     st, _ = po.solve_steady(om, u, v, w, p, s, 1000.0, 1e-3, iters)
     dt = time.perf_counter() - t0
-    n = nx * ny * nz
+    n = a.n_cells
+    ref_cells = mixed_ref_cells or REF_CELLS
     it_per_s_sample = iters / dt
     cpu_model = "unknown"
     try:
@@ -80,15 +88,46 @@ def cpu_baseline(settings_kw, sample=(100, 40, 40), iters=6):
         pass
     import shutil
     return {
-        "value": it_per_s_sample * n / REF_CELLS,
-        "unit": "SIMPLE iterations/s (10.24M-cell equivalent)",
+        "value": it_per_s_sample * n / ref_cells,
+        "unit": "SIMPLE iterations/s (10.24M-cell equivalent)" if not mixed_ref_cells else "SIMPLE iterations/s (one GPU's mixed slab of %d cells)" % ref_cells,
         "cores": 1,
         "host_cpu": "%s (%d logical cores on the box; ORC's path is single-threaded)" % (cpu_model, os.cpu_count() or 0),
         "rust_toolchain": "present" if shutil.which("cargo") else "absent (ORC itself cannot be built: the port is timed)",
         "kind": "port",
-        "sample": "%dx%dx%d hex channel (%d cells = 1/%d of the workload), %d SIMPLE iterations in %.2f s, status %d; scaled by cells"
-                  % (nx, ny, nz, n, REF_CELLS // n, iters, dt, st) + note,
+        "sample": "%dx%dx%d %s (%d cells = 1/%d of the workload), %d SIMPLE iterations in %.2f s, status %d; scaled by cells"
+                  % (nx, ny, nz, "blocks of the mixed channel" if mixed_ref_cells else "hex channel", n, ref_cells // n, iters, dt, st) + note,
     }
+
+
+def spawn_ranks(n):
+    """python bench.py --gpus N without a launcher: start `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>` as a child process (one rank per GPU over RCCL, or over
+    the host-staged transport on one GPU when ORC_BENCH_HOST_TRANSPORT=1), stream its output through and return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True, bufsize=1)
+    line = None
+    for out in proc.stdout:  # rank 0 prints exactly one JSON line; anything else a rank writes to stdout goes to our stderr
+        if out.startswith('{"metric"'):
+            line = out
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if line is not None:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    elif rc == 0:
+        sys.stderr.write("bench.py: the ranks ended without a result line\n")
+        rc = 1
+    return rc
 
 
 def main():
@@ -96,9 +135,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--nx", type=int, default=400)
-    ap.add_argument("--ny", type=int, default=160)
-    ap.add_argument("--nz", type=int, default=160)
+    ap.add_argument("--workload", default="hex", choices=["hex", "config5"], help="hex: the synthetic hex channel (BASELINE configs[3], the headline); "
+                    "config5: BASELINE configs[4], the mixed tet / hex / poly channel — every rank generates and owns nz block layers "
+                    "(default 252 x 100 x 72 blocks = 5.14 M cells per GPU, 41 M on 8 GPUs)")
+    ap.add_argument("--nx", type=int, default=None)
+    ap.add_argument("--ny", type=int, default=None)
+    ap.add_argument("--nz", type=int, default=None)
     ap.add_argument("--solver", default="multigrid", choices=["multigrid", "bicgstab", "jacobi", "multigrid_gs", "bicgstab_gs"])
     ap.add_argument("--momentum", default="umist", choices=["ud", "cd1", "quick", "umist"])
     ap.add_argument("--inner", type=int, default=50, help="matrix_solver.iterations (lib.rs:80)")
@@ -109,20 +151,40 @@ def main():
     ap.add_argument("--levels-csv", default=None, help="write the per-level product table (profiles/rNN_levels.csv)")
     ap.add_argument("--spin-up", type=int, default=2, help="untimed SIMPLE iterations before the snapshot every timed step restores "
                     "(the timed iteration is number spin-up + 1 of the run; its cost grows slowly with the state)")
+    ap.add_argument("--dry-run", action="store_true", help="launcher rehearsal (CPU test of `--gpus N` without a launcher): the ranks join the "
+                    "gloo control plane, agree on a number and rank 0 prints a line with value null; no GPU work")
     args = ap.parse_args()
+    dflt = (400, 160, 160) if args.workload == "hex" else (252, 100, 72)
+    args.nx, args.ny, args.nz = (v if v is not None else d for v, d in zip((args.nx, args.ny, args.nz), dflt))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` started like the N = 1 case: this process becomes the launcher.  Decided before anything here has
+        # touched the GPU (no HIP call, no torch import); the ranks are fresh CHILD processes of torch.distributed.run, nothing is
+        # re-executed in place.  Rank 0's JSON line is forwarded, the children's exit code is ours.
+        raise SystemExit(spawn_ranks(args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("bench.py --gpus %d inside a torch.distributed.run of %d ranks: the two must agree" % (args.gpus, world))
 
     dist = None
     if world > 1:
         import torch
         import torch.distributed as dist
         dist.init_process_group(backend="gloo")  # control plane only; the data path uses RCCL inside liborc_amd
+    if args.dry_run:
+        seen = world
+        if dist is not None:
+            t = torch.tensor([1.0], dtype=torch.float64)
+            dist.all_reduce(t)
+            seen = int(t.item())
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"metric": "SIMPLE iterations/s (dry run of the launcher: no GPU work)", "value": None, "n_gpus": world, "ranks_seen": seen,
+                              "dry_run": True}), flush=True)
+        return
 
     import orc_amd
     from orc_amd.mesh import Mesh, hex_channel, set_channel_bcs
@@ -151,7 +213,11 @@ def main():
 
     nx, ny, nz = args.nx, args.ny, args.nz
     t_setup = time.perf_counter()
-    if world == 1:
+    mixed_facts = None
+    if args.workload == "config5":
+        from orc_amd import parallel
+        solver, mesh, n_cells_total, nnz, mixed_facts = parallel.make_mixed_slab_solver(nx, ny, nz, rank, world, settings, initial_fields, dist)
+    elif world == 1:
         a = set_channel_bcs(hex_channel(nx, ny, nz))
         mesh = Mesh(a)
         u, v, w, p = initial_fields(np.asarray(a["cell_centroid"]))
@@ -272,6 +338,9 @@ def main():
     key = (args.nx, args.ny, args.nz, args.momentum, args.solver)
     workload_name = ("BASELINE configs[3]" if key == (400, 160, 160, "umist", "multigrid")
                      else "BASELINE configs[2]" if key == (512, 2016, 1, "quick", "bicgstab_gs") else "custom")
+    mixed = args.workload == "config5"
+    if mixed:
+        workload_name = "BASELINE configs[4]" if (key[:3] == (252, 100, 72) and args.solver == "multigrid") else "custom (BASELINE configs[4] family)"
     bicg_bytes = 2.0 * spmv_bytes + 104.0 * n_local
     # Memory-side traffic per launch from the PMC counters (TCC_EA0_RDREQ by request size + TCC_EA0_WRREQ, separate rocprofv3
     # --pmc passes: scripts/gpu_pmc_r02.sh; equal to FETCH_SIZE x 2 + WRITE_SIZE of MI355X_MICROARCH.md §HBM for this
@@ -292,8 +361,11 @@ def main():
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         units = n_cells_total / float(REF_CELLS)  # 10.24M-cell SIMPLE iterations per step (N at weak scaling)
+        if mixed:
+            units = float(world)  # one slab of nz block layers per rank: slab-iterations per step
         out = {
-            "metric": "SIMPLE iterations/s (10.24M-cell hex channel equivalents; = iterations/s at N=1)",
+            "metric": ("SIMPLE iterations/s (10.24M-cell hex channel equivalents; = iterations/s at N=1)" if not mixed else
+                       "SIMPLE iterations/s (mixed tet/hex/poly slab equivalents: N x iterations/s, one %dx%dx%d-block slab per GPU)" % (nx, ny, nz)),
             "value": units * args.steps / dt,
             "unit": "iterations/s",
             "n_gpus": world,
@@ -302,8 +374,11 @@ def main():
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
             "scaling": "weak",
-            "scaling_definition": "weak: every rank owns a %dx%dx%d slab of a %dx%dx(%d*N) channel cut along z; value = N x (10.24M-cell SIMPLE "
-                                  "iterations per second), i.e. cells processed per second / 10.24M" % (nx, ny, nz, nx, ny, nz),
+            "scaling_definition": ("weak: every rank owns a %dx%dx%d slab of a %dx%dx(%d*N) channel cut along z; value = N x (10.24M-cell SIMPLE "
+                                   "iterations per second), i.e. cells processed per second / 10.24M" % (nx, ny, nz, nx, ny, nz)) if not mixed else
+                                  ("weak: every rank generates and owns %d block layers of a %dx%dx(%d*N)-block mixed channel cut along z (cells by centroid; "
+                                   "two generated ghost layers per inner side, no process holds the whole mesh); value = N x SIMPLE iterations per second"
+                                   % (nz, nx, ny, nz)),
             "step_definition": "restore the device-side snapshot taken after %d spin-up iterations (0.57 GB device-to-device, inside the "
                                "timed region) + one full SIMPLE iteration; every step does identical work" % SPIN_UP,
             "vs_baseline": None,
@@ -312,10 +387,12 @@ def main():
             "status": int(st),
             "step_ms": [round(x, 2) for x in step_ms],
             "config": {
-                "workload": "%s: synthetic hex channel %dx%dx%d per GPU (%d cells total), TVD-%s momentum, "
+                "workload": "%s: synthetic %s %dx%dx%d per GPU (%d cells total), TVD-%s momentum, "
                             "Rhie-Chow + SecondOrder, solver=%s (%d inner iterations) + Jacobi preconditioner, relaxation u %.3g / p %.3g, "
-                            "full SIMPLE iteration" % (workload_name, nx, ny, nz, n_cells_total, args.momentum.upper(), args.solver, args.inner,
+                            "full SIMPLE iteration" % (workload_name, "mixed tet / pyramid / prism / hex / polyhedral channel, blocks" if mixed else "hex channel",
+                                                       nx, ny, nz, n_cells_total, args.momentum.upper(), args.solver, args.inner,
                                                        args.momentum_relaxation, args.pressure_relaxation),
+                "mixed_mesh": mixed_facts,
                 "cells_total": int(n_cells_total),
                 "parallelism": ("cell slabs x%d, halo exchange + all-reduce over %s" % (world, "the host-staged debug transport (gloo; ranks share one GPU: a "
                                 "rehearsal, not a measurement)" if host_transport else "RCCL (ncclSend/ncclRecv + ncclAllReduce over xGMI)")) if world > 1 else "single GPU",
@@ -367,7 +444,7 @@ def main():
             "breakdown_guard_events_in_timed_region": int(guard_events_timed),
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(settings_kw)
+            out["cpu_baseline"] = cpu_baseline(settings_kw, iters=3 if mixed else 6, mixed_ref_cells=(n_cells_total // world) if mixed else None)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -89,6 +89,18 @@ OrcPartition *orc_mesh_partition(int64_t n_cells, int64_t n_faces, const int64_t
                                  const double *face_area, const double *face_normal, const double *face_centroid,
                                  const double *cell_centroid, const double *cell_volume, const int64_t *cell_face_ptr,
                                  const int64_t *cell_faces, int32_t n_ranks, int32_t rank, int32_t ordering, int *status);
+/* [r04] The same for a mesh a rank generated or read FOR ITSELF (its share of the cells plus ghost layers): the caller names the
+ * owner of every cell (cell_owner[n_cells]: a rank, or -1 = nobody's — e.g. the outer of two generated ghost layers; such a cell
+ * may not touch a cell of `rank`), the cells keep their order, n_global is the cell count of the whole mesh (< 0: n_cells).
+ * No process ever holds the whole mesh: BASELINE configs[4] (40 M mixed cells on 8 GPUs) generates 1/8 + two block layers per
+ * side on every rank.  The two ranks of a cut must number the cells they share in the same relative order (generators that
+ * number layer by layer do; tests/test_partition_cpu.py exchanges global ids over gloo to check it).  global_ids are indices
+ * into the caller's own arrays. */
+OrcPartition *orc_mesh_partition_owner(int64_t n_cells, int64_t n_faces, const int64_t *face_c0, const int64_t *face_c1, const int32_t *face_zone,
+                                       const double *face_area, const double *face_normal, const double *face_centroid,
+                                       const double *cell_centroid, const double *cell_volume, const int64_t *cell_face_ptr,
+                                       const int64_t *cell_faces, const int32_t *cell_owner, int32_t n_ranks, int32_t rank, int64_t n_global,
+                                       int *status);
 void orc_partition_destroy(OrcPartition *p);
 int orc_partition_sizes(const OrcPartition *p, int64_t *n_owned, int64_t *n_local, int64_t *n_global, int64_t *n_faces, int64_t *n_cell_faces,
                         int32_t *n_peers, int64_t *n_send);
@@ -308,6 +320,9 @@ long long orc_debug_xsort_products(void);
  * orc_amg_coarsen (same kernels), so a test can evaluate the same product on the oracle. */
 int orc_debug_amg_coarse_product(int64_t n, const int64_t *row_ptr, const int64_t *col_idx, const double *values, int scaled, const double *x,
                                  double *y, int *has_window_mirror);
+/* collectives this process has issued since the last reset — halo exchanges (one grouped ncclSend/ncclRecv launch each) and
+ * all-reduces, status agreements included: the latency-bound messages of a partitioned SIMPLE iteration */
+long long orc_debug_collectives(int reset);
 int orc_debug_clamp_partials_grid(long long requested);
 int orc_debug_max_partials(void);
 int orc_debug_amg_certification(long long out[2], int reset);

@@ -2614,11 +2614,15 @@ int multigrid_arm3_dev(const MatView3 &A3, const double *const b[3], double *con
     const int64_t n = A3.P.n;
     for (int k = 0; k < 3; ++k) status_out[k] = ORC_OK;
     if (n == 0) return ORC_OK;
-    if (!triple_supported()) return set_error(ORC_ERR_BAD_ARGUMENT, "three-system solve: tree reductions on one GPU only");
+    if (!triple_supported()) return set_error(ORC_ERR_BAD_ARGUMENT, "three-system solve: tree reductions only");
     Ctx &g = ctx();
     hipStream_t st = g.stream;
     ArenaScope scope(arena);
     const size_t n3 = (size_t)3 * (size_t)n;
+    // [r04] partitioned mesh (A3.halo): level 0 exchanges the interleaved iterate's ghost entries and all-reduces its sums (every RCCL
+    // call on the library stream, issued by this thread); the hierarchies and every coarse level are rank-local as in the
+    // one-system path (ghost columns are never partners and are dropped from the Galerkin products).  x[k] hold ncols entries.
+    const size_t ncols3 = (size_t)3 * (size_t)std::max<int64_t>(A3.P.ncols, n);
     const MgParams mp{3 /* MULTIGRID_COARSENING_LEVELS, :10 */, iteration_count, ORC_SOLVER_BICGSTAB, preconditioner, relaxation_factor, convergence_threshold};
 
     // ---- hierarchies: one thread per system, from now on (they need the matrices only)
@@ -2628,6 +2632,7 @@ int multigrid_arm3_dev(const MatView3 &A3, const double *const b[3], double *con
         plain[k].val = A3.val[k];
         plain[k].symmetric = lanes[k].symmetric;
         plain[k].persistent_pattern = true;
+        plain[k].halo = A3.halo;  // (nothing below exchanges through it: the set-up and the coarse parts are rank-local)
     }
     ORC_HIP(hipStreamSynchronize(st));  // the assembled matrices are complete before other streams read them
     Ctx local[3];
@@ -2647,6 +2652,13 @@ int multigrid_arm3_dev(const MatView3 &A3, const double *const b[3], double *con
         if (stp == ORC_OK) stp = multigrid_prepare_dev(plain[k], preconditioner, *lanes[k].hier_arena, lanes[k].hierarchy, sibling, k == 0 ? 1 : 2, lanes[k].scratch_arena);
         if (k == 0 && sibling) sibling->finish();  // whatever happened to u: v and w must not wait for a level that will not come
         if (hipStreamSynchronize(local[k].stream) != hipSuccess && stp == ORC_OK) stp = set_error(ORC_ERR_HIP, "stream synchronisation failed in a set-up thread");
+        // test hook (tests/mp_worker.py, mode gpu_lane_error): ORC_DEBUG_INJECT_LANE_ERROR="rank:lane" fails that rank's set-up thread
+        // locally — the level-0 collectives of every rank still complete and the caller's status agreement tells all of them
+        if (const char *inj = getenv("ORC_DEBUG_INJECT_LANE_ERROR")) {
+            int r_ = -1, k_ = -1;
+            if (sscanf(inj, "%d:%d", &r_, &k_) == 2 && r_ == local[k].rank && k_ == k && stp == ORC_OK)
+                stp = set_error(ORC_ERR_HIP, "injected lane error (rank %d, lane %d)", r_, k_);
+        }
         st_prep[k] = stp;
         prepared[k] = true;
     };
@@ -2677,7 +2689,7 @@ int multigrid_arm3_dev(const MatView3 &A3, const double *const b[3], double *con
     double *b3, *x3, *r3;
     int *dev_status;
     ORC_TRY(arena.alloc(n3, &b3));
-    ORC_TRY(arena.alloc(n3, &x3));
+    ORC_TRY(arena.alloc(ncols3, &x3));
     ORC_TRY(arena.alloc(n3, &r3));
     ORC_TRY(arena.alloc((size_t)4, &dev_status));
     ORC_HIP(hipMemsetAsync(dev_status, 0, 4 * sizeof(int), st));

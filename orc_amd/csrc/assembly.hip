@@ -1461,6 +1461,10 @@ static int solve_momentum_triple(SolverState &s, const std::function<void()> &on
     A3.P = s.mesh->pat.dev();
     A3.val[0] = s.a_u.p; A3.val[1] = s.a_v.p; A3.val[2] = s.a_w.p;
     A3.mesh_pattern = true;
+    if (s.mesh->halo.active()) {  // [r04] cell-partitioned mesh: one halo exchange and one all-reduce per step for the three systems
+        A3.halo = &s.mesh->halo;
+        g.reduction_order = ORC_REDUCTION_TREE;  // partitioned operators always reduce as trees + all-reduce
+    }
     const double *b[3] = {s.b_u.p, s.b_v.p, s.b_w.p};
     double *x[3] = {s.u.p, s.v.p, s.w.p};
     if (s.arena.empty()) ORC_TRY(s.arena.reset());
@@ -1469,7 +1473,7 @@ static int solve_momentum_triple(SolverState &s, const std::function<void()> &on
         const size_t n3 = (size_t)3 * (size_t)s.n_own;
         double *b3, *x3;
         ORC_TRY(s.arena.alloc(n3, &b3));
-        ORC_TRY(s.arena.alloc(n3, &x3));
+        ORC_TRY(s.arena.alloc((size_t)3 * (size_t)s.n, &x3));  // with its ghost entries on a partitioned mesh
         ORC_TRY(interleave3_dev(b[0], b[1], b[2], b3, s.n_own));
         ORC_TRY(interleave3_dev(x[0], x[1], x[2], x3, s.n_own));
         ORC_TRY(bicgstab3_dev(A3, b3, x3, t.iterations, t.preconditioner, s.arena));
@@ -1540,8 +1544,12 @@ int solver_iterate(SolverState &s, uint64_t iterations, double *report) {
                               (method == ORC_SOLVER_MULTIGRID || method == ORC_SOLVER_BICGSTAB || method == ORC_SOLVER_JACOBI ||
                                method == ORC_SOLVER_MULTIGRID_GS || method == ORC_SOLVER_BICGSTAB_GS_PRECOND || method == ORC_SOLVER_MULTICOLOR_GS);
         const bool lanes_partitioned = s.concurrent_momentum && H.active() && !dbg && !ctx().profile && method == ORC_SOLVER_MULTIGRID;
-        const bool triple_ok = lanes_ok && s.triple_momentum && triple_supported() && s.settings.reduction_order != ORC_REDUCTION_REFERENCE &&
-                               (method == ORC_SOLVER_MULTIGRID || method == ORC_SOLVER_BICGSTAB);
+        // [r04] the lock-step schedule also on a partitioned mesh (tree reductions there by construction): N > 1 runs the schedule of the
+        // N = 1 headline, with a third of the momentum phase's halo exchanges and all-reduces (ORC_TRIPLE_MOMENTUM=0: one system per solve)
+        const bool triple_part = s.concurrent_momentum && H.active() && !dbg && !ctx().profile && s.triple_momentum && triple_supported() &&
+                                 (method == ORC_SOLVER_MULTIGRID || method == ORC_SOLVER_BICGSTAB);
+        const bool triple_ok = (lanes_ok && s.triple_momentum && triple_supported() && s.settings.reduction_order != ORC_REDUCTION_REFERENCE &&
+                                (method == ORC_SOLVER_MULTIGRID || method == ORC_SOLVER_BICGSTAB)) || triple_part;
         // The p' hierarchy is needed after the momentum solves.  Beside the per-system lanes it is built from the start; in the
         // lock-step schedule the momentum set-ups are the critical path of the first phase (nothing bandwidth-bound but the
         // level-0 solve runs beside them), so it starts when they are through and runs beside the bandwidth-bound coarse levels.
@@ -1554,7 +1562,11 @@ int solver_iterate(SolverState &s, uint64_t iterations, double *report) {
         }
         if (triple_ok) {
             // :99-136, the three systems in lock-step on their shared pattern
-            ORC_TRY(solve_momentum_triple(s, p_late ? std::function<void()>([&] { prep.start(s); }) : std::function<void()>()));
+            int st3 = solve_momentum_triple(s, p_late ? std::function<void()>([&] { prep.start(s); }) : std::function<void()>());
+            // partitioned: a rank whose set-up thread or coarse level failed locally has still taken part in every level-0 collective;
+            // the verdict must be the same on every rank or they part ways at the next one
+            if (H.active()) st3 = comm_global_status(st3);
+            ORC_TRY(st3);
         } else if (lanes_ok) {
             static const int setup_first_env = getenv("ORC_SETUP_FIRST") ? atoi(getenv("ORC_SETUP_FIRST")) : 0;  // measured: exact, +8 % wall (1.24 s against 1.15 s)
             const bool setup_first = setup_first_env != 0 && method == ORC_SOLVER_MULTIGRID;

@@ -5,6 +5,8 @@
 // links, and the halo of a 10M-cell slab (64 000 doubles = 512 KB per field) is latency-, not link-bound.
 #include <rccl/rccl.h>
 
+#include <atomic>
+
 #include "halo.hpp"
 
 namespace orc {
@@ -16,6 +18,13 @@ static_assert(sizeof(ncclUniqueId) == ORC_COMM_ID_BYTES, "ncclUniqueId size");
         ncclResult_t r__ = (call);                                                                                  \
         if (r__ != ncclSuccess) return orc::set_error(ORC_ERR_COMM, "%s failed: %s", #call, ncclGetErrorString(r__)); \
     } while (0)
+
+static std::atomic<long long> g_collectives{0};
+long long comm_collectives(bool reset) {
+    const long long v = g_collectives.load(std::memory_order_relaxed);
+    if (reset) g_collectives.store(0, std::memory_order_relaxed);
+    return v;
+}
 
 static HostExchangeFn g_host_ex = nullptr;
 static HostAllreduceFn g_host_ar = nullptr;
@@ -39,6 +48,7 @@ static int host_allreduce(double *dev, int n, int op) {
 int comm_allreduce_sum(double *dev, int n) {
     Ctx &c = ctx();
     if (c.world <= 1) return ORC_OK;
+    g_collectives.fetch_add(1, std::memory_order_relaxed);
     if (g_host_ar) return host_allreduce(dev, n, 0);
     ORC_NCCL(ncclAllReduce(dev, dev, (size_t)n, ncclDouble, ncclSum, (ncclComm_t)c.nccl_comm, c.stream));
     return ORC_OK;
@@ -47,6 +57,7 @@ int comm_allreduce_sum(double *dev, int n) {
 int comm_allreduce_max(double *dev, int n) {
     Ctx &c = ctx();
     if (c.world <= 1) return ORC_OK;
+    g_collectives.fetch_add(1, std::memory_order_relaxed);
     if (g_host_ar) return host_allreduce(dev, n, 1);
     ORC_NCCL(ncclAllReduce(dev, dev, (size_t)n, ncclDouble, ncclMax, (ncclComm_t)c.nccl_comm, c.stream));
     return ORC_OK;
@@ -84,6 +95,7 @@ HaloPlan::~HaloPlan() {
 int HaloPlan::exchange(double *const *xs, int k) {
     Ctx &c = ctx();
     if (!active() || c.world <= 1) return ORC_OK;
+    g_collectives.fetch_add(1, std::memory_order_relaxed);
     ORC_TRY(send_buf.ensure((size_t)k * (size_t)n_send));
     for (int f = 0; f < k; ++f)
         hipLaunchKernelGGL(halo_pack_k, dim3(grid_for(n_send)), dim3(kBlock), 0, c.stream, xs[f], send_idx.p, send_buf.p + (size_t)f * n_send, n_send);
@@ -113,9 +125,50 @@ int HaloPlan::exchange(double *const *xs, int k) {
     return ORC_OK;
 }
 
+__global__ void halo_pack_w_k(const double *__restrict__ x, const int32_t *__restrict__ idx, double *__restrict__ buf, int64_t n, int w) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n * w; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t cell = i / w;
+        buf[i] = x[(int64_t)idx[cell] * w + (i - cell * w)];
+    }
+}
+
+int HaloPlan::exchange_interleaved(double *xw, int w) {
+    Ctx &c = ctx();
+    if (!active() || c.world <= 1) return ORC_OK;
+    if (w < 1) return set_error(ORC_ERR_BAD_ARGUMENT, "exchange_interleaved: width %d", w);
+    g_collectives.fetch_add(1, std::memory_order_relaxed);
+    ORC_TRY(send_buf.ensure((size_t)w * (size_t)n_send));
+    hipLaunchKernelGGL(halo_pack_w_k, dim3(grid_for(n_send * w)), dim3(kBlock), 0, c.stream, xw, send_idx.p, send_buf.p, n_send, w);
+    ORC_HIP(hipGetLastError());
+    const int np = (int)peers.size();
+    if (g_host_ex) {
+        h_send.resize((size_t)w * (size_t)n_send);
+        h_recv.resize((size_t)w * (size_t)n_ghost);
+        std::vector<int64_t> so(send_off), sc(send_cnt), ro(recv_off), rc(recv_cnt);
+        for (int q = 0; q < np; ++q) { so[q] *= w; sc[q] *= w; ro[q] *= w; rc[q] *= w; }
+        ORC_HIP(hipMemcpyAsync(h_send.data(), send_buf.p, sizeof(double) * h_send.size(), hipMemcpyDeviceToHost, c.stream));
+        ORC_HIP(hipStreamSynchronize(c.stream));
+        g_host_ex(np, peers.data(), h_send.data(), so.data(), sc.data(), h_recv.data(), ro.data(), rc.data(), g_host_user);
+        ORC_HIP(hipMemcpyAsync(xw + (size_t)w * n_own, h_recv.data(), sizeof(double) * h_recv.size(), hipMemcpyHostToDevice, c.stream));
+        ORC_HIP(hipStreamSynchronize(c.stream));
+        return ORC_OK;
+    }
+    ORC_NCCL(ncclGroupStart());
+    for (int q = 0; q < np; ++q) {
+        if (send_cnt[q] > 0)
+            ORC_NCCL(ncclSend(send_buf.p + (size_t)w * send_off[q], (size_t)w * send_cnt[q], ncclDouble, peers[q], (ncclComm_t)c.nccl_comm, c.stream));
+        if (recv_cnt[q] > 0)
+            ORC_NCCL(ncclRecv(xw + (size_t)w * (n_own + recv_off[q]), (size_t)w * recv_cnt[q], ncclDouble, peers[q], (ncclComm_t)c.nccl_comm, c.stream));
+    }
+    ORC_NCCL(ncclGroupEnd());
+    return ORC_OK;
+}
+
 }  // namespace orc
 
 extern "C" {
+
+long long orc_debug_collectives(int reset) { return orc::comm_collectives(reset != 0); }
 
 int orc_comm_get_unique_id(unsigned char id[ORC_COMM_ID_BYTES]) {
     ncclUniqueId uid;

@@ -33,7 +33,13 @@ struct HaloPlan {
     // exchange the ghost entries of k vectors (each n_own + n_ghost long) in one grouped launch
     int exchange(double *const *xs, int k);
     int exchange(double *x) { return exchange(&x, 1); }
+    // [r04] ONE vector of w interleaved doubles per cell (x[w * cell + s]: the lock-step momentum solve's u, v, w iterates,
+    // MatView3): one pack launch, one message per peer of w times the cells — a third of the exchanges of three one-system solves
+    int exchange_interleaved(double *xw, int w);
 };
+// collectives issued by this process since the last reset (halo exchanges, all-reduces incl. status agreements): what a SIMPLE
+// iteration costs in latency-bound messages (orc_debug_collectives)
+long long comm_collectives(bool reset);
 
 int comm_allreduce_sum(double *dev, int n);
 int comm_allreduce_max(double *dev, int n);

@@ -76,33 +76,55 @@ __device__ __forceinline__ double fold_partials_block(const double *__restrict__
 // association of nalgebra 0.32.4's `dotx` (base/blas.rs): eight running accumulators
 // over blocks of 8, folded as res += (acc0+acc4); (acc1+acc5); (acc2+acc6); (acc3+acc7), then the tail left to right.
 // Lane k of one wavefront owns accumulator k and walks its elements in order — n/8 dependent additions, so this is a
-// slow path (microseconds per thousand rows); it exists so that a device solve can be compared with the reference's
+// slow path (milliseconds per ten million rows); it exists so that a device solve can be compared with the reference's
 // arithmetic BIT FOR BIT at any iteration count, instead of through tolerances that the unguarded r_hat_0 = 1
 // BiCGSTAB (linear_algebra.rs:252) amplifies.  a == nullptr stands for the all-ones r_hat_0 (1.0 * b[i] == b[i]).
-__global__ __launch_bounds__(64) void dot_reference_k(const double *__restrict__ a, const double *__restrict__ b, int64_t n,
-                                                      double *__restrict__ out, const double *__restrict__ skip_flags) {
+// [r04] The n/8 dependent additions per accumulator are the floor (about 4 ms for 10.24 M elements); r02/r03's kernel paid a
+// global-memory round trip per eight blocks on top of it (0.2 s per dot product at that size: ten minutes per SIMPLE iteration of
+// the benchmark in this mode).  Now the products a[i] * b[i] are formed by fifteen loader wavefronts, coalesced, into a double-
+// buffered LDS tile (the multiplication is element-wise: who performs it changes nothing), while lanes 0-7 of wavefront 0 walk the
+// previous tile in order.  Same accumulators, same order of additions, same final fold: every bit as before.
+constexpr int kDotTile = 4096;  // elements per LDS tile (2 x 32 KB)
+__global__ __launch_bounds__(1024) void dot_reference_k(const double *__restrict__ a, const double *__restrict__ b, int64_t n,
+                                                        double *__restrict__ out, const double *__restrict__ skip_flags) {
+    __shared__ double tile[2][kDotTile];
     if (skip_flags && (skip_flags[0] != 0. || skip_flags[1] != 0.)) return;
-    const int lane = threadIdx.x;
-    const int64_t blocks = n >> 3;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t n8 = (n >> 3) << 3;  // elements in whole blocks of eight
+    const int64_t n_tiles = (n8 + kDotTile - 1) / kDotTile;
+    auto load = [&](int64_t t, int first, int stride) {  // products of tile t into tile[t & 1]
+        double *dst = tile[t & 1];
+        const int64_t base = t * kDotTile;
+        for (int e = first; e < kDotTile; e += stride) {
+            const int64_t i = base + e;
+            if (i < n8) dst[e] = (a ? a[i] : 1.) * b[i];
+        }
+    };
     double acc = 0.;
-    if (lane < 8) {
-        int64_t j = 0;
-        for (; j + 8 <= blocks; j += 8) {  // eight blocks' loads in flight, additions in block order
-            double pa[8], pb[8];
+    if (n_tiles > 0) load(0, tid, 1024);
+    __syncthreads();
+    for (int64_t t = 0; t < n_tiles; ++t) {
+        if (wave == 0) {
+            if (lane < 8) {
+                const double *src = tile[t & 1] + lane;
+                const int64_t left = n8 - t * kDotTile;
+                const int cnt = (int)((left < kDotTile ? left : kDotTile) >> 3);  // blocks in this tile
+                int j = 0;
+                for (; j + 16 <= cnt; j += 16) {
+                    double v[16];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int64_t i = ((j + q) << 3) + lane;
-                pb[q] = b[i];
-                pa[q] = a ? a[i] : 1.;
+                    for (int q = 0; q < 16; ++q) v[q] = src[(j + q) << 3];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc += v[q];
+                }
+                for (; j < cnt; ++j) acc += src[j << 3];
             }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) acc += pa[q] * pb[q];
+        } else if (t + 1 < n_tiles) {
+            load(t + 1, tid - 64, 960);
         }
-        for (; j < blocks; ++j) {
-            const int64_t i = (j << 3) + lane;
-            acc += (a ? a[i] : 1.) * b[i];
-        }
+        __syncthreads();
     }
+    if (wave != 0) return;
     // lane k < 4 forms acc_k + acc_{k+4}; lane 0 adds the four pairs and the tail in order
     const double hi = __shfl_down(acc, 4, 64);
     const double pair = acc + hi;
@@ -113,13 +135,13 @@ __global__ __launch_bounds__(64) void dot_reference_k(const double *__restrict__
         res += p1;
         res += p2;
         res += p3;
-        for (int64_t k = blocks << 3; k < n; ++k) res += (a ? a[k] : 1.) * b[k];
+        for (int64_t k = n8; k < n; ++k) res += (a ? a[k] : 1.) * b[k];
         out[0] = res;
     }
 }
 
 int dot_reference(const double *a, const double *b, int64_t n, double *out, const double *skip_flags) {
-    hipLaunchKernelGGL(dot_reference_k, dim3(1), dim3(64), 0, ctx().stream, a, b, n, out, skip_flags);
+    hipLaunchKernelGGL(dot_reference_k, dim3(1), dim3(1024), 0, ctx().stream, a, b, n, out, skip_flags);
     ORC_HIP(hipGetLastError());
     return ORC_OK;
 }
@@ -890,7 +912,7 @@ int bench_bicgstab_dev(const MatView &A, const double *b, double *x, int reps, A
 // below keeps, per system, the thread -> element map, the order of the additions and the fold of its one-system
 // counterpart above, so a system solved here and the same system solved alone agree in every bit
 // (tests/test_gpu_triple.py).  Scalars of system s: scal3[idx * 3 + s].
-bool triple_supported() { return ctx().reduction_order != ORC_REDUCTION_REFERENCE && ctx().world == 1; }
+bool triple_supported() { return ctx().reduction_order != ORC_REDUCTION_REFERENCE; }
 
 struct EpiStore3 {
     static constexpr int kReductions = 0;
@@ -948,6 +970,7 @@ static int launch_spmv3(const MatView3 &A_in, const double *x3, const Epi3 &epi,
     const int g = spmv_grid(A.P.n_slices);  // the one-system grid: same walk, same partial sums
     if (grid_out) *grid_out = g;
     if (A.P.n == 0) return ORC_OK;
+    if (A.halo) ORC_TRY(A.halo->exchange_interleaved(const_cast<double *>(x3), 3));  // C1: the ghost entries of the three systems in one message per peer
     static const int chunk = getenv("ORC_SPMV3_CHUNK") ? atoi(getenv("ORC_SPMV3_CHUNK")) : 4;
     if (chunk == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 8>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
     else if (chunk == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 2>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
@@ -975,15 +998,15 @@ static double *triple_scratch() {  // partial sums nobody reads (residual3_dev);
     }();
     return p;
 }
-int residual3_dev(const MatView3 &A, const double *b3, const double *x3, double *r3) {
+int residual3_dev(const MatView3 &A, const double *b3, double *x3, double *r3) {
     double *dummy = triple_scratch();
     if (!dummy) return set_error(ORC_ERR_HIP, "hipMalloc of the residual scratch failed");
     return launch_spmv3(A, x3, EpiResidual3{b3, r3, nullptr}, dummy, nullptr);
 }
-int residual_norm2_3_dev(const MatView3 &A, const double *b3, const double *x3, double *partials, double *out3) {
+int residual_norm2_3_dev(const MatView3 &A, const double *b3, double *x3, double *partials, double *out3) {
     int g = 0;
     ORC_TRY(launch_spmv3(A, x3, EpiResidualNorm3{b3}, partials, &g));
-    return reduce_partials(partials, g, 3, out3, false);
+    return reduce_partials(partials, g, 3, out3, A.halo != nullptr);
 }
 
 __global__ void interleave3_k(const double *__restrict__ a, const double *__restrict__ b, const double *__restrict__ c, double *__restrict__ out3, int64_t n) {
@@ -1092,7 +1115,8 @@ __global__ __launch_bounds__(kBlock) void bicg_s3_k(double *__restrict__ scal3, 
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
         const bool frz = bicg_frozen3(scal3, s, guard);
-        const double sum_nu = fold_partials_block(fold + (size_t)s * fold_count, fold_count, lds16);
+        // fold_count == 0 (partitioned operator): fold holds the sums themselves — folded by reduce_partials_k, summed over the ranks
+        const double sum_nu = fold_count ? fold_partials_block(fold + (size_t)s * fold_count, fold_count, lds16) : fold[s];
         const double rho = scal3[SC3(rho_idx, s)];
         alpha[s] = rho / sum_nu;
         const bool bad = guard && !(finite_nonzero(rho) && finite_nonzero(sum_nu) && isfinite(alpha[s]));
@@ -1143,8 +1167,8 @@ __global__ __launch_bounds__(kBlock) void bicg_xr3_k(double *__restrict__ scal3,
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
         const bool frz = guard && scal3[SC3(S_FROZEN, s)] != 0.;
-        const double ts = fold_partials_block(fold + (size_t)(2 * s) * fold_count, fold_count, lds16);
-        const double tt = fold_partials_block(fold + (size_t)(2 * s + 1) * fold_count, fold_count, lds16);
+        const double ts = fold_count ? fold_partials_block(fold + (size_t)(2 * s) * fold_count, fold_count, lds16) : fold[2 * s];
+        const double tt = fold_count ? fold_partials_block(fold + (size_t)(2 * s + 1) * fold_count, fold_count, lds16) : fold[2 * s + 1];
         alpha[s] = scal3[SC3(rho_idx, s)] / scal3[SC3(S_SUM_NU, s)];
         omega[s] = ts / tt;
         const bool bad = guard && !(finite_nonzero(tt) && isfinite(omega[s]));
@@ -1243,7 +1267,7 @@ __global__ __launch_bounds__(kBlock) void bicg_p3_k(double *__restrict__ scal3, 
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
         const bool frz = bicg_frozen3(scal3, s, guard);
-        const double rho = fold_partials_block(fold + (size_t)s * fold_count, fold_count, lds16);
+        const double rho = fold_count ? fold_partials_block(fold + (size_t)s * fold_count, fold_count, lds16) : fold[s];
         const double rho_prev = scal3[SC3(rho_prev_idx, s)];
         const double alpha = rho_prev / scal3[SC3(S_SUM_NU, s)];
         omega[s] = scal3[SC3(S_TS, s)] / scal3[SC3(S_TT, s)];
@@ -1294,9 +1318,14 @@ __global__ void guard_event3_k(const double *__restrict__ scal3, int *__restrict
 int bicgstab3_dev(const MatView3 &A_in, const double *b3_in, double *x3, uint64_t iteration_count, int preconditioner, Arena &arena) {
     const int64_t n = A_in.P.n;
     if (n == 0) return ORC_OK;
-    if (!triple_supported()) return set_error(ORC_ERR_BAD_ARGUMENT, "three-system solve: tree reductions on one GPU only");
+    if (!triple_supported()) return set_error(ORC_ERR_BAD_ARGUMENT, "three-system solve: tree reductions only");
     ArenaScope scope(arena);
     const size_t n3 = (size_t)3 * (size_t)n;
+    // partitioned operator (A.halo): the vectors that ENTER a product (x3 — the caller's —, p3, s3) carry their ghost entries:
+    // 3 * ncols doubles; the three sums of an iteration are folded by one-workgroup launches and summed over the ranks by one
+    // all-reduce each (reduce_partials: 3, 6 and 3 scalars) instead of being folded by their consumers
+    const bool part = A_in.halo != nullptr && ctx().world > 1;
+    const size_t nc3 = (size_t)3 * (size_t)std::max<int64_t>(A_in.P.ncols, n);
     MatView3 A = A_in;
     const double *b3 = b3_in;
     if (preconditioner == ORC_PRECOND_JACOBI) {  // :159-167, as iterative_solve_body does it
@@ -1314,31 +1343,36 @@ int bicgstab3_dev(const MatView3 &A_in, const double *b3_in, double *x3, uint64_
     }
     ORC_TRY(materialize_scaled_view3(A, iteration_count, arena));
     double *r3, *p3, *nu3, *s3, *t3, *partials, *partials2, *scal3;
+    double *sums;  // partitioned: the folded and all-reduced sums of the launch before (6 doubles)
     ORC_TRY(arena.alloc(n3, &r3));
-    ORC_TRY(arena.alloc(n3, &p3));
+    ORC_TRY(arena.alloc(nc3, &p3));
     ORC_TRY(arena.alloc(n3, &nu3));
-    ORC_TRY(arena.alloc(n3, &s3));
+    ORC_TRY(arena.alloc(nc3, &s3));
     ORC_TRY(arena.alloc(n3, &t3));
     ORC_TRY(arena.alloc((size_t)6 * kMaxPartials, &partials));
     ORC_TRY(arena.alloc((size_t)3 * kMaxPartials, &partials2));
     ORC_TRY(arena.alloc((size_t)3 * S_COUNT, &scal3));
+    ORC_TRY(arena.alloc((size_t)8, &sums));
     hipStream_t st = ctx().stream;
     ORC_HIP(hipMemsetAsync(scal3, 0, 3 * S_COUNT * sizeof(double), st));
     const int guard = ctx().breakdown_guard ? 1 : 0;
     const int vg = grid_for((n + 1) / 2);
     int g = 0;
     ORC_TRY(launch_spmv3(A, x3, EpiResidual3{b3, r3, p3}, partials, &g));  // r = b - A x ; p = r ; rho = sum(r)   (:250-254)
-    ORC_TRY(reduce_partials(partials, g, 3, scal3 + SC3(S_RHO0, 0), false));
+    ORC_TRY(reduce_partials(partials, g, 3, scal3 + SC3(S_RHO0, 0), part));
     for (uint64_t it = 0; it < iteration_count; ++it) {
         const int cur = (int)(it & 1), nxt = cur ^ 1;
         ORC_TRY(launch_spmv3(A, p3, EpiStoreSum3{nu3}, partials, &g));                                   // nu = A p, sum(nu)   (:256-257)
+        if (part) ORC_TRY(reduce_partials(partials, g, 3, sums, true));                                  // C2: one all-reduce for the three systems
         hipLaunchKernelGGL(bicg_s3_k, dim3(vg), dim3(kBlock), 0, st, scal3, S_RHO0 + cur, (const double *)r3, (const double *)nu3, s3, n, guard,
-                           (const double *)partials, g);                                                 // s = r - alpha nu    (:259)
+                           part ? (const double *)sums : (const double *)partials, part ? 0 : g);        // s = r - alpha nu    (:259)
         ORC_TRY(launch_spmv3(A, s3, EpiTs3{s3, t3}, partials, &g));                                      // t = A s, t.s, t.t   (:260-261)
+        if (part) ORC_TRY(reduce_partials(partials, g, 6, sums, true));
         hipLaunchKernelGGL(bicg_xr3_k, dim3(vg), dim3(kBlock), 0, st, scal3, S_RHO0 + cur, x3, (const double *)p3, (const double *)s3, (const double *)t3, r3,
-                           n, partials2, guard, (const double *)partials, g);                            // x, r, sum(r)        (:258, :262-265)
+                           n, partials2, guard, part ? (const double *)sums : (const double *)partials, part ? 0 : g);  // x, r, sum(r)  (:258, :262-265)
+        if (part) ORC_TRY(reduce_partials(partials2, vg, 3, sums, true));
         hipLaunchKernelGGL(bicg_p3_k, dim3(vg), dim3(kBlock), 0, st, scal3, S_RHO0 + cur, S_RHO0 + nxt, (const double *)r3, (const double *)nu3, p3, n,
-                           guard, (const double *)partials2, vg);                                        // p                   (:266-267)
+                           guard, part ? (const double *)sums : (const double *)partials2, part ? 0 : vg);  // p                   (:266-267)
     }
     ORC_HIP(hipGetLastError());
     if (guard && ctx().guard_events) {

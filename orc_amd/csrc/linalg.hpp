@@ -125,6 +125,10 @@ struct MatView3 {
     const double *s1 = nullptr, *s2 = nullptr;  // row scalings, interleaved [3 n] (MatView::s1 / s2 per system)
     bool mesh_pattern = false;                  // level 0 (kernel-name tag only, see spmv_uniform_k's kMesh)
     int nt = 0;                                 // set by the launch (MatView::nt)
+    // [r04] partitioned level-0 operator (MatView::halo): the interleaved input vector holds 3 * P.ncols doubles, its ghost entries are
+    // refreshed by ONE exchange of 24 bytes per cell before every product, the reductions are summed over the ranks in one all-reduce
+    // of 3 (or 6) scalars — a third of the collectives of three one-system solves (solver.rs:99-136 on a cell-partitioned mesh)
+    HaloPlan *halo = nullptr;
 };
 
 // Owning pattern (built on the host from CSR, e.g. the mesh pattern or a user matrix).
@@ -262,9 +266,10 @@ int interleave3_dev(const double *a, const double *b, const double *c, double *o
 int deinterleave3_dev(const double *in3, double *a, double *b, double *c, int64_t n);
 int diag_inverse3_dev(const MatView3 &A, double *dinv3);
 int spmv3_dev(const MatView3 &A, const double *x3, double *y3);
-int residual3_dev(const MatView3 &A, const double *b3, const double *x3, double *r3);
+int residual3_dev(const MatView3 &A, const double *b3, double *x3, double *r3);
 // out[s] = sum((b - A x)^2) of system s
-int residual_norm2_3_dev(const MatView3 &A, const double *b3, const double *x3, double *partials /* 3 * kMaxPartials */, double *out3);
+// (a partitioned operator: x3 holds 3 * P.ncols doubles and its ghost entries are refreshed first; out3 is summed over the ranks)
+int residual_norm2_3_dev(const MatView3 &A, const double *b3, double *x3, double *partials /* 3 * kMaxPartials */, double *out3);
 // iterative_solve's BiCGSTAB arm (linear_algebra.rs:247-269) with its Jacobi preconditioner (:159-167) for the three systems at
 // once; fixed iteration count, so the three stay in lock-step; the breakdown guard acts per system.  Tree reductions only.
 int bicgstab3_dev(const MatView3 &A, const double *b3, double *x3, uint64_t iteration_count, int preconditioner, Arena &arena);
@@ -278,7 +283,7 @@ int bench_inloop_products3_dev(const MatView3 &A, const double *x3, double *y3, 
 int matview_stream_nt(const MatView &A);  // the cache policy launch_spmv picks for this view's matrix streams (MatView::nt)
 int materialize_scaled_view(MatView &A, uint64_t iteration_count, Arena &arena);
 int materialize_scaled_view3(MatView3 &A, uint64_t iteration_count, Arena &arena);
-// is the triple path usable in the calling context (single GPU, tree reductions)?
+// is the triple path usable in the calling context (tree reductions; since r04 also on a partitioned mesh)?
 bool triple_supported();
 
 // One system's share of a three-system Multigrid solve: the streams its hierarchy set-up and its per-system coarse levels

@@ -84,6 +84,107 @@ void geometric_order(int64_t n, const double *cc, std::vector<int64_t> &seq) {
     std::stable_sort(seq.begin(), seq.end(), [&](int64_t a, int64_t b) { return cc[3 * a + axis] < cc[3 * b + axis]; });
 }
 
+// One rank's part of a mesh whose cells are put in the order `seq` (pos = its inverse) and given to ranks by `owner` (per CELL;
+// -1 = nobody's: such a cell may not touch a cell of `rank`).  Owned cells first in the order, then one ghost block per peer
+// (peers ascending, a block sorted by position), faces touching an owned cell in ascending id with the global orientation.
+OrcPartition *build_part(int64_t n, int64_t F, const int64_t *face_c0, const int64_t *face_c1, const int32_t *face_zone, const double *face_area,
+                         const double *face_normal, const double *face_centroid, const double *cell_centroid, const double *cell_volume,
+                         const int64_t *cell_face_ptr, const int64_t *cell_faces, const std::vector<int64_t> &ptr, const std::vector<int64_t> &adj,
+                         const std::vector<int64_t> &seq, const std::vector<int64_t> &pos, const std::vector<int32_t> &owner, int32_t n_ranks, int32_t rank,
+                         int64_t n_global, int *status) {
+    auto fail = [&](int code, const char *msg) -> OrcPartition * {
+        if (status) *status = set_error(code, "%s", msg);
+        return nullptr;
+    };
+    auto P = std::make_unique<OrcPartition>();
+    P->n_global = n_global;
+    // ---- owned cells in the order; ghost cells per peer (sorted by position) and my send lists
+    std::vector<int64_t> own_pos;  // positions of my cells, ascending
+    for (int64_t p = 0; p < n; ++p)
+        if (owner[(size_t)seq[(size_t)p]] == rank) own_pos.push_back(p);
+    P->n_owned = (int64_t)own_pos.size();
+    std::vector<int64_t> own_local((size_t)n, -1);  // cell -> local id of an owned cell
+    for (int64_t l = 0; l < P->n_owned; ++l) own_local[(size_t)seq[(size_t)own_pos[(size_t)l]]] = l;
+    std::vector<std::vector<int64_t>> ghost((size_t)n_ranks), send((size_t)n_ranks);  // positions / local ids
+    for (int64_t l = 0; l < P->n_owned; ++l) {
+        const int64_t c = seq[(size_t)own_pos[(size_t)l]];
+        for (int64_t q = ptr[(size_t)c]; q < ptr[(size_t)c + 1]; ++q) {
+            const int64_t nb = adj[(size_t)q];
+            const int o = owner[(size_t)nb];
+            if (o == rank) continue;
+            if (o < 0 || o >= n_ranks) return fail(ORC_ERR_BAD_ARGUMENT, "a cell of this rank touches a cell that belongs to no rank");
+            ghost[(size_t)o].push_back(pos[(size_t)nb]);
+            send[(size_t)o].push_back(l);
+        }
+    }
+    P->recv_ptr.push_back(0);
+    P->send_ptr.push_back(0);
+    std::vector<std::pair<int64_t, int64_t>> ghost_local;  // (position, local id), sorted by position
+    int64_t next_local = P->n_owned;
+    for (int r = 0; r < n_ranks; ++r) {
+        auto &g = ghost[(size_t)r];
+        auto &s = send[(size_t)r];
+        std::sort(g.begin(), g.end());
+        g.erase(std::unique(g.begin(), g.end()), g.end());
+        std::sort(s.begin(), s.end());
+        s.erase(std::unique(s.begin(), s.end()), s.end());
+        if (g.empty() && s.empty()) continue;
+        if (g.empty() != s.empty()) return fail(ORC_ERR_BAD_ARGUMENT, "asymmetric cell adjacency");  // cannot happen: faces are two-sided
+        P->peers.push_back(r);
+        for (int64_t pg : g) ghost_local.emplace_back(pg, next_local++);
+        P->recv_ptr.push_back(next_local - P->n_owned);
+        for (int64_t ls : s) P->send_idx.push_back(ls);
+        P->send_ptr.push_back((int64_t)P->send_idx.size());
+    }
+    P->n_local = next_local;
+    std::sort(ghost_local.begin(), ghost_local.end());
+    auto local_id = [&](int64_t cell) -> int64_t {
+        if (own_local[(size_t)cell] >= 0) return own_local[(size_t)cell];
+        const int64_t p = pos[(size_t)cell];
+        auto it = std::lower_bound(ghost_local.begin(), ghost_local.end(), std::make_pair(p, (int64_t)-1));
+        return (it != ghost_local.end() && it->first == p) ? it->second : -1;
+    };
+    // ---- cells
+    P->global_ids.resize((size_t)P->n_local);
+    for (int64_t l = 0; l < P->n_owned; ++l) P->global_ids[(size_t)l] = seq[(size_t)own_pos[(size_t)l]];
+    for (auto &gl : ghost_local) P->global_ids[(size_t)gl.second] = seq[(size_t)gl.first];
+    P->ccent.resize((size_t)3 * P->n_local);
+    P->vol.resize((size_t)P->n_local);
+    for (int64_t l = 0; l < P->n_local; ++l) {
+        const int64_t c = P->global_ids[(size_t)l];
+        for (int k = 0; k < 3; ++k) P->ccent[(size_t)(3 * l + k)] = cell_centroid[3 * c + k];
+        P->vol[(size_t)l] = cell_volume[c];
+    }
+    // ---- faces touching an owned cell, ascending global id, global orientation
+    std::vector<int64_t> local_face((size_t)F, -1);
+    auto owned = [&](int64_t cell) { return own_local[(size_t)cell] >= 0; };
+    for (int64_t f = 0; f < F; ++f) {
+        if (!(owned(face_c0[f]) || (face_c1[f] >= 0 && owned(face_c1[f])))) continue;
+        const int64_t l0 = local_id(face_c0[f]), l1 = face_c1[f] >= 0 ? local_id(face_c1[f]) : -1;
+        if (l0 < 0 || (face_c1[f] >= 0 && l1 < 0)) return fail(ORC_ERR_BAD_ARGUMENT, "a face of an owned cell has a neighbour outside the ghost layer");
+        local_face[(size_t)f] = (int64_t)P->face_c0.size();
+        P->global_face_ids.push_back(f);
+        P->face_c0.push_back(l0);
+        P->face_c1.push_back(l1);
+        P->face_zone.push_back(face_zone[f]);
+        P->area.push_back(face_area[f]);
+        for (int k = 0; k < 3; ++k) { P->normal.push_back(face_normal[3 * f + k]); P->fcent.push_back(face_centroid[3 * f + k]); }
+    }
+    // ---- face lists of the owned cells (Cell.face_indices: ascending face id, kept by the order-preserving renumbering)
+    P->cfp.assign((size_t)P->n_local + 1, 0);
+    for (int64_t l = 0; l < P->n_owned; ++l) {
+        const int64_t c = P->global_ids[(size_t)l];
+        for (int64_t q = cell_face_ptr[c]; q < cell_face_ptr[c + 1]; ++q) {
+            const int64_t lf = local_face[(size_t)cell_faces[q]];
+            if (lf < 0) return fail(ORC_ERR_BAD_ARGUMENT, "cell_faces names a face that does not touch its cell");
+            P->cf.push_back(lf);
+        }
+        P->cfp[(size_t)l + 1] = (int64_t)P->cf.size();
+    }
+    for (int64_t l = P->n_owned; l < P->n_local; ++l) P->cfp[(size_t)l + 1] = (int64_t)P->cf.size();
+    return P.release();
+}
+
 }  // namespace
 
 extern "C" {
@@ -112,98 +213,48 @@ OrcPartition *orc_mesh_partition(int64_t n_cells, int64_t n_faces, const int64_t
     else { seq.resize((size_t)n); std::iota(seq.begin(), seq.end(), 0); }
     std::vector<int64_t> pos((size_t)n);
     for (int64_t i = 0; i < n; ++i) pos[(size_t)seq[(size_t)i]] = i;
-    auto block_lo = [&](int r) { return (int64_t)((__int128)n * r / n_ranks); };
-    auto owner_of_pos = [&](int64_t p) {
-        int r = (int)((__int128)(p + 1) * n_ranks / std::max<int64_t>(n, 1));  // first guess, then correct
-        r = std::min(std::max(r, 0), n_ranks - 1);
-        while (r > 0 && p < block_lo(r)) --r;
-        while (r < n_ranks - 1 && p >= block_lo(r + 1)) ++r;
-        return r;
-    };
-    const int64_t lo = block_lo(rank), hi = block_lo(rank + 1);
-    auto P = std::make_unique<OrcPartition>();
-    P->n_owned = hi - lo;
-    P->n_global = n;
-    // ---- ghost cells per peer (sorted by position) and my send lists
-    std::vector<std::vector<int64_t>> ghost((size_t)n_ranks), send((size_t)n_ranks);  // positions
-    for (int64_t p = lo; p < hi; ++p) {
-        const int64_t c = seq[(size_t)p];
-        int last_peer = -1;
-        for (int64_t q = ptr[(size_t)c]; q < ptr[(size_t)c + 1]; ++q) {
-            const int64_t nb = adj[(size_t)q], pn = pos[(size_t)nb];
-            if (pn >= lo && pn < hi) continue;
-            const int o = owner_of_pos(pn);
-            ghost[(size_t)o].push_back(pn);
-            if (o != last_peer) { send[(size_t)o].push_back(p); last_peer = o; }
-        }
-    }
-    std::vector<int64_t> local_of_pos;  // for ghosts: map position -> local id (sparse: use a hash-free sorted lookup)
-    P->recv_ptr.push_back(0);
-    P->send_ptr.push_back(0);
-    std::vector<std::pair<int64_t, int64_t>> ghost_local;  // (position, local id), sorted by position
-    int64_t next_local = P->n_owned;
+    // n_ranks contiguous blocks of the order
+    std::vector<int32_t> owner((size_t)n);
     for (int r = 0; r < n_ranks; ++r) {
-        auto &g = ghost[(size_t)r];
-        auto &s = send[(size_t)r];
-        std::sort(g.begin(), g.end());
-        g.erase(std::unique(g.begin(), g.end()), g.end());
-        std::sort(s.begin(), s.end());
-        s.erase(std::unique(s.begin(), s.end()), s.end());
-        if (g.empty() && s.empty()) continue;
-        if (g.empty() != s.empty()) return fail(ORC_ERR_BAD_ARGUMENT, "asymmetric cell adjacency");  // cannot happen: faces are two-sided
-        P->peers.push_back(r);
-        for (int64_t pg : g) ghost_local.emplace_back(pg, next_local++);
-        P->recv_ptr.push_back(next_local - P->n_owned);
-        for (int64_t ps : s) P->send_idx.push_back(ps - lo);
-        P->send_ptr.push_back((int64_t)P->send_idx.size());
+        const int64_t lo = (int64_t)((__int128)n * r / n_ranks), hi = (int64_t)((__int128)n * (r + 1) / n_ranks);
+        for (int64_t p = lo; p < hi; ++p) owner[(size_t)seq[(size_t)p]] = r;
     }
-    P->n_local = next_local;
-    std::sort(ghost_local.begin(), ghost_local.end());
-    auto local_id = [&](int64_t cell) -> int64_t {
-        const int64_t p = pos[(size_t)cell];
-        if (p >= lo && p < hi) return p - lo;
-        auto it = std::lower_bound(ghost_local.begin(), ghost_local.end(), std::make_pair(p, (int64_t)-1));
-        return (it != ghost_local.end() && it->first == p) ? it->second : -1;
+    return build_part(n, F, face_c0, face_c1, face_zone, face_area, face_normal, face_centroid, cell_centroid, cell_volume, cell_face_ptr, cell_faces, ptr, adj,
+                      seq, pos, owner, n_ranks, rank, n, status);
+}
+
+// [r04] The same with the owner of every cell given by the caller (-1: nobody's — a cell this rank's mesh carries only because
+// its generator made it, e.g. the outer of two ghost layers; it may not touch an owned cell) and the cells kept in their own order.
+// This is what a rank calls on a mesh it generated or read FOR ITSELF — its share plus ghost layers — so that no process ever holds
+// the whole mesh (BASELINE configs[4]: 40 M cells on 8 GPUs).  A peer's ghost block of my cells and my send list to that peer are
+// the same cells in the same order provided the two ranks number the cells they share in the same relative order (generators that
+// number layer by layer do); parallel.py's world-N tests exchange global ids to check exactly that.  n_global: the cell count of
+// the whole mesh (the ranks' owned cells summed), for the report means.
+OrcPartition *orc_mesh_partition_owner(int64_t n_cells, int64_t n_faces, const int64_t *face_c0, const int64_t *face_c1, const int32_t *face_zone,
+                                       const double *face_area, const double *face_normal, const double *face_centroid,
+                                       const double *cell_centroid, const double *cell_volume, const int64_t *cell_face_ptr,
+                                       const int64_t *cell_faces, const int32_t *cell_owner, int32_t n_ranks, int32_t rank, int64_t n_global, int *status) {
+    auto fail = [&](int code, const char *msg) -> OrcPartition * {
+        if (status) *status = set_error(code, "%s", msg);
+        return nullptr;
     };
-    // ---- cells
-    P->global_ids.resize((size_t)P->n_local);
-    for (int64_t p = lo; p < hi; ++p) P->global_ids[(size_t)(p - lo)] = seq[(size_t)p];
-    for (auto &gl : ghost_local) P->global_ids[(size_t)gl.second] = seq[(size_t)gl.first];
-    P->ccent.resize((size_t)3 * P->n_local);
-    P->vol.resize((size_t)P->n_local);
-    for (int64_t l = 0; l < P->n_local; ++l) {
-        const int64_t c = P->global_ids[(size_t)l];
-        for (int k = 0; k < 3; ++k) P->ccent[(size_t)(3 * l + k)] = cell_centroid[3 * c + k];
-        P->vol[(size_t)l] = cell_volume[c];
-    }
-    // ---- faces touching an owned cell, ascending global id, global orientation
-    std::vector<int64_t> local_face((size_t)F, -1);
-    auto owned = [&](int64_t cell) { const int64_t p = pos[(size_t)cell]; return p >= lo && p < hi; };
-    for (int64_t f = 0; f < F; ++f) {
-        if (!(owned(face_c0[f]) || (face_c1[f] >= 0 && owned(face_c1[f])))) continue;
-        const int64_t l0 = local_id(face_c0[f]), l1 = face_c1[f] >= 0 ? local_id(face_c1[f]) : -1;
-        if (l0 < 0 || (face_c1[f] >= 0 && l1 < 0)) return fail(ORC_ERR_BAD_ARGUMENT, "a face of an owned cell has a neighbour outside the ghost layer");
-        local_face[(size_t)f] = (int64_t)P->face_c0.size();
-        P->global_face_ids.push_back(f);
-        P->face_c0.push_back(l0);
-        P->face_c1.push_back(l1);
-        P->face_zone.push_back(face_zone[f]);
-        P->area.push_back(face_area[f]);
-        for (int k = 0; k < 3; ++k) { P->normal.push_back(face_normal[3 * f + k]); P->fcent.push_back(face_centroid[3 * f + k]); }
-    }
-    // ---- face lists of the owned cells (Cell.face_indices: ascending face id, kept by the order-preserving renumbering)
-    P->cfp.assign((size_t)P->n_local + 1, 0);
-    for (int64_t l = 0; l < P->n_owned; ++l) {
-        const int64_t c = P->global_ids[(size_t)l];
-        for (int64_t q = cell_face_ptr[c]; q < cell_face_ptr[c + 1]; ++q) {
-            const int64_t lf = local_face[(size_t)cell_faces[q]];
-            if (lf < 0) return fail(ORC_ERR_BAD_ARGUMENT, "cell_faces names a face that does not touch its cell");
-            P->cf.push_back(lf);
-        }
-        P->cfp[(size_t)l + 1] = (int64_t)P->cf.size();
-    }
-    for (int64_t l = P->n_owned; l < P->n_local; ++l) P->cfp[(size_t)l + 1] = (int64_t)P->cf.size();
-    return P.release();
+    if (status) *status = ORC_OK;
+    if (n_cells < 0 || n_faces < 0 || !face_c0 || !face_c1 || !face_zone || !face_area || !face_normal || !face_centroid || !cell_centroid ||
+        !cell_volume || !cell_face_ptr || !cell_faces || !cell_owner)
+        return fail(ORC_ERR_BAD_ARGUMENT, "null argument");
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(ORC_ERR_BAD_ARGUMENT, "bad rank / n_ranks");
+    const int64_t n = n_cells, F = n_faces;
+    for (int64_t f = 0; f < F; ++f)
+        if (face_c0[f] < 0 || face_c0[f] >= n || face_c1[f] >= n) return fail(ORC_ERR_BAD_ARGUMENT, "face cell index out of range");
+    std::vector<int64_t> ptr, adj, seq((size_t)n), pos((size_t)n);
+    build_adjacency(n, F, face_c0, face_c1, ptr, adj);
+    std::iota(seq.begin(), seq.end(), 0);
+    std::iota(pos.begin(), pos.end(), 0);
+    std::vector<int32_t> owner(cell_owner, cell_owner + n);
+    for (int32_t o : owner)
+        if (o < -1 || o >= n_ranks) return fail(ORC_ERR_BAD_ARGUMENT, "cell owner out of range");
+    return build_part(n, F, face_c0, face_c1, face_zone, face_area, face_normal, face_centroid, cell_centroid, cell_volume, cell_face_ptr, cell_faces, ptr, adj,
+                      seq, pos, owner, n_ranks, rank, n_global < 0 ? n : n_global, status);
 }
 
 void orc_partition_destroy(OrcPartition *p) { delete p; }

@@ -99,6 +99,11 @@ def partition_arrays(a, n_ranks, rank, ordering=ORDER_ORC):
                                k[6].ctypes.data_as(_F64), k[7].ctypes.data_as(_F64), k[8].ctypes.data_as(_I64), k[9].ctypes.data_as(_I64),
                                C.c_int32(n_ranks), C.c_int32(rank), C.c_int32(ordering), C.byref(st))
     check(st.value)
+    return _partition_result(L, ptr, a)
+
+
+def _partition_result(L, ptr, a):
+    """arrays of an OrcPartition handle -> (MeshArrays, halo dict, global_ids); destroys the handle"""
     ptr = C.c_void_p(ptr)
     try:
         no, nl, ng, nf, ncf, ns = (C.c_int64() for _ in range(6))
@@ -124,6 +129,75 @@ def partition_arrays(a, n_ranks, rank, ordering=ORDER_ORC):
         L.orc_partition_destroy(ptr)
     halo = dict(n_owned=no.value, n_global=ng.value, peers=peers, send_ptr=sp, send_idx=si, recv_ptr=rp, global_face_ids=gfaces)
     return out, halo, gids
+
+
+def partition_owner_arrays(a, cell_owner, n_ranks, rank, n_global=-1):
+    """orc_mesh_partition_owner: rank `rank`'s part of a mesh `a` the rank generated or read FOR ITSELF (its share plus ghost
+    layers); cell_owner[c] = owning rank of every cell or -1 (nobody's: may not touch an owned cell).  Cells keep their order;
+    global_ids index `a`.  Returns (MeshArrays, halo, global_ids) like partition_arrays."""
+    L = lib()
+    L.orc_mesh_partition_owner.restype = C.c_void_p
+    k = [np.ascontiguousarray(a["face_c0"], np.int64), np.ascontiguousarray(a["face_c1"], np.int64),
+         np.ascontiguousarray(a["face_zone"], np.int32), np.ascontiguousarray(a["face_area"], np.float64),
+         np.ascontiguousarray(a["face_normal"], np.float64), np.ascontiguousarray(a["face_centroid"], np.float64),
+         np.ascontiguousarray(a["cell_centroid"], np.float64), np.ascontiguousarray(a["cell_volume"], np.float64),
+         np.ascontiguousarray(a["cell_face_ptr"], np.int64), np.ascontiguousarray(a["cell_faces"], np.int64)]
+    own = np.ascontiguousarray(cell_owner, np.int32)
+    assert len(own) == len(k[7])
+    st = C.c_int(0)
+    ptr = L.orc_mesh_partition_owner(C.c_int64(len(k[7])), C.c_int64(len(k[3])), k[0].ctypes.data_as(_I64), k[1].ctypes.data_as(_I64),
+                                     k[2].ctypes.data_as(_I32), k[3].ctypes.data_as(_F64), k[4].ctypes.data_as(_F64), k[5].ctypes.data_as(_F64),
+                                     k[6].ctypes.data_as(_F64), k[7].ctypes.data_as(_F64), k[8].ctypes.data_as(_I64), k[9].ctypes.data_as(_I64),
+                                     own.ctypes.data_as(_I32), C.c_int32(n_ranks), C.c_int32(rank), C.c_int64(n_global), C.byref(st))
+    check(st.value)
+    return _partition_result(L, ptr, a)
+
+
+# ------------------------------------------------------------------ BASELINE configs[4]: rank-local generation of the mixed tet/hex/poly channel
+def mixed_slab_arrays(nx, ny, nz_local, rank, world, lx=0.002, ly=0.001, dz=1e-4, polyhedra=True, tmpdir=None):
+    """Rank `rank`'s share of the (nx, ny, nz_local * world)-block mixed channel (orc_poly_channel_write_msh: hexahedra, prism
+    columns, Kuhn tetrahedra, pyramids and — polyhedra=True — rhombic dodecahedra), cut into slabs of nz_local block layers along z.
+
+    No process ever holds the whole mesh (40 M cells at BASELINE configs[4]): the rank GENERATES its own layers plus two ghost
+    layers per inner side — two, because a polyhedral cell reaches half a block into its neighbour layers: the cells of the first
+    ghost layer are then complete (true centroid, volume), those of the second exist only to complete them and belong to nobody —
+    writes them as a TGRID file in `tmpdir`, reads it back with the product reader (the generator has no in-memory form) and cuts
+    its part out with orc_mesh_partition_owner.  The generator is invariant under translation by an EVEN number of block layers
+    (the polyhedral region is a checkerboard in i + j + k) and numbers cells layer by layer, so neighbouring ranks see the cells
+    they share in the same relative order: ghost blocks and send lists agree without negotiation (checked over gloo by
+    tests/test_partition_cpu.py).  Cells belong to the rank whose layers hold their centroid.
+
+    Returns (MeshArrays of the local mesh with BCs unset, halo dict with n_global = -1 (the caller sums n_owned over the ranks),
+    global_ids into the rank's generated sub-box, the sub-box arrays)."""
+    import os
+    import tempfile
+    from . import io as orc_io
+    from .mesh import write_mixed_channel_msh
+    if nz_local % 2 or nz_local < 2:
+        raise ValueError("nz_local must be even (the polyhedral checkerboard is invariant under even shifts only)")
+    g_lo = 2 if rank > 0 else 0
+    g_hi = 2 if rank < world - 1 else 0
+    nzt = nz_local + g_lo + g_hi
+    k0 = rank * nz_local - g_lo  # global index of the sub-box's first block layer (even)
+    path = os.path.join(tmpdir or tempfile.gettempdir(), "orc_mixed_slab_%d_%d.msh" % (os.getpid(), rank))
+    try:
+        write_mixed_channel_msh(path, nx, ny, nzt, lx=lx, ly=ly, lz=dz * nzt, polyhedra=polyhedra)
+        d = orc_io.read_mesh(path)
+    finally:
+        if os.path.exists(path):
+            os.remove(path)
+    a = MeshArrays(d.arrays())
+    layer = np.floor(np.asarray(a["cell_centroid"])[:, 2] / dz + 1e-6).astype(np.int64) + k0  # global block layer of every cell
+    owner = (layer // nz_local).astype(np.int32)
+    owner[(layer < rank * nz_local - 1) | (layer > (rank + 1) * nz_local)] = -1  # the outer ghost layers: nobody's
+    owner[(owner < 0) | (owner >= world)] = -1
+    a["cell_centroid"] = np.asarray(a["cell_centroid"]).copy()
+    a["face_centroid"] = np.asarray(a["face_centroid"]).copy()
+    a["cell_centroid"][:, 2] += dz * k0
+    a["face_centroid"][:, 2] += dz * k0
+    out, halo, gids = partition_owner_arrays(a, owner, world, rank, -1)
+    halo["n_global"] = -1
+    return out, halo, gids, a
 
 
 class PartitionedMesh(Mesh):
@@ -237,3 +311,38 @@ def make_slab_solver(nx, ny, nz, rank, world, settings, initial_fields):
     solver = Solver(mesh, settings, 1000.0, 1e-3)
     solver.set_fields(u, v, w, p)
     return solver, mesh, halo["n_global"], mesh.nnz
+
+
+def make_mixed_slab_solver(nx, ny, nz, rank, world, settings, initial_fields, dist=None, polyhedra=True):
+    """BASELINE configs[4] as an N-rank run, weak scaling: every rank owns nz block layers of the (nx, ny, nz * world)-block mixed
+    tet / hex / poly channel, generated rank-locally (mixed_slab_arrays).  Returns (solver, mesh, cells of the whole mesh, local nnz,
+    dict of set-up facts for the bench line)."""
+    import time
+    from .mesh import set_mixed_channel_bcs
+    from .solver import Solver
+    t0 = time.perf_counter()
+    a, halo, _lids, sub = mixed_slab_arrays(nx, ny, nz, rank, world, polyhedra=polyhedra)
+    t_gen = time.perf_counter() - t0
+    set_mixed_channel_bcs(a)
+    n_global = halo["n_owned"]
+    if world > 1:
+        import torch
+        t = torch.tensor([float(n_global)], dtype=torch.float64)
+        dist.all_reduce(t)
+        n_global = int(t.item())
+    halo["n_global"] = n_global
+    nfc = np.diff(np.asarray(a["cell_face_ptr"])[:halo["n_owned"] + 1])
+    host_bytes = sum(np.asarray(v).nbytes for v in sub.values() if isinstance(v, np.ndarray)) + sum(np.asarray(v).nbytes for v in a.values() if isinstance(v, np.ndarray))
+    facts = dict(generated_cells=int(sub.n_cells), owned_cells=int(halo["n_owned"]), ghost_cells=int(len(a["cell_volume"]) - halo["n_owned"]),
+                 faces_per_cell={int(k): int(v) for k, v in zip(*np.unique(nfc, return_counts=True))}, generation_s=round(t_gen, 2),
+                 host_arrays_gb=round(host_bytes / 1e9, 2))
+    del sub
+    if world > 1:
+        mesh = PartitionedMesh(a, halo)
+    else:
+        mesh = Mesh(a)
+        mesh.n_owned = mesh.n_cells
+    u, v, w, p = initial_fields(np.asarray(a["cell_centroid"]))
+    solver = Solver(mesh, settings, 1000.0, 1e-3)
+    solver.set_fields(u, v, w, p)
+    return solver, mesh, n_global, mesh.nnz, facts

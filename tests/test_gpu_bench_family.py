@@ -91,3 +91,35 @@ def test_bench_channel_product_default_follows_the_reference_trajectory(gpu, ora
     un = np.linalg.norm(refs[1][0])
     for k, (x, y) in enumerate(zip(s.get_fields(), refs[1])):
         assert np.linalg.norm(x - y) < 1e-4 * (un if k < 3 else np.linalg.norm(y))
+
+
+def test_midsize_bench_channel_reference_order_against_the_committed_oracle_run(gpu):
+    """128 x 64 x 64 = 524 288 cells of the bench family in the reference's own mode against the oracle's fields, stored as SHA-256
+    hashes + samples by tests/golden/make_golden_bench_midsize.py (two CPU-minutes there, too long for a test).  The size brings in
+    what the in-test oracle cases cannot: 2 048-workgroup grids with several slices per wavefront, 16-bit column bases on slices
+    that straddle z-layers, coarse levels of 131 072 / 65 536 rows with real LDS windows and many-block packed mirrors.
+    Bit-exactness is a hash comparison; on a mismatch the stored samples say which field parts first and by how much."""
+    import hashlib
+    import os
+    from conftest import GOLDEN
+    from orc_amd.mesh import Mesh, hex_channel, set_channel_bcs
+    from orc_amd.settings import NumericalSettings
+    from orc_amd.solver import Solver
+    g = np.load(os.path.join(GOLDEN, "bench_midsize_128x64x64.npz"), allow_pickle=False)
+    shape, stride = tuple(int(x) for x in g["shape"]), int(g["stride"])
+    a = set_channel_bcs(hex_channel(*shape))
+    f0 = bench.initial_fields(np.asarray(a["cell_centroid"]))
+    kw = dict(BENCH_KW, frozen_diagonals=0, breakdown_guard=0)
+    s = Solver(Mesh(a), NumericalSettings.default(reduction_order=REFERENCE, **kw), 1000.0, 1e-3)
+    s.set_fields(*f0)
+    for it in (1, 2, 3):
+        st, rep = s.iterate(1, report=True, raise_on_error=False)
+        assert st == 0, "iteration %d" % it
+        for name, x in zip("uvwp", s.get_fields()):
+            x = np.ascontiguousarray(x)
+            sample = g["sample_%s_%d" % (name, it)]
+            worst = float(np.max(np.abs(x[::stride] - sample)) / max(np.max(np.abs(sample)), 1e-300))
+            assert hashlib.sha256(x.tobytes()).digest() == g["sha256_%s_%d" % (name, it)].tobytes(), \
+                "iteration %d, field %s differs from the oracle (largest sampled difference %.3e of the field's scale)" % (it, name, worst)
+        ro = g["report_%d" % it]  # oracle: means 0-2, mean Peclet 3, velocity correction 4, pressure correction 5
+        assert same_bits(np.array([rep[0][k] for k in (0, 1, 2, 3, 6, 7)]), ro), (it, rep[0], ro)

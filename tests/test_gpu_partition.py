@@ -39,6 +39,49 @@ def test_two_ranks_converged_default_stack_matches_the_oracle(gpu):
     assert "MP_WORKER_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-4000:]
 
 
+def test_lock_step_momentum_solve_on_a_partitioned_mesh(gpu):
+    """The three momentum systems in lock-step across two ranks (interleaved halo exchange, one all-reduce per step for the three
+    systems): bit-identical per system to the one-system partitioned solves, with about half the collectives per SIMPLE iteration
+    (a third in the momentum phase)."""
+    r = launch(2, "gpu_triple_partitioned", timeout=900)
+    print(r.stdout[-1500:])
+    assert "MP_WORKER_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-4000:]
+
+
+def test_two_ranks_on_rank_local_mixed_poly_slabs_match_single_rank(gpu):
+    """BASELINE configs[4] as an N-rank run (Missing #1): each of two ranks generates ITS slab of the mixed tet / hex /
+    poly channel (two ghost block layers, orc_mesh_partition_owner) and the partitioned SIMPLE iterations — Jacobi, BiCGSTAB and the
+    Multigrid arm — agree with the single-rank run on the whole mesh."""
+    r = launch(2, "gpu_mixed_slabs", timeout=900)
+    print(r.stdout[-1500:])
+    assert "MP_WORKER_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-4000:]
+
+
+def test_bench_py_spawns_two_ranks_by_itself_on_one_gpu(gpu):
+    """`python bench.py --gpus 2` with no launcher around it (Missing #2): the process spawns its ranks (host-staged
+    transport: both share cuda:0 — a rehearsal of the N-rank entry, not a measurement) and prints ONE line, for the hex slabs and
+    for the config-5 mixed slabs."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["ORC_BENCH_HOST_TRANSPORT"] = "1"
+    for extra, cells in ((["--nx", "40", "--ny", "26", "--nz", "16"], 2 * 40 * 26 * 16), (["--workload", "config5", "--nx", "24", "--ny", "8", "--nz", "4"], None)):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--spmv-reps", "2", "--inner", "10",
+                            "--no-cpu-baseline"] + extra, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        lines = [l for l in r.stdout.splitlines() if l.strip()]
+        assert len(lines) == 1, r.stdout
+        out = json.loads(lines[0])
+        assert out["n_gpus"] == 2 and out["config"]["transport"] == "host" and out["status"] == 0 and out["value"] > 0
+        if cells:
+            assert out["config"]["cells_total"] == cells
+        else:
+            assert "configs[4]" in out["config"]["workload"] and out["config"]["mixed_mesh"]["ghost_cells"] > 0
+
+
 def test_lane_error_on_one_rank_reaches_every_rank(gpu):
     """Status agreement of the partitioned momentum solve on its failing path: an error injected into one lane of one rank
     (after its hierarchy set-up, before its coarse levels) leaves every rank with the same non-zero status — no rank waits in a

@@ -83,3 +83,13 @@ def test_rcm_ordering_reduces_the_bandwidth_of_a_shuffled_mesh():
     assert sorted(gids.tolist()) == list(range(len(gids))) and halo["n_owned"] == len(gids) and len(halo["peers"]) == 0
     assert bandwidth(sh) > 5 * bandwidth(g)
     assert bandwidth(a) <= 2 * bandwidth(g)
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_rank_local_generation_of_the_mixed_poly_channel_gloo(world):
+    """BASELINE configs[4] (mixed tet / hex / poly, partitioned) without the whole mesh in any process: every rank generates its
+    slab + two ghost block layers per inner side and cuts its part out with orc_mesh_partition_owner.  World sizes 2 and 8 (the
+    config's own) on a small mesh: tiling, complete ghost geometry, face lists, halo symmetry by really exchanging global ids over
+    gloo, distributed product == global product."""
+    r = launch(world, "cpu_mixed_slabs")
+    assert "MP_WORKER_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
