@@ -313,15 +313,17 @@ def main():
     if args.solver in ("multigrid", "multigrid_gs") and world == 1:
         solver.restore()
         for lvl, (rows_l, nnz_l, padded_l, ms_l) in enumerate(solver.bench_amg_levels(20)):
-            # bytes per product: value + column per stored entry, row length + x + y per row, + the Jacobi scaling vector
-            # the products of levels 2 and 3 read (levels 0 and 1 materialise their scaled values once per smoothing solve)
-            bytes_l = 12.0 * nnz_l + 20.0 * rows_l + (8.0 * rows_l if lvl >= 2 else 0.0)
+            # ALGORITHMIC bytes per product: value + 4-byte column per stored entry, row length + x + y per row.  Every level's
+            # smoothing solve materialises its Jacobi-scaled values (orc_bench_amg_levels does the same), so no product reads a scaling
+            # vector (r03 added 8 n on levels 2-3 by mistake); the launches really stream 2-byte columns / window positions,
+            # so `frac_of_peak` is algorithmic throughput, not traffic — profiles/r04_pmc_products.csv has the measured bytes per level.
+            bytes_l = 12.0 * nnz_l + 20.0 * rows_l
             levels.append({"level": lvl, "rows": rows_l, "nnz": nnz_l, "padded": padded_l, "us_per_product": ms_l * 1e3,
                            "algorithmic_bytes": bytes_l, "GBs": bytes_l / (ms_l * 1e-3) / 1e9,
                            "frac_of_peak": bytes_l / (ms_l * 1e-3) / 1e9 / HBM_PEAK_GBS})
         if args.levels_csv and rank == 0:
             with open(args.levels_csv, "w") as fh:
-                fh.write("level,rows,nnz,padded_entries,padding_ratio,us_per_product,algorithmic_bytes,GB_per_s,frac_of_8TBs\n")
+                fh.write("level,rows,nnz,padded_entries,padding_ratio,us_per_product,algorithmic_bytes_12nnz_20n,algorithmic_GB_per_s,algorithmic_frac_of_8TBs\n")
                 for L in levels:
                     fh.write("%d,%d,%d,%d,%.4f,%.2f,%.0f,%.1f,%.4f\n" % (L["level"], L["rows"], L["nnz"], L["padded"], L["padded"] / max(L["nnz"], 1),
                                                                         L["us_per_product"], L["algorithmic_bytes"], L["GBs"], L["frac_of_peak"]))
@@ -331,8 +333,15 @@ def main():
         # n_colors launches of gs_color_sorted_k and moves one SpMV's bytes + the right-hand side
         gs_ms, gs_colors = solver.bench_gs_sweep(args.spmv_reps)
         gs_bytes = spmv_bytes + 8.0 * n_local
-        gs = {"kernel": "gs_color_sorted_k", "launches_per_sweep": gs_colors, "avg_sweep_ms": gs_ms, "avg_launch_ms": gs_ms / max(gs_colors, 1),
-              "algorithmic_bytes_per_sweep": gs_bytes, "achieved": gs_bytes / (gs_ms * 1e-3) / 1e9, "frac": gs_bytes / (gs_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        ms1, ms3, _ = solver.bench_gs_sweep0(args.spmv_reps)  # [r04] what the slot-space solver launches: from zero, no fill, u/v/w per launch
+        gs = {"kernel": "gsx_sweep0_k<3> (u, v, w per colour launch; gsx_sweep0_k<1> for the p' system)", "launches_per_sweep": gs_colors,
+              "three_systems": {"avg_sweep_ms": ms3, "algorithmic_bytes_per_sweep": 3.0 * gs_bytes, "achieved": 3.0 * gs_bytes / (ms3 * 1e-3) / 1e9,
+                                "frac": 3.0 * gs_bytes / (ms3 * 1e-3) / 1e9 / HBM_PEAK_GBS},
+              "one_system": {"avg_sweep_ms": ms1, "algorithmic_bytes_per_sweep": gs_bytes, "achieved": gs_bytes / (ms1 * 1e-3) / 1e9,
+                             "frac": gs_bytes / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS},
+              "r03_kernel_gs_color_sorted_k": {"avg_sweep_ms": gs_ms, "frac": gs_bytes / (gs_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+              "avg_sweep_ms": ms3, "avg_launch_ms": ms3 / max(gs_colors, 1),
+              "algorithmic_bytes_per_sweep": 3.0 * gs_bytes, "achieved": 3.0 * gs_bytes / (ms3 * 1e-3) / 1e9, "frac": 3.0 * gs_bytes / (ms3 * 1e-3) / 1e9 / HBM_PEAK_GBS,
               "note": "one sweep = 12 nnz + 20 n (SURVEY 8d) + 8 n (the right-hand side); at ~1 M cells the matrix (62 MB) lives in the 256 MiB "
                       "Infinity Cache and a launch covers 1/n_colors of the rows: these launches are latency-, not HBM-bound"}
     key = (args.nx, args.ny, args.nz, args.momentum, args.solver)
@@ -397,7 +406,7 @@ def main():
                 "parallelism": ("cell slabs x%d, halo exchange + all-reduce over %s" % (world, "the host-staged debug transport (gloo; ranks share one GPU: a "
                                 "rehearsal, not a measurement)" if host_transport else "RCCL (ncclSend/ncclRecv + ncclAllReduce over xGMI)")) if world > 1 else "single GPU",
                 "transport": ("host" if host_transport else "rccl") if world > 1 else None,
-                "momentum_solves": "u, v, w in lock-step on their shared pattern (one column stream, interleaved vectors)" if (world == 1 and args.solver in ("multigrid", "bicgstab") and os.environ.get("ORC_TRIPLE_MOMENTUM", "1") != "0") else "one system per solve",
+                "momentum_solves": "u, v, w in lock-step on their shared pattern (one column stream, interleaved vectors)" if (args.solver in ("multigrid", "bicgstab", "bicgstab_gs") and os.environ.get("ORC_TRIPLE_MOMENTUM", "1") != "0" and (world == 1 or args.solver != "bicgstab_gs")) else "one system per solve",
                 "setup_s": round(t_setup, 2),
                 "hbm_used_gb": round(hbm_used_gb, 1),
             },

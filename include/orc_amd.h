@@ -296,6 +296,9 @@ const char *orc_bench_inloop_variant(void);
 /* one multicolour Gauss-Seidel sweep over a_u (extension; BASELINE configs[2]): n_colors launches of the colour-sorted
  * kernel per sweep, average ms per sweep over `reps` sweeps */
 int orc_bench_gs_sweep(OrcSolver *s, int reps, double *avg_ms, int *n_colors);
+/* [r04] the preconditioner application x^ = M^-1 b as the slot-space GS-BiCGSTAB launches it (one sweep from zero without a zero fill,
+ * n_colors launches): avg_ms[0] one system (the p' solve), avg_ms[1] the u, v, w momentum systems per launch */
+int orc_bench_gs_sweep0(OrcSolver *s, int reps, double avg_ms[2], int *n_colors);
 int orc_bench_amg_levels(OrcSolver *s, int reps, int64_t *rows, int64_t *nnz, int64_t *padded, double *avg_ms, int *n_levels);
 /* Measurement only: force a product kernel variant for the next launches (0 = production choice, 1 = padded SELL-64,
  * 2 = padded with predicated padding, 3 = packed where a mirror exists, 4/5 = packed/padded WITHOUT the x gathers —

@@ -28,6 +28,7 @@ int download_csr_values(OrcMesh &m, const DevBuf<double> &sell, double *host_val
 
 namespace orc {
 int bench_gs_sweep_dev(const MatView &A, const double *b, double *x, int reps, Arena &arena, float *ms_per_sweep, int *n_colors);  // gs.hip
+int bench_gs_sweep0_dev(const MatView A[3], const double *const b[3], int reps, Arena &arena, float ms[2], int *n_colors);         // gs.hip
 }
 
 extern "C" {
@@ -633,6 +634,27 @@ int orc_bench_gs_sweep(OrcSolver *s, int reps, double *avg_ms, int *n_colors) {
     int nc = 0;
     ORC_TRY(bench_gs_sweep_dev(A, t.b_u.p, x, std::max(reps, 1), t.arena, &ms, &nc));
     *avg_ms = ms;
+    if (n_colors) *n_colors = nc;
+    return ORC_OK;
+}
+
+// [r04] the same application as the slot-space GS-BiCGSTAB launches it (from zero, no fill): avg_ms[0] one system, avg_ms[1] u, v, w per launch
+int orc_bench_gs_sweep0(OrcSolver *s, int reps, double avg_ms[2], int *n_colors) {
+    if (!s || !avg_ms) return set_error(ORC_ERR_BAD_ARGUMENT, "null argument");
+    SolverState &t = s->st;
+    MatView A[3];
+    const double *vals[3] = {t.a_u.p, t.a_v.p, t.a_w.p};
+    const double *b[3] = {t.b_u.p, t.b_v.p, t.b_w.p};
+    for (int k = 0; k < 3; ++k) {
+        A[k].P = t.mesh->pat.dev();
+        A[k].val = vals[k];
+        A[k].symmetric = t.mesh->pat.symmetric;
+        A[k].persistent_pattern = true;
+    }
+    float ms[2] = {0.f, 0.f};
+    int nc = 0;
+    ORC_TRY(bench_gs_sweep0_dev(A, b, std::max(reps, 1), t.arena, ms, &nc));
+    avg_ms[0] = ms[0]; avg_ms[1] = ms[1];
     if (n_colors) *n_colors = nc;
     return ORC_OK;
 }

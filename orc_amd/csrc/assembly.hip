@@ -678,6 +678,11 @@ __global__ __launch_bounds__(kBlock) void momentum_k(MeshDev M, SellDev P, Momen
     }
 }
 
+// pe[c] <- (((0 + pe_x) + pe_y) + pe_z) / 3: the term cell c adds to the reference's running mean (discretization.rs:338)
+__global__ void peclet_cell_term_k(double *__restrict__ pe, int64_t n) {
+    GRID_STRIDE(c, n) pe[c] = (((0. + pe[c]) + pe[n + c]) + pe[2 * n + c]) / 3.;
+}
+
 // the Peclet statistics of momentum_k from the stored per-cell terms (same per-workgroup partial layout)
 __global__ __launch_bounds__(kBlock) void peclet_stats_k(const double *__restrict__ pe, int64_t n_own, int64_t n, double *__restrict__ partials) {
     __shared__ double lds[8];
@@ -728,7 +733,7 @@ __global__ __launch_bounds__(kBlock) void correction_k(MeshDev M, const double *
                                                        const double *__restrict__ dw, const double *__restrict__ pp,
                                                        double *__restrict__ u, double *__restrict__ v, double *__restrict__ w,
                                                        double *__restrict__ p, double alpha_p, double alpha_u,
-                                                       double *__restrict__ partials, int *status) {
+                                                       double *__restrict__ partials, int *status, double *__restrict__ corr_cell) {
     __shared__ double lds[8];
     double s_pp = 0., s_corr = 0., s_u = 0., s_v = 0., s_w = 0.;
     GRID_STRIDE(c, M.n_own) {
@@ -754,6 +759,7 @@ __global__ __launch_bounds__(kBlock) void correction_k(MeshDev M, const double *
         u[c] = un; v[c] = vn; w[c] = wn;
         const double nn = vnorm(acc);
         s_corr += nn * nn;  // :1224
+        if (corr_cell) corr_cell[c] = nn * nn;  // reference reduction order: summed cell by cell afterwards (k_apply_correction)
         s_pp += ppc * ppc;
         s_u += un; s_v += vn; s_w += wn;
     }
@@ -1024,6 +1030,7 @@ int k_momentum(SolverState &s, double *peclet_host) {
                    s.a_u.p, s.a_v.p, s.a_w.p, s.b_u.p, s.b_v.p, s.b_w.p, s.du.p, s.dv.p, s.dw.p, s.settings.momentum,
                    s.settings.q1_compat, s.rho};
     const int g = grid_for(s.n);
+    bool ref_pe = false;  // the mean Peclet number as the reference's running sum (discretization.rs:338), reference reduction order only
     if (s.settings.frozen_diagonals == 0) {
         // in-place diagonals (the reference's own mode): level by level over the cell order
         ORC_TRY(vec_copy(s.du_old.p, s.du.p, s.n));
@@ -1042,11 +1049,14 @@ int k_momentum(SolverState &s, double *peclet_host) {
             hipLaunchKernelGGL(HIP_KERNEL_NAME(momentum_k<true>), dim3(grid_for(I.count)), dim3(kBlock), 0, ctx().stream, m.dev(), m.pat.dev(), A, s.partials.p, I);
         }
         hipLaunchKernelGGL(peclet_stats_k, dim3(g), dim3(kBlock), 0, ctx().stream, s.pe.p, s.n_own, s.n, s.partials.p);
+        ref_pe = s.settings.reduction_order == ORC_REDUCTION_REFERENCE && !s.mesh->halo.active() && peclet_host != nullptr;
+        if (ref_pe) hipLaunchKernelGGL(peclet_cell_term_k, dim3(g), dim3(kBlock), 0, ctx().stream, s.pe.p, s.n);  // pe[c] = its term of :338
     } else {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(momentum_k<false>), dim3(g), dim3(kBlock), 0, ctx().stream, m.dev(), m.pat.dev(), A, s.partials.p, InplaceArgs());
     }
     hipLaunchKernelGGL(reduce_minmax_k, dim3(1), dim3(64), 0, ctx().stream, s.partials.p, g, s.scal.p + 8);
     ORC_HIP(hipGetLastError());
+    if (ref_pe) ORC_TRY(sum_reference(s.pe.p, s.n, s.scal.p + 8));
     if (peclet_host) {
         if (s.mesh->halo.active()) {  // statistics over the whole mesh: sum; max of (-min, max)
             hipLaunchKernelGGL(negate_k, dim3(1), dim3(1), 0, ctx().stream, s.scal.p + 9);
@@ -1073,10 +1083,24 @@ int k_pressure_correction(SolverState &s) {
 int k_apply_correction(SolverState &s, double *sums_host) {
     OrcMesh &m = *s.mesh;
     const int g = grid_for(s.n);
+    // [r04] The reference's own mode (in-place diagonals + nalgebra's reduction order, one GPU): the REPORT's sums are taken in the
+    // reference's association too — p'.norm() through dotx (solver.rs:1226), the velocity-correction sum cell by cell (:1224), the
+    // means as left-to-right folds (:206-208) — so that not only the fields but the six report doubles of an iteration are the
+    // oracle's bit for bit (scripts/reference_mode_fullsize.py compares exactly those at 10.24 M cells).  s.pe is free by now.
+    const bool ref_report = s.settings.reduction_order == ORC_REDUCTION_REFERENCE && s.settings.frozen_diagonals == 0 && !s.mesh->halo.active() && s.pe.p;
     hipLaunchKernelGGL(correction_k, dim3(g), dim3(kBlock), 0, ctx().stream, m.dev(), s.du.p, s.dv.p, s.dw.p, s.p_prime.p, s.u.p, s.v.p,
-                       s.w.p, s.p.p, s.settings.pressure_relaxation, s.settings.momentum_relaxation, s.partials.p, s.dev_status.p);
+                       s.w.p, s.p.p, s.settings.pressure_relaxation, s.settings.momentum_relaxation, s.partials.p, s.dev_status.p,
+                       ref_report ? s.pe.p : (double *)nullptr);
     ORC_HIP(hipGetLastError());
-    ORC_TRY(reduce_partials(s.partials.p, g, 5, s.scal.p, s.mesh->halo.active()));
+    if (ref_report) {
+        ORC_TRY(dot_reference(s.p_prime.p, s.p_prime.p, s.n, s.scal.p + 0, nullptr));
+        ORC_TRY(sum_reference(s.pe.p, s.n, s.scal.p + 1));
+        ORC_TRY(sum_reference(s.u.p, s.n, s.scal.p + 2));
+        ORC_TRY(sum_reference(s.v.p, s.n, s.scal.p + 3));
+        ORC_TRY(sum_reference(s.w.p, s.n, s.scal.p + 4));
+    } else {
+        ORC_TRY(reduce_partials(s.partials.p, g, 5, s.scal.p, s.mesh->halo.active()));
+    }
     if (sums_host) {
         ORC_HIP(hipMemcpyAsync(sums_host, s.scal.p, 5 * sizeof(double), hipMemcpyDeviceToHost, ctx().stream));
         ORC_HIP(hipStreamSynchronize(ctx().stream));
@@ -1468,6 +1492,33 @@ static int solve_momentum_triple(SolverState &s, const std::function<void()> &on
     const double *b[3] = {s.b_u.p, s.b_v.p, s.b_w.p};
     double *x[3] = {s.u.p, s.v.p, s.w.p};
     if (s.arena.empty()) ORC_TRY(s.arena.reset());
+    if (t.solver_type == ORC_SOLVER_BICGSTAB_GS_PRECOND) {  // [r04] BASELINE configs[2]: u, v, w per colour in ONE launch (gs.hip, slot space)
+        ArenaScope scope(s.arena);
+        MatView V[3];
+        const double *bb[3];
+        const size_t nn = (size_t)std::max<int64_t>(s.n_own, 1);
+        for (int k = 0; k < 3; ++k) {
+            V[k].P = s.mesh->pat.dev();
+            V[k].val = A3.val[k];
+            V[k].symmetric = s.mesh->pat.symmetric;
+            V[k].persistent_pattern = true;
+            bb[k] = b[k];
+            if (t.preconditioner == ORC_PRECOND_JACOBI) {  // linear_algebra.rs:159-166, as iterative_solve_dev does it per system
+                double *dinv, *bt;
+                ORC_TRY(s.arena.alloc(nn, &dinv));
+                ORC_TRY(s.arena.alloc(nn, &bt));
+                ORC_TRY(diag_inverse_dev(V[k], dinv));
+                ORC_TRY(scale_vec_dev(dinv, b[k], bt, s.n_own));
+                V[k].s1 = dinv;
+                bb[k] = bt;
+            } else if (t.preconditioner != ORC_PRECOND_NONE) {
+                return set_error(ORC_ERR_BAD_ARGUMENT, "unknown preconditioner %d", t.preconditioner);
+            }
+        }
+        ORC_TRY(gs_bicgstab3_dev(V, bb, x, t.iterations, s.arena));
+        ORC_HIP(hipStreamSynchronize(g.stream));
+        return ORC_OK;
+    }
     if (t.solver_type == ORC_SOLVER_BICGSTAB) {
         ArenaScope scope(s.arena);
         const size_t n3 = (size_t)3 * (size_t)s.n_own;
@@ -1549,7 +1600,8 @@ int solver_iterate(SolverState &s, uint64_t iterations, double *report) {
         const bool triple_part = s.concurrent_momentum && H.active() && !dbg && !ctx().profile && s.triple_momentum && triple_supported() &&
                                  (method == ORC_SOLVER_MULTIGRID || method == ORC_SOLVER_BICGSTAB);
         const bool triple_ok = (lanes_ok && s.triple_momentum && triple_supported() && s.settings.reduction_order != ORC_REDUCTION_REFERENCE &&
-                                (method == ORC_SOLVER_MULTIGRID || method == ORC_SOLVER_BICGSTAB)) || triple_part;
+                                (method == ORC_SOLVER_MULTIGRID || method == ORC_SOLVER_BICGSTAB ||
+                                 (method == ORC_SOLVER_BICGSTAB_GS_PRECOND && gs_slot_space_enabled()))) || triple_part;
         // The p' hierarchy is needed after the momentum solves.  Beside the per-system lanes it is built from the start; in the
         // lock-step schedule the momentum set-ups are the critical path of the first phase (nothing bandwidth-bound but the
         // level-0 solve runs beside them), so it starts when they are through and runs beside the bandwidth-bound coarse levels.

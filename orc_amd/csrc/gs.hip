@@ -31,6 +31,7 @@ struct ColorSell {
     DevBuf<int64_t> slice_ptr;          // [n_slices + 1]
     DevBuf<int> row_len, rowid, diag_off;  // per slot: entries, original row (-1: padding slot), element offset of the diagonal (-1: none)
     DevBuf<int> col;                    // [padded] original column indices
+    DevBuf<int> cslot;                  // [padded] [r04] the slot of that column's row: what the slot-space solver gathers through
     DevBuf<int> slot_of_row;            // [n]
     std::vector<int> color_slice;       // [n_colors + 1] first slice of every colour
 };
@@ -50,6 +51,8 @@ struct Coloring {
 struct SortedView {
     const int64_t *sp = nullptr;
     const int *row_len = nullptr, *rowid = nullptr, *diag_off = nullptr, *col = nullptr;
+    const int *cslot = nullptr;  // [r04] columns as slots (slot-space solver)
+    int n_slices = 0;
     const double *val = nullptr;
     std::vector<int> color_slice;
     bool ok() const { return val != nullptr; }
@@ -273,11 +276,14 @@ static int build_color_sell(const SellDev &P, Coloring &C) {
     S.padded = sp_p[(size_t)S.n_slices];
     if (S.padded >= ((int64_t)1 << 31)) return set_error(ORC_ERR_BAD_ARGUMENT, "colour-sorted matrix too large for 32-bit offsets");
     std::vector<int> col_p((size_t)std::max<int64_t>(S.padded, 1), 0), diag_p((size_t)std::max<int64_t>(S.n_slots, 1), -1);
+    std::vector<int> cslot_p((size_t)std::max<int64_t>(S.padded, 1), 0);
     for (int64_t i = 0; i < n; ++i) {
         const int64_t slot = slot_of_row[(size_t)i];
         const int64_t src = sp[(size_t)(i >> 6)] + (i & 63), dst = sp_p[(size_t)(slot >> 6)] + (slot & 63);
         for (int k = 0; k < row_len[(size_t)i]; ++k) {
             col_p[(size_t)(dst + (int64_t)k * 64)] = col[(size_t)(src + (int64_t)k * 64)];
+            const int cj = col[(size_t)(src + (int64_t)k * 64)];
+            cslot_p[(size_t)(dst + (int64_t)k * 64)] = cj < n ? slot_of_row[(size_t)cj] : -1;  // (ghost columns: the slot-space solver is single-GPU)
             if (diag[(size_t)i] == (int)(src + (int64_t)k * 64)) diag_p[(size_t)slot] = (int)(dst + (int64_t)k * 64);
         }
     }
@@ -286,6 +292,7 @@ static int build_color_sell(const SellDev &P, Coloring &C) {
     ORC_TRY(S.rowid.upload(rowid.data(), rowid.size()));
     ORC_TRY(S.diag_off.upload(diag_p.data(), diag_p.size()));
     ORC_TRY(S.col.upload(col_p.data(), col_p.size()));
+    ORC_TRY(S.cslot.upload(cslot_p.data(), cslot_p.size()));
     ORC_TRY(S.slot_of_row.upload(slot_of_row.data(), slot_of_row.size()));
     S.built = true;
     return ORC_OK;
@@ -437,7 +444,7 @@ __global__ __launch_bounds__(1024) void gs_slice_ptr_k(const int *__restrict__ l
 }
 // pattern and values of the view -> colour-sorted storage (thread per original row), diagonal offsets on the way
 __global__ void gs_permute_all_k(MatView A, const int *__restrict__ slot_of_row, const int64_t *__restrict__ sp_p, int *__restrict__ col_p,
-                                 double *__restrict__ val_p, int *__restrict__ diag_p) {
+                                 double *__restrict__ val_p, int *__restrict__ diag_p, int *__restrict__ cslot_p) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < A.P.n; i += (int64_t)gridDim.x * blockDim.x) {
         const int len = A.P.row_len[i];
         const int64_t src = A.P.slice_ptr[i >> 6] + (i & 63);
@@ -447,6 +454,7 @@ __global__ void gs_permute_all_k(MatView A, const int *__restrict__ slot_of_row,
         for (int k = 0; k < len; ++k) {
             const int j = A.P.col[src + (int64_t)k * 64];
             col_p[dst + (int64_t)k * 64] = j;
+            cslot_p[dst + (int64_t)k * 64] = j < A.P.n ? slot_of_row[j] : -1;
             val_p[dst + (int64_t)k * 64] = view_value(A, i, src + (int64_t)k * 64);
             if (j == i) d = (int)(dst + (int64_t)k * 64);
         }
@@ -492,11 +500,13 @@ static int build_sorted_on_device(const MatView &A, const Coloring &C, Arena &ar
     ORC_HIP(hipMemcpyAsync(&padded, sp_p + n_slices, sizeof(int64_t), hipMemcpyDeviceToHost, st));
     ORC_HIP(hipStreamSynchronize(st));
     if (padded >= ((int64_t)1 << 31)) return set_error(ORC_ERR_BAD_ARGUMENT, "colour-sorted matrix too large for 32-bit offsets");
+    int *cslot_p;
     ORC_TRY(arena.alloc((size_t)std::max<int64_t>(padded, 1), &col_p));
+    ORC_TRY(arena.alloc((size_t)std::max<int64_t>(padded, 1), &cslot_p));
     ORC_TRY(arena.alloc((size_t)std::max<int64_t>(padded, 1), &val_p));
-    hipLaunchKernelGGL(gs_permute_all_k, dim3(grid_for(n)), dim3(kBlock), 0, st, A, slot_of_row, sp_p, col_p, val_p, diag_p);
+    hipLaunchKernelGGL(gs_permute_all_k, dim3(grid_for(n)), dim3(kBlock), 0, st, A, slot_of_row, sp_p, col_p, val_p, diag_p, cslot_p);
     ORC_HIP(hipGetLastError());
-    V.sp = sp_p; V.row_len = len_p; V.rowid = rowid; V.diag_off = diag_p; V.col = col_p; V.val = val_p;
+    V.sp = sp_p; V.row_len = len_p; V.rowid = rowid; V.diag_off = diag_p; V.col = col_p; V.val = val_p; V.cslot = cslot_p; V.n_slices = n_slices;
     return ORC_OK;
 }
 
@@ -623,6 +633,389 @@ static int spmv_launch(const MatView &A, const double *x, const Epi &epi, double
     return ORC_OK;
 }
 
+// ------------------------------------------------------------------ [r04] GS-preconditioned BiCGSTAB in SLOT SPACE, S systems in lock-step
+// BASELINE configs[2] (1.03 M cells): r03's solve spent 54 % of its kernel time in 10-microsecond colour launches at 0.2 of peak,
+// another 12 % in one-workgroup folds and zero fills, and ran u, v, w as three such chains.  Here the whole solve lives in the
+// colour-sorted numbering ("slots"): the vectors are permuted once on the way in and out, products and sweeps gather through the
+// slot of a column (ColorSell::cslot) — still adding a row's entries in their original ascending-column order, so every row sum has
+// its bits — and
+//   * the preconditioner application x^ = M^-1 b (one sweep from zero, omega = 1) needs no zero fill: a colour's kernel knows that
+//     every column of its own or a later colour still holds the zero of the start (a slot compare against the colour's first slot),
+//     skips those gathers, and their products — exact zeros that leave the running sum unchanged — with them;
+//   * the three sums of an iteration are folded by the kernels that consume them (fold_partials_block, as in the reference arm);
+//   * S = 3: the momentum systems share the mesh pattern, so one launch serves u, v and w — interleaved vectors x[3 slot + s], three
+//     value streams, one column stream: a third of the launches, three times the work per launch of these latency-bound kernels.
+// Per system the arithmetic of S = 3 is that of S = 1 (same grids, same thread -> slot map, same folds): bit-identical (tests).
+template <int S> struct SlotMat {
+    const int64_t *sp;
+    const int *row_len, *rowid, *diag_off, *cslot;
+    const double *val[S];
+    int n_slices;
+    int64_t n_slots;
+};
+template <int S> struct CVecs { const double *p[S]; };
+template <int S> struct MVecs { double *p[S]; };
+enum { GX_RHO0 = 0, GX_RHO1 = 1, GX_SUM_NU = 2, GX_TS = 3, GX_TT = 4, GX_FROZEN = 5, GX_FROZEN2 = 6, GX_STRIDE = 8 };
+
+template <int S>
+__global__ void gsx_in_k(const int *__restrict__ rowid, int64_t n_slots, CVecs<S> src, double *__restrict__ dst) {
+    for (int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; slot < n_slots; slot += (int64_t)gridDim.x * blockDim.x) {
+        const int i = rowid[slot];
+#pragma unroll
+        for (int s = 0; s < S; ++s) dst[S * slot + s] = i >= 0 ? src.p[s][i] : 0.;
+    }
+}
+template <int S>
+__global__ void gsx_out_k(const int *__restrict__ rowid, int64_t n_slots, const double *__restrict__ src, MVecs<S> dst) {
+    for (int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; slot < n_slots; slot += (int64_t)gridDim.x * blockDim.x) {
+        const int i = rowid[slot];
+        if (i < 0) continue;
+#pragma unroll
+        for (int s = 0; s < S; ++s) dst.p[s][i] = src[S * slot + s];
+    }
+}
+
+// kMode 0: r = b - A x, p = r, sum(r)   1: y = A x, sum(y)   2: t = A x, t.aux, t.t      (linear_algebra.rs:250-261)
+// partial sums: quantity q of system s at partials[(s * kRed + q) * gridDim.x + blockIdx.x]
+template <int S, int kMode>
+__global__ __launch_bounds__(kBlock) void gsx_spmv_k(SlotMat<S> M, const double *__restrict__ x, const double *__restrict__ aux, double *__restrict__ y,
+                                                     double *__restrict__ y2, double *__restrict__ partials) {
+    __shared__ double lds[8];
+    constexpr int kRed = kMode == 2 ? 2 : 1;
+    const int lane = threadIdx.x & 63;
+    double red[S][2];
+#pragma unroll
+    for (int s = 0; s < S; ++s) red[s][0] = red[s][1] = 0.;
+    SliceWalk w(M.n_slices);
+    for (int64_t slice = w.begin; slice < w.end; slice += w.step) {
+        const int64_t slot = slice * 64 + lane;
+        const int i = M.rowid[slot];
+        const int len = i >= 0 ? M.row_len[slot] : 0;
+        const int64_t base = M.sp[slice] + lane;
+        const int width = (int)((M.sp[slice + 1] - M.sp[slice]) >> 6);
+        double acc[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) acc[s] = 0.;
+        for (int k0 = 0; k0 < width; k0 += 8) {
+            int c[8];
+            double v[S][8];
+            const int64_t p0 = base + (int64_t)k0 * 64;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool in = k0 + u < len;
+                c[u] = in ? M.cslot[p0 + (int64_t)u * 64] : 0;
+#pragma unroll
+                for (int s = 0; s < S; ++s) v[s][u] = in ? M.val[s][p0 + (int64_t)u * 64] : 0.;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (k0 + u < len && c[u] >= 0) {  // (c < 0: a ghost column — never in a slot-space solve, which is single-GPU)
+#pragma unroll
+                    for (int s = 0; s < S; ++s) acc[s] += v[s][u] * x[(int64_t)S * c[u] + s];
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const int64_t e = S * slot + s;
+            if (kMode == 0) {
+                const double r = i >= 0 ? aux[e] - acc[s] : 0.;
+                y[e] = r; y2[e] = r;
+                red[s][0] += r;
+            } else if (kMode == 1) {
+                const double o = i >= 0 ? acc[s] : 0.;
+                y[e] = o;
+                red[s][0] += o;
+            } else {
+                const double o = i >= 0 ? acc[s] : 0.;
+                y[e] = o;
+                if (i >= 0) { red[s][0] += o * aux[e]; red[s][1] += o * o; }
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+#pragma unroll
+        for (int q = 0; q < kRed; ++q) {
+            const double t = block_sum(red[s][q], lds);
+            if (threadIdx.x == 0) partials[(size_t)(s * kRed + q) * gridDim.x + blockIdx.x] = t;
+        }
+    }
+}
+
+// x^ = M^-1 b for the slots [slice_lo, slice_hi) of one colour: gs_color_sorted_k's row update (linear_algebra.rs:225-239, omega = 1)
+// from a zero start — the entries whose column belongs to this or a later colour (cslot >= first slot of the colour) multiply the
+// zero of the start: skipped with their gathers (an exact zero added to the running sum leaves it as it is)
+template <int S>
+__global__ __launch_bounds__(kBlock) void gsx_sweep0_k(SlotMat<S> M, const double *__restrict__ b, double *__restrict__ xh, int slice_lo, int slice_hi,
+                                                       int *__restrict__ status) {
+    const int lane = threadIdx.x & 63;
+    const int waves = blockDim.x >> 6;
+    const int first_slot = slice_lo * 64;
+    for (int sidx = slice_lo + blockIdx.x * waves + (threadIdx.x >> 6); sidx < slice_hi; sidx += gridDim.x * waves) {
+        const int64_t slot = (int64_t)sidx * 64 + lane;
+        const int i = M.rowid[slot];
+        const int len = i >= 0 ? M.row_len[slot] : 0;
+        const int64_t base = M.sp[sidx] + lane;
+        const int width = (int)((M.sp[sidx + 1] - M.sp[sidx]) >> 6);
+        double sum[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) sum[s] = 0.;
+        for (int k0 = 0; k0 < width; k0 += 8) {
+            int c[8];
+            double v[S][8];
+            const int64_t p0 = base + (int64_t)k0 * 64;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool in = k0 + u < len;
+                c[u] = in ? M.cslot[p0 + (int64_t)u * 64] : first_slot;
+                const bool prev = c[u] >= 0 && c[u] < first_slot;  // a column swept by an earlier colour: the only ones that are not zero yet
+#pragma unroll
+                for (int s = 0; s < S; ++s) v[s][u] = prev ? M.val[s][p0 + (int64_t)u * 64] : 0.;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (c[u] >= 0 && c[u] < first_slot) {
+#pragma unroll
+                    for (int s = 0; s < S; ++s) sum[s] += v[s][u] * xh[(int64_t)S * c[u] + s];
+                }
+            }
+        }
+        const int d = i >= 0 ? M.diag_off[slot] : -1;
+        if (i >= 0 && d < 0 && len > 0) atomicCAS(status, 0, (int)ORC_ERR_STRUCTURAL_ZERO);  // get(i, i) panics (lib.rs:664)
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            double xi = 0.;
+            if (d >= 0) xi = 0. * (1. - 1.) + 1. * (b[S * slot + s] - sum[s]) / M.val[s][d];  // x_i (1 - w) + w (b_i - sum) / a_ii with x_i = 0, w = 1
+            xh[S * slot + s] = xi;
+        }
+    }
+}
+
+__device__ __forceinline__ bool gx_frozen(const double *sc, int guard) { return guard && (sc[GX_FROZEN] != 0. || sc[GX_FROZEN2] != 0.); }
+
+// rho_0 = sum(r) of every system from the residual product's partial sums (one workgroup)
+template <int S>
+__global__ __launch_bounds__(kBlock) void gsx_rho0_k(double *__restrict__ scal, const double *__restrict__ fold, int fold_count) {
+    __shared__ double lds16[16];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const double rho = fold_partials_block(fold + (size_t)s * fold_count, fold_count, lds16);
+        if (threadIdx.x == 0) scal[GX_STRIDE * s + GX_RHO0] = rho;
+    }
+}
+// s = r - alpha nu, alpha = rho / sum(nu)                                         (:257, :259)
+template <int S>
+__global__ __launch_bounds__(kBlock) void gsx_s_k(double *__restrict__ scal, int rho_idx, const double *__restrict__ r, const double *__restrict__ nu,
+                                                  double *__restrict__ sv, int64_t n, int guard, const double *__restrict__ fold, int fold_count) {
+    __shared__ double lds16[16];
+    double alpha[S];
+    bool act[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        double *sc = scal + GX_STRIDE * s;
+        const bool frz = gx_frozen(sc, guard);
+        const double sum_nu = fold_partials_block(fold + (size_t)s * fold_count, fold_count, lds16);
+        const double rho = sc[rho_idx];
+        alpha[s] = rho / sum_nu;
+        const bool bad = guard && !(fin_nz(rho) && fin_nz(sum_nu) && isfinite(alpha[s]));
+        act[s] = !frz && !bad;
+        if (blockIdx.x == 0 && threadIdx.x == 0 && !frz) {
+            sc[GX_SUM_NU] = sum_nu;
+            if (bad) sc[GX_FROZEN] = 1.;
+        }
+    }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+            if (act[s]) sv[S * i + s] = r[S * i + s] - alpha[s] * nu[S * i + s];
+    }
+}
+// x = (x + alpha p^) + omega s^ ; r = s - omega t ; partial sum(r)                (:258, :261-265, right-preconditioned)
+template <int S>
+__global__ __launch_bounds__(kBlock) void gsx_xr_k(double *__restrict__ scal, int rho_idx, double *__restrict__ x, const double *__restrict__ ph,
+                                                   const double *__restrict__ sh, const double *__restrict__ sv, const double *__restrict__ t,
+                                                   double *__restrict__ r, const int *__restrict__ rowid, int64_t n, double *__restrict__ partials,
+                                                   int guard, const double *__restrict__ fold, int fold_count) {
+    __shared__ double lds[8];
+    __shared__ double lds16[16];
+    double alpha[S], omega[S], acc[S];
+    int state[S];  // 0 = normal, 1 = t vanished or overflowed (x = h, r = s, stop), 2 = frozen (no-op)
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        double *sc = scal + GX_STRIDE * s;
+        const bool frz = guard && sc[GX_FROZEN] != 0.;
+        const double ts = fold_partials_block(fold + (size_t)(2 * s) * fold_count, fold_count, lds16);
+        const double tt = fold_partials_block(fold + (size_t)(2 * s + 1) * fold_count, fold_count, lds16);
+        alpha[s] = sc[rho_idx] / sc[GX_SUM_NU];
+        omega[s] = ts / tt;
+        const bool bad = guard && !(fin_nz(tt) && isfinite(omega[s]));
+        if (bad) omega[s] = 0.;
+        state[s] = frz ? 2 : (bad ? 1 : 0);
+        acc[s] = 0.;
+        if (blockIdx.x == 0 && threadIdx.x == 0 && !frz) {
+            sc[GX_TS] = ts; sc[GX_TT] = tt;
+            if (bad) sc[GX_FROZEN2] = 1.;
+        }
+    }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const bool live = rowid[i] >= 0;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            if (state[s] == 2) continue;
+            const int64_t e = S * i + s;
+            const double h = x[e] + alpha[s] * ph[e];
+            x[e] = state[s] == 1 ? h : h + omega[s] * sh[e];
+            const double ri = state[s] == 1 ? sv[e] : sv[e] - omega[s] * t[e];
+            r[e] = ri;
+            if (live) acc[s] += ri;
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const double tsum = block_sum(acc[s], lds);
+        if (threadIdx.x == 0 && state[s] != 2) partials[(size_t)s * gridDim.x + blockIdx.x] = tsum;
+    }
+}
+// beta = rho / rho_prev * alpha / omega ; p = r + beta (p - omega nu)             (:266-267)
+template <int S>
+__global__ __launch_bounds__(kBlock) void gsx_p_k(double *__restrict__ scal, int rho_prev_idx, int rho_idx, const double *__restrict__ r,
+                                                  const double *__restrict__ nu, double *__restrict__ p, int64_t n, int guard,
+                                                  const double *__restrict__ fold, int fold_count) {
+    __shared__ double lds16[16];
+    double beta[S], omega[S];
+    bool act[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        double *sc = scal + GX_STRIDE * s;
+        const bool frz = gx_frozen(sc, guard);
+        const double rho = fold_partials_block(fold + (size_t)s * fold_count, fold_count, lds16);
+        const double rho_prev = sc[rho_prev_idx];
+        const double alpha = rho_prev / sc[GX_SUM_NU];
+        omega[s] = sc[GX_TS] / sc[GX_TT];
+        beta[s] = rho / rho_prev * alpha / omega[s];
+        const bool bad = guard && !(fin_nz(omega[s]) && isfinite(beta[s]));
+        act[s] = !frz && !bad;
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            if (!frz) {
+                sc[rho_idx] = rho;
+                if (bad) sc[GX_FROZEN] = 1.;
+            } else if (sc[GX_FROZEN2] != 0.) {
+                sc[GX_FROZEN] = 1.;  // the x / r update took x = h, r = s: promote, or the next one would add alpha p^ again (see bicg_p_k)
+            }
+        }
+    }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+            if (act[s]) p[S * i + s] = r[S * i + s] + beta[s] * (p[S * i + s] - omega[s] * nu[S * i + s]);
+    }
+}
+template <int S>
+__global__ void gsx_guard_event_k(const double *__restrict__ scal, int *__restrict__ counter) {
+    int c = 0;
+    for (int s = 0; s < S; ++s)
+        if (scal[GX_STRIDE * s + GX_FROZEN] != 0. || scal[GX_STRIDE * s + GX_FROZEN2] != 0.) ++c;
+    if (c) atomicAdd(counter, c);
+}
+
+static inline int gsx_grid(int64_t work_groups) {  // <= 1024 workgroups: every consumer folds the partial sums of its producer
+    int64_t g = std::min<int64_t>(work_groups, 1024);
+    if (g >= 8) g = (g / 8) * 8;
+    return clamp_partials_grid(g);
+}
+
+// linear_algebra.rs:247-269 right-preconditioned by one coloured Gauss-Seidel sweep (extension), S systems on one pattern.
+// M: colour-sorted storage with this solve's values; b[s], x[s]: the systems' vectors in ROW order (x in / out).
+template <int S>
+static int gsx_bicgstab(const SlotMat<S> &M, const std::vector<int> &color_slice, const CVecs<S> &b, const MVecs<S> &x, uint64_t iteration_count, Arena &arena,
+                        int *status) {
+    hipStream_t st = ctx().stream;
+    const int64_t ns = M.n_slots;
+    const size_t len = (size_t)S * (size_t)std::max<int64_t>(ns, 1);
+    double *bs, *xs, *r, *p, *nu, *sv, *t, *ph, *sh, *partials, *partials2, *scal;
+    ORC_TRY(arena.alloc(len, &bs)); ORC_TRY(arena.alloc(len, &xs)); ORC_TRY(arena.alloc(len, &r)); ORC_TRY(arena.alloc(len, &p));
+    ORC_TRY(arena.alloc(len, &nu)); ORC_TRY(arena.alloc(len, &sv)); ORC_TRY(arena.alloc(len, &t)); ORC_TRY(arena.alloc(len, &ph));
+    ORC_TRY(arena.alloc(len, &sh));
+    ORC_TRY(arena.alloc((size_t)2 * S * kMaxPartials, &partials));
+    ORC_TRY(arena.alloc((size_t)S * kMaxPartials, &partials2));
+    ORC_TRY(arena.alloc((size_t)S * GX_STRIDE, &scal));
+    ORC_HIP(hipMemsetAsync(scal, 0, S * GX_STRIDE * sizeof(double), st));
+    const int guard = ctx().breakdown_guard ? 1 : 0;
+    const int vg = gsx_grid((ns + kBlock - 1) / kBlock), g = gsx_grid(((int64_t)M.n_slices + 3) / 4);
+    CVecs<S> xc;
+    for (int s = 0; s < S; ++s) xc.p[s] = x.p[s];
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gsx_in_k<S>), dim3(vg), dim3(kBlock), 0, st, M.rowid, ns, b, bs);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gsx_in_k<S>), dim3(vg), dim3(kBlock), 0, st, M.rowid, ns, xc, xs);
+    auto sweep = [&](const double *rhs, double *out) {
+        for (size_t c = 0; c + 1 < color_slice.size(); ++c) {
+            const int lo = color_slice[c], hi = color_slice[c + 1];
+            if (hi <= lo) continue;
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(gsx_sweep0_k<S>), dim3(std::min(kMaxGrid, (hi - lo + 3) / 4)), dim3(kBlock), 0, st, M, rhs, out, lo, hi, status);
+        }
+    };
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gsx_spmv_k<S, 0>), dim3(g), dim3(kBlock), 0, st, M, (const double *)xs, (const double *)bs, r, p, partials);  // r = b - A x ; p = r
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gsx_rho0_k<S>), dim3(1), dim3(kBlock), 0, st, scal, (const double *)partials, g);
+    for (uint64_t it = 0; it < iteration_count; ++it) {
+        const int cur = (int)(it & 1), nxt = cur ^ 1;
+        sweep(p, ph);                                                                                                               // p^ = M^-1 p
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(gsx_spmv_k<S, 1>), dim3(g), dim3(kBlock), 0, st, M, (const double *)ph, (const double *)nullptr, nu, (double *)nullptr, partials);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(gsx_s_k<S>), dim3(vg), dim3(kBlock), 0, st, scal, GX_RHO0 + cur, (const double *)r, (const double *)nu, sv, ns, guard,
+                           (const double *)partials, g);
+        sweep(sv, sh);                                                                                                              // s^ = M^-1 s
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(gsx_spmv_k<S, 2>), dim3(g), dim3(kBlock), 0, st, M, (const double *)sh, (const double *)sv, t, (double *)nullptr, partials);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(gsx_xr_k<S>), dim3(vg), dim3(kBlock), 0, st, scal, GX_RHO0 + cur, xs, (const double *)ph, (const double *)sh, (const double *)sv,
+                           (const double *)t, r, M.rowid, ns, partials2, guard, (const double *)partials, g);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(gsx_p_k<S>), dim3(vg), dim3(kBlock), 0, st, scal, GX_RHO0 + cur, GX_RHO0 + nxt, (const double *)r, (const double *)nu, p, ns, guard,
+                           (const double *)partials2, vg);
+    }
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gsx_out_k<S>), dim3(vg), dim3(kBlock), 0, st, M.rowid, ns, (const double *)xs, x);
+    ORC_HIP(hipGetLastError());
+    if (guard && ctx().guard_events) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(gsx_guard_event_k<S>), dim3(1), dim3(1), 0, st, (const double *)scal, ctx().guard_events);
+        ORC_HIP(hipGetLastError());
+    }
+    return ORC_OK;
+}
+
+// is the slot-space solver used?  (ORC_GS_SLOTSPACE=0: r03's row-space recurrences; read per solve: the tests compare the two)
+static inline bool gsx_enabled() { return !(getenv("ORC_GS_SLOTSPACE") && atoi(getenv("ORC_GS_SLOTSPACE")) == 0); }
+
+// The u, v, w momentum systems of a SIMPLE iteration (solver.rs:99-136) under ORC_SOLVER_BICGSTAB_GS_PRECOND, in lock-step: the views
+// share the mesh pattern (persistent: its colouring and colour-sorted layout are cached); b[k], x[k] in row order.  Single GPU.
+int gs_bicgstab3_dev(const MatView A[3], const double *const b[3], double *const x[3], uint64_t iteration_count, Arena &arena) {
+    const int64_t n = A[0].P.n;
+    if (n == 0) return ORC_OK;
+    if (!A[0].persistent_pattern || A[0].halo) return set_error(ORC_ERR_BAD_ARGUMENT, "gs_bicgstab3_dev: mesh-pattern systems on one GPU only");
+    hipStream_t st = ctx().stream;
+    std::unique_ptr<Coloring> owned;
+    const Coloring *C = nullptr;
+    ArenaScope scope(arena);
+    ORC_TRY(get_coloring(A[0], owned, &C, &arena));
+    if (!C->sorted.built) return set_error(ORC_ERR_BAD_ARGUMENT, "gs_bicgstab3_dev: no colour-sorted layout (ORC_GS_SORTED=0?)");
+    int *status;
+    ORC_TRY(arena.alloc((size_t)1, &status));
+    ORC_HIP(hipMemsetAsync(status, 0, sizeof(int), st));
+    SlotMat<3> M;
+    M.sp = C->sorted.slice_ptr.p; M.row_len = C->sorted.row_len.p; M.rowid = C->sorted.rowid.p; M.diag_off = C->sorted.diag_off.p; M.cslot = C->sorted.cslot.p;
+    M.n_slices = C->sorted.n_slices; M.n_slots = C->sorted.n_slots;
+    CVecs<3> bv;
+    MVecs<3> xv;
+    for (int k = 0; k < 3; ++k) {
+        double *vals;
+        ORC_TRY(arena.alloc((size_t)std::max<int64_t>(C->sorted.padded, 1), &vals));
+        hipLaunchKernelGGL(gs_permute_values_k, dim3(grid_for(n)), dim3(kBlock), 0, st, A[k], C->sorted.slot_of_row.p, C->sorted.slice_ptr.p, vals);
+        M.val[k] = vals; bv.p[k] = b[k]; xv.p[k] = x[k];
+    }
+    ORC_HIP(hipGetLastError());
+    ORC_TRY(gsx_bicgstab<3>(M, C->sorted.color_slice, bv, xv, iteration_count, arena, status));
+    int h = 0;
+    ORC_HIP(hipMemcpyAsync(&h, status, sizeof(int), hipMemcpyDeviceToHost, st));
+    ORC_HIP(hipStreamSynchronize(st));
+    return h == ORC_ERR_STRUCTURAL_ZERO ? h : ORC_OK;
+}
+bool gs_slot_space_enabled() { return gsx_enabled(); }
+
 int gs_arm_dev(const MatView &A, const double *b, double *x, uint64_t iteration_count, double relaxation_factor, int method, Arena &arena) {
     const int64_t n = A.P.n;
     if (n == 0) return ORC_OK;
@@ -648,6 +1041,7 @@ int gs_arm_dev(const MatView &A, const double *b, double *x, uint64_t iteration_
         ORC_HIP(hipGetLastError());
         view.sp = C->sorted.slice_ptr.p; view.row_len = C->sorted.row_len.p; view.rowid = C->sorted.rowid.p; view.diag_off = C->sorted.diag_off.p;
         view.col = C->sorted.col.p; view.val = vals; view.color_slice = C->sorted.color_slice;
+        view.cslot = C->sorted.cslot.p; view.n_slices = C->sorted.n_slices;
     } else if (sorted_enabled && !A.persistent_pattern) {
         ORC_TRY(build_sorted_on_device(A, *C, arena, view));
     }
@@ -657,6 +1051,14 @@ int gs_arm_dev(const MatView &A, const double *b, double *x, uint64_t iteration_
             if (A.halo) ORC_TRY(A.halo->exchange(x));
             ORC_TRY(gs_sweep(A, *C, b, x, relaxation_factor, status, sv));
         }
+    } else if (!global && sv->ok() && sv->cslot && gsx_enabled()) {  // [r04] the same recurrences in slot space (single GPU)
+        SlotMat<1> M;
+        M.sp = sv->sp; M.row_len = sv->row_len; M.rowid = sv->rowid; M.diag_off = sv->diag_off; M.cslot = sv->cslot; M.val[0] = sv->val;
+        M.n_slices = sv->n_slices; M.n_slots = (int64_t)sv->n_slices * 64;
+        CVecs<1> bv;
+        MVecs<1> xv;
+        bv.p[0] = b; xv.p[0] = x;
+        ORC_TRY(gsx_bicgstab<1>(M, sv->color_slice, bv, xv, iteration_count, arena, status));
     } else {  // ORC_SOLVER_BICGSTAB_GS_PRECOND: linear_algebra.rs:247-269 with p^ = M^-1 p, s^ = M^-1 s, M^-1 = one GS sweep from 0
         const size_t nn = (size_t)std::max(A.P.ncols, n);  // products gather ghost entries of p^ and s^
         double *r, *p, *nu, *s, *t, *ph, *sh, *partials, *scal;
@@ -734,6 +1136,74 @@ int bench_gs_sweep_dev(const MatView &A, const double *b, double *x, int reps, A
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     return rc;
+}
+
+// [r04] the preconditioner application as the slot-space solver launches it: x^ = M^-1 b from zero (gsx_sweep0_k, n_colors launches, no
+// zero fill), one system (ms[0]) and u, v, w per launch (ms[1]); A[k]: the three momentum views on the mesh pattern
+int bench_gs_sweep0_dev(const MatView A[3], const double *const b[3], int reps, Arena &arena, float ms[2], int *n_colors) {
+    const int64_t n = A[0].P.n;
+    ms[0] = ms[1] = 0.f;
+    if (n == 0) return ORC_OK;
+    hipStream_t st = ctx().stream;
+    std::unique_ptr<Coloring> owned;
+    const Coloring *C = nullptr;
+    ArenaScope scope(arena);
+    ORC_TRY(get_coloring(A[0], owned, &C, &arena));
+    if (!C->sorted.built) return set_error(ORC_ERR_BAD_ARGUMENT, "no colour-sorted layout");
+    if (n_colors) *n_colors = C->n_colors;
+    int *status;
+    ORC_TRY(arena.alloc((size_t)1, &status));
+    ORC_HIP(hipMemsetAsync(status, 0, sizeof(int), st));
+    SlotMat<3> M3;
+    M3.sp = C->sorted.slice_ptr.p; M3.row_len = C->sorted.row_len.p; M3.rowid = C->sorted.rowid.p; M3.diag_off = C->sorted.diag_off.p; M3.cslot = C->sorted.cslot.p;
+    M3.n_slices = C->sorted.n_slices; M3.n_slots = C->sorted.n_slots;
+    CVecs<3> bv;
+    for (int k = 0; k < 3; ++k) {
+        double *vals;
+        ORC_TRY(arena.alloc((size_t)std::max<int64_t>(C->sorted.padded, 1), &vals));
+        hipLaunchKernelGGL(gs_permute_values_k, dim3(grid_for(n)), dim3(kBlock), 0, st, A[k], C->sorted.slot_of_row.p, C->sorted.slice_ptr.p, vals);
+        M3.val[k] = vals; bv.p[k] = b[k];
+    }
+    SlotMat<1> M1;
+    M1.sp = M3.sp; M1.row_len = M3.row_len; M1.rowid = M3.rowid; M1.diag_off = M3.diag_off; M1.cslot = M3.cslot; M1.val[0] = M3.val[0];
+    M1.n_slices = M3.n_slices; M1.n_slots = M3.n_slots;
+    CVecs<1> b1;
+    b1.p[0] = b[0];
+    const int64_t ns = M3.n_slots;
+    double *bs3, *xh3, *bs1, *xh1;
+    ORC_TRY(arena.alloc((size_t)3 * ns, &bs3)); ORC_TRY(arena.alloc((size_t)3 * ns, &xh3));
+    ORC_TRY(arena.alloc((size_t)ns, &bs1)); ORC_TRY(arena.alloc((size_t)ns, &xh1));
+    const int vg = gsx_grid((ns + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gsx_in_k<3>), dim3(vg), dim3(kBlock), 0, st, M3.rowid, ns, bv, bs3);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gsx_in_k<1>), dim3(vg), dim3(kBlock), 0, st, M1.rowid, ns, b1, bs1);
+    ORC_HIP(hipGetLastError());
+    const std::vector<int> &cs = C->sorted.color_slice;
+    auto timed = [&](auto &&sweep, float *out) -> int {
+        hipEvent_t e0, e1;
+        ORC_HIP(hipEventCreate(&e0));
+        ORC_HIP(hipEventCreate(&e1));
+        sweep();  // warm
+        int rc = hipEventRecord(e0, st) == hipSuccess ? ORC_OK : set_error(ORC_ERR_HIP, "hipEventRecord failed");
+        for (int i = 0; i < reps && rc == ORC_OK; ++i) sweep();
+        if (rc == ORC_OK && (hipEventRecord(e1, st) != hipSuccess || hipEventSynchronize(e1) != hipSuccess)) rc = set_error(ORC_ERR_HIP, "hipEventRecord failed");
+        if (rc == ORC_OK && hipEventElapsedTime(out, e0, e1) != hipSuccess) rc = set_error(ORC_ERR_HIP, "hipEventElapsedTime failed");
+        if (rc == ORC_OK) *out /= (float)std::max(reps, 1);
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        return rc;
+    };
+    ORC_TRY(timed([&] {
+        for (size_t c = 0; c + 1 < cs.size(); ++c)
+            if (cs[c + 1] > cs[c])
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(gsx_sweep0_k<1>), dim3(std::min(kMaxGrid, (cs[c + 1] - cs[c] + 3) / 4)), dim3(kBlock), 0, st, M1, (const double *)bs1, xh1, cs[c], cs[c + 1], status);
+    }, &ms[0]));
+    ORC_TRY(timed([&] {
+        for (size_t c = 0; c + 1 < cs.size(); ++c)
+            if (cs[c + 1] > cs[c])
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(gsx_sweep0_k<3>), dim3(std::min(kMaxGrid, (cs[c + 1] - cs[c] + 3) / 4)), dim3(kBlock), 0, st, M3, (const double *)bs3, xh3, cs[c], cs[c + 1], status);
+    }, &ms[1]));
+    ORC_HIP(hipGetLastError());
+    return ORC_OK;
 }
 
 // test hook: the colouring of a pattern (host arrays out)

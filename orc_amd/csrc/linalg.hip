@@ -40,37 +40,6 @@ int reduce_partials(const double *partials, int count, int nq, double *out, bool
     return ORC_OK;
 }
 
-// The same fold done by EVERY workgroup of the kernel that consumes the sum (256 threads): four passes over
-// reduce_partials_k's 16 virtual wavefronts, so the association — and therefore every bit — is that of the one-workgroup
-// kernel.  A BiCGSTAB iteration has three such sums; as separate one-workgroup launches they sit between the big kernels
-// of their stream and, when other streams fill the chip, wait for a slot each time (84 us on average in the concurrent
-// schedule against 4.8 us alone).  Returns the sum to every thread.
-__device__ __forceinline__ double fold_partials_block(const double *__restrict__ partials, int count, double *lds16 /* 16 doubles */) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;  // blockDim.x == 256
-    double a[4], b[4];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {  // virtual thread vt of 1024 adds partials[vt] and partials[vt + 1024] (count <= 2048)
-        const int vt = (w + 4 * p) * 64 + lane;
-        a[p] = vt < count ? partials[vt] : 0.;
-        b[p] = vt + 1024 < count ? partials[vt + 1024] : 0.;
-    }
-    __syncthreads();  // lds16 may still be read from a previous fold
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int vt = (w + 4 * p) * 64 + lane;
-        double v = 0.;
-        if (vt < count) v += a[p];
-        if (vt + 1024 < count) v += b[p];
-        v = wave_sum(v);
-        if (lane == 0) lds16[w + 4 * p] = v;
-    }
-    __syncthreads();
-    double r = 0.;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) r += lds16[i];
-    return r;
-}
-
 // ------------------------------------------------------------------ reference-order reductions (verification mode)
 // OrcSettings.reduction_order = ORC_REDUCTION_REFERENCE: every dot product / norm of the solvers is evaluated in the
 // association of nalgebra 0.32.4's `dotx` (base/blas.rs): eight running accumulators
@@ -142,6 +111,51 @@ __global__ __launch_bounds__(1024) void dot_reference_k(const double *__restrict
 
 int dot_reference(const double *a, const double *b, int64_t n, double *out, const double *skip_flags) {
     hipLaunchKernelGGL(dot_reference_k, dim3(1), dim3(1024), 0, ctx().stream, a, b, n, out, skip_flags);
+    ORC_HIP(hipGetLastError());
+    return ORC_OK;
+}
+
+// out[0] = ((0 + a[0]) + a[1]) + ...: the plain left-to-right fold behind nalgebra's `sum()` / `mean()` (solver.rs:206-208) and the
+// running sums of the reference's cell loops (solver.rs:1224, discretization.rs:338) — ONE chain of n dependent additions (about
+// 35 ms for 10.24 M elements): lane 0 of wavefront 0 walks LDS tiles the other fifteen wavefronts fill.  Verification mode only.
+__global__ __launch_bounds__(1024) void sum_reference_k(const double *__restrict__ a, int64_t n, double *__restrict__ out) {
+    __shared__ double tile[2][kDotTile];
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int64_t n_tiles = (n + kDotTile - 1) / kDotTile;
+    auto load = [&](int64_t t, int first, int stride) {
+        double *dst = tile[t & 1];
+        const int64_t base = t * kDotTile;
+        for (int e = first; e < kDotTile; e += stride)
+            if (base + e < n) dst[e] = a[base + e];
+    };
+    double acc = 0.;
+    if (n_tiles > 0) load(0, tid, 1024);
+    __syncthreads();
+    for (int64_t t = 0; t < n_tiles; ++t) {
+        if (wave == 0) {
+            if (tid == 0) {
+                const double *src = tile[t & 1];
+                const int64_t left = n - t * kDotTile;
+                const int cnt = (int)(left < kDotTile ? left : kDotTile);
+                int j = 0;
+                for (; j + 16 <= cnt; j += 16) {
+                    double v[16];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) v[q] = src[j + q];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc += v[q];
+                }
+                for (; j < cnt; ++j) acc += src[j];
+            }
+        } else if (t + 1 < n_tiles) {
+            load(t + 1, tid - 64, 960);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) out[0] = acc;
+}
+int sum_reference(const double *a, int64_t n, double *out) {
+    hipLaunchKernelGGL(sum_reference_k, dim3(1), dim3(1024), 0, ctx().stream, a, n, out);
     ORC_HIP(hipGetLastError());
     return ORC_OK;
 }

@@ -260,6 +260,8 @@ int residual_dev(const MatView &A, const double *b, const double *x, double *r);
 int residual_norm2_dev(const MatView &A, const double *b, const double *x, double *partials, double *out, double *r_scratch = nullptr);
 // out[0] = a . b in nalgebra's dotx association (a == nullptr: the all-ones vector); one wavefront, verification mode only
 int dot_reference(const double *a, const double *b, int64_t n, double *out, const double *skip_flags);
+// out[0] = the left-to-right sum of a (nalgebra's sum(): solver.rs:206-208; the running sums of the reference's cell loops); verification mode
+int sum_reference(const double *a, int64_t n, double *out);
 
 // ---- three systems in lock-step (MatView3): interleaved vectors of 3 n doubles
 int interleave3_dev(const double *a, const double *b, const double *c, double *out3, int64_t n);
@@ -301,6 +303,11 @@ struct TripleLane {
 int multigrid_arm3_dev(const MatView3 &A3, const double *const b[3], double *const x[3], uint64_t iteration_count, double relaxation_factor,
                        double convergence_threshold, int preconditioner, Arena &arena, TripleLane lanes[3], SiblingPairing *sibling, int status_out[3],
                        const std::function<void()> &on_hierarchies_built = nullptr);  // called once, from the calling thread, when the three set-ups are through
+
+// [r04] multicolour-GS-preconditioned BiCGSTAB (extension, gs.hip) for the three momentum systems in lock-step on the mesh pattern
+// (BASELINE configs[2]); b[k], x[k] in row order, x in / out; single GPU.  gs_slot_space_enabled: ORC_GS_SLOTSPACE != 0.
+int gs_bicgstab3_dev(const MatView A[3], const double *const b[3], double *const x[3], uint64_t iteration_count, Arena &arena);
+bool gs_slot_space_enabled();
 
 // plain vector helpers used by the SIMPLE driver
 int vec_fill(double *x, double v, int64_t n);

@@ -24,6 +24,37 @@ __device__ __forceinline__ T ld_stream(const T *p) {
     return *p;
 }
 
+// The same fold done by EVERY workgroup of the kernel that consumes the sum (256 threads): four passes over
+// reduce_partials_k's 16 virtual wavefronts, so the association — and therefore every bit — is that of the one-workgroup
+// kernel.  A BiCGSTAB iteration has three such sums; as separate one-workgroup launches they sit between the big kernels
+// of their stream and, when other streams fill the chip, wait for a slot each time (84 us on average in the concurrent
+// schedule against 4.8 us alone).  Returns the sum to every thread.
+__device__ __forceinline__ double fold_partials_block(const double *__restrict__ partials, int count, double *lds16 /* 16 doubles */) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;  // blockDim.x == 256
+    double a[4], b[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {  // virtual thread vt of 1024 adds partials[vt] and partials[vt + 1024] (count <= 2048)
+        const int vt = (w + 4 * p) * 64 + lane;
+        a[p] = vt < count ? partials[vt] : 0.;
+        b[p] = vt + 1024 < count ? partials[vt + 1024] : 0.;
+    }
+    __syncthreads();  // lds16 may still be read from a previous fold
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int vt = (w + 4 * p) * 64 + lane;
+        double v = 0.;
+        if (vt < count) v += a[p];
+        if (vt + 1024 < count) v += b[p];
+        v = wave_sum(v);
+        if (lane == 0) lds16[w + 4 * p] = v;
+    }
+    __syncthreads();
+    double r = 0.;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r += lds16[i];
+    return r;
+}
+
 // XCD-aware slice walk: workgroups b and b+8 share an XCD (MI355X_MICROARCH "Workgroup dispatch"),
 // so XCD g = blockIdx%8 sweeps the contiguous slice range [g*spx, (g+1)*spx): the x-vector
 // window a row block needs (i+-1, i+-nx, i+-nx*ny) then stays inside one XCD's 4 MiB L2 instead

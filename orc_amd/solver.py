@@ -126,6 +126,13 @@ class Solver:
         self.inloop_variant = lib().orc_bench_inloop_variant().decode()  # "<narrow>, <scaled>, <non-temporal>" template arguments of those launches
         return [ms[k] for k in range(4)]
 
+    def bench_gs_sweep0(self, reps=50):
+        """orc_bench_gs_sweep0: (ms per sweep-from-zero of one system, ms per sweep of u, v, w in one launch per colour, colours)"""
+        ms = (C.c_double * 2)()
+        nc = C.c_int(0)
+        check(lib().orc_bench_gs_sweep0(self.ptr, C.c_int(reps), ms, C.byref(nc)))
+        return ms[0], ms[1], nc.value
+
     def bench_gs_sweep(self, reps=50):
         """orc_bench_gs_sweep: (ms per multicolour Gauss-Seidel sweep over a_u, number of colours = launches per sweep)"""
         ms, nc = C.c_double(0.0), C.c_int(0)

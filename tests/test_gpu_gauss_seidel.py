@@ -130,3 +130,52 @@ def test_solve_steady_with_gs_preconditioned_bicgstab(gpu, oracle, mesh_path):
     s.iterate(1500)
     u, v, w, p = s.get_fields()
     assert H.rel_l2(u, uo) < 1e-6 and H.rel_l2(p, po_) < 1e-6
+
+
+def test_slot_space_solver_follows_the_row_space_recurrences(gpu, monkeypatch):
+    """[r04] The GS-preconditioned BiCGSTAB now lives in the colour-sorted numbering (gs.hip: gsx_*): vectors permuted once, the
+    preconditioner sweep from zero without a zero fill (columns of the colour's own and later colours are skipped: exact zeros),
+    sums folded by their consumers.  Row sums and sweeps keep their bits; only the partial sums group rows differently, so after a few
+    iterations the two forms agree to rounding (ORC_GS_SLOTSPACE=0 = r03's row-space form), with and without the Jacobi scaling, and
+    both reach the solution."""
+    from orc_amd.linear_algebra import iterative_solve
+    a = fv_like_matrix(30, 24, 12)
+    n = a.shape[0]
+    xs = splitmix64_uniform(n, 3)
+    b = a @ xs
+    for precond in (0, 1):
+        out = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("ORC_GS_SLOTSPACE", mode)
+            x = 0.01 * splitmix64_uniform(n, 9)
+            iterative_solve(a, b, x, 5, BICGSTAB_GS, 1.0, 1e-3, precond)
+            out[mode] = x
+        assert np.isfinite(out["1"]).all()
+        assert np.linalg.norm(out["1"] - out["0"]) < 1e-10 * np.linalg.norm(out["0"]), precond
+        x = np.zeros(n)
+        monkeypatch.setenv("ORC_GS_SLOTSPACE", "1")
+        iterative_solve(a, b, x, 40, BICGSTAB_GS, 1.0, 1e-3, precond)
+        assert np.linalg.norm(x - xs) < 1e-9 * np.linalg.norm(xs)
+
+
+def test_gs_momentum_systems_in_lock_step_are_bit_identical_to_their_own_solves(gpu, monkeypatch):
+    """u, v, w per colour in ONE launch (interleaved slot-space vectors, three value streams on the shared colour-sorted pattern):
+    whole SIMPLE iterations with BASELINE configs[2]'s solver are bit-identical to the runs that solve the systems one at a time
+    (ORC_TRIPLE_MOMENTUM=0: three lanes, same kernels with S = 1), frozen systems included (w == 0 exactly on the one-cell-deep
+    channel: its solve breaks down at once and the guard freezes it while u and v carry on)."""
+    import helpers as H
+    from orc_amd.mesh import Mesh, hex_channel, set_channel_bcs
+    from orc_amd.settings import NumericalSettings
+    from orc_amd.solver import solve_steady
+    for shape, w_zero in (((24, 16, 10), False), ((40, 30, 1), True)):
+        a = set_channel_bcs(hex_channel(*shape))
+        s = NumericalSettings.default(momentum=4, solver_type=BICGSTAB_GS, iterations=12)
+        out = []
+        for triple in ("1", "0"):
+            monkeypatch.setenv("ORC_TRIPLE_MOMENTUM", triple)
+            u, v, w, p = H.seeded_fields(a, seed=8, scale_u=4e-4, w_zero=w_zero)
+            solve_steady(Mesh(a), u, v, w, p, s, 1000.0, 1e-3, 3)
+            out.append((u, v, w, p))
+        assert np.isfinite(out[0][0]).all()
+        for x, y in zip(*out):
+            assert np.array_equal(x, y), shape
