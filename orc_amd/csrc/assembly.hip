@@ -1118,6 +1118,23 @@ static int create_stream(hipStream_t *out, int role, int lane) {
     // the momentum phase (measured: 0.863-0.879 s per iteration against 0.903-0.909 s with 2, the round-1 setting that
     // favoured the then latency-bound set-up, and 0.926-0.957 s without priorities); 1: by lane; 0: none
     static const int prio_mode = getenv("ORC_STREAM_PRIORITIES") ? atoi(getenv("ORC_STREAM_PRIORITIES")) : 3;
+    // [r04] measurement: confine the SET-UP streams to a share of the CUs (ORC_SETUP_CU_MASK = a 32-bit hex pattern repeated over the
+    // device's CU mask words, e.g. 55555555 = every other CU of every XCD), so that the bandwidth-bound products beside them keep at
+    // least the rest of the chip to themselves; the solve streams stay unmasked.  (A masked stream has no priority class.)
+    static const char *mask_env = getenv("ORC_SETUP_CU_MASK");
+    if (mask_env && role == kSetupStream) {
+        const uint32_t pat = (uint32_t)strtoul(mask_env, nullptr, 16);
+        if (pat != 0u) {
+            uint32_t words[16];
+            for (int i = 0; i < 16; ++i) words[i] = pat;
+            hipDeviceProp_t prop;
+            int dev = 0;
+            int n_cu = 256;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
+            ORC_HIP(hipExtStreamCreateWithCUMask(out, (uint32_t)std::min(16, (n_cu + 31) / 32), words));
+            return ORC_OK;
+        }
+    }
     int least = 0, greatest = 0;
     if (prio_mode != 0 && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) {
         int klass = prio_mode == 1 ? lane : (role == kSolveStream ? 2 : 0);

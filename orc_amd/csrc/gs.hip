@@ -797,38 +797,45 @@ __device__ __forceinline__ bool gx_frozen(const double *sc, int guard) { return 
 // rho_0 = sum(r) of every system from the residual product's partial sums (one workgroup)
 template <int S>
 __global__ __launch_bounds__(kBlock) void gsx_rho0_k(double *__restrict__ scal, const double *__restrict__ fold, int fold_count) {
-    __shared__ double lds16[16];
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-        const double rho = fold_partials_block(fold + (size_t)s * fold_count, fold_count, lds16);
-        if (threadIdx.x == 0) scal[GX_STRIDE * s + GX_RHO0] = rho;
-    }
+    __shared__ double lds[S * 16];
+    double rho[S];
+    fold_partials_multi<S>(fold, fold_count, lds, rho);
+    if (threadIdx.x == 0)
+        for (int s = 0; s < S; ++s) scal[GX_STRIDE * s + GX_RHO0] = rho[s];
 }
+// The vector kernels work on the interleaved vectors as FLAT arrays (element e = S slot + s belongs to system e % S): fully coalesced
+// 8-byte accesses — a thread that handled "its slot's S values" touched 24-byte strides, 12 cache lines per wave instruction instead
+// of 4 (r04's first form: 1.9 TB/s).  Element-wise results do not depend on who computes them; the one reduction (sum(r) in gsx_xr_k)
+// hands its r values back to the slot's own thread through LDS, so the partial sums keep the thread -> slot map of S = 1.
 // s = r - alpha nu, alpha = rho / sum(nu)                                         (:257, :259)
 template <int S>
 __global__ __launch_bounds__(kBlock) void gsx_s_k(double *__restrict__ scal, int rho_idx, const double *__restrict__ r, const double *__restrict__ nu,
                                                   double *__restrict__ sv, int64_t n, int guard, const double *__restrict__ fold, int fold_count) {
-    __shared__ double lds16[16];
-    double alpha[S];
+    __shared__ double lds[S * 16];
+    double alpha[S], sum_nu[S];
     bool act[S];
+    fold_partials_multi<S>(fold, fold_count, lds, sum_nu);
 #pragma unroll
     for (int s = 0; s < S; ++s) {
         double *sc = scal + GX_STRIDE * s;
         const bool frz = gx_frozen(sc, guard);
-        const double sum_nu = fold_partials_block(fold + (size_t)s * fold_count, fold_count, lds16);
         const double rho = sc[rho_idx];
-        alpha[s] = rho / sum_nu;
-        const bool bad = guard && !(fin_nz(rho) && fin_nz(sum_nu) && isfinite(alpha[s]));
+        alpha[s] = rho / sum_nu[s];
+        const bool bad = guard && !(fin_nz(rho) && fin_nz(sum_nu[s]) && isfinite(alpha[s]));
         act[s] = !frz && !bad;
         if (blockIdx.x == 0 && threadIdx.x == 0 && !frz) {
-            sc[GX_SUM_NU] = sum_nu;
+            sc[GX_SUM_NU] = sum_nu[s];
             if (bad) sc[GX_FROZEN] = 1.;
         }
     }
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t total = (int64_t)S * n, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int s = (int)(e % S);
+        double a = alpha[0];
+        bool on = act[0];
 #pragma unroll
-        for (int s = 0; s < S; ++s)
-            if (act[s]) sv[S * i + s] = r[S * i + s] - alpha[s] * nu[S * i + s];
+        for (int q = 1; q < S; ++q) { if (s == q) { a = alpha[q]; on = act[q]; } }
+        if (on) sv[e] = r[e] - a * nu[e];
     }
 }
 // x = (x + alpha p^) + omega s^ ; r = s - omega t ; partial sum(r)                (:258, :261-265, right-preconditioned)
@@ -838,15 +845,16 @@ __global__ __launch_bounds__(kBlock) void gsx_xr_k(double *__restrict__ scal, in
                                                    double *__restrict__ r, const int *__restrict__ rowid, int64_t n, double *__restrict__ partials,
                                                    int guard, const double *__restrict__ fold, int fold_count) {
     __shared__ double lds[8];
-    __shared__ double lds16[16];
-    double alpha[S], omega[S], acc[S];
+    __shared__ double lds_f[2 * S * 16];
+    __shared__ double r_tile[S * kBlock];
+    double alpha[S], omega[S], acc[S], tsq[2 * S];
     int state[S];  // 0 = normal, 1 = t vanished or overflowed (x = h, r = s, stop), 2 = frozen (no-op)
+    fold_partials_multi<2 * S>(fold, fold_count, lds_f, tsq);  // (t.s, t.t) of system s at 2 s, 2 s + 1
 #pragma unroll
     for (int s = 0; s < S; ++s) {
         double *sc = scal + GX_STRIDE * s;
         const bool frz = guard && sc[GX_FROZEN] != 0.;
-        const double ts = fold_partials_block(fold + (size_t)(2 * s) * fold_count, fold_count, lds16);
-        const double tt = fold_partials_block(fold + (size_t)(2 * s + 1) * fold_count, fold_count, lds16);
+        const double ts = tsq[2 * s], tt = tsq[2 * s + 1];
         alpha[s] = sc[rho_idx] / sc[GX_SUM_NU];
         omega[s] = ts / tt;
         const bool bad = guard && !(fin_nz(tt) && isfinite(omega[s]));
@@ -858,18 +866,37 @@ __global__ __launch_bounds__(kBlock) void gsx_xr_k(double *__restrict__ scal, in
             if (bad) sc[GX_FROZEN2] = 1.;
         }
     }
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const bool live = rowid[i] >= 0;
+    // a workgroup takes chunks of kBlock consecutive slots (= S kBlock consecutive doubles of every vector); thread tid owns slot
+    // chunk * kBlock + tid for the sums — S = 1's map — and computes the flat elements chunk * S kBlock + tid + j kBlock, j < S
+    const int64_t n_chunks = (n + kBlock - 1) / kBlock, total = (int64_t)S * n;
+    for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        const int64_t base = chunk * (int64_t)S * kBlock;
 #pragma unroll
-        for (int s = 0; s < S; ++s) {
-            if (state[s] == 2) continue;
-            const int64_t e = S * i + s;
-            const double h = x[e] + alpha[s] * ph[e];
-            x[e] = state[s] == 1 ? h : h + omega[s] * sh[e];
-            const double ri = state[s] == 1 ? sv[e] : sv[e] - omega[s] * t[e];
-            r[e] = ri;
-            if (live) acc[s] += ri;
+        for (int j = 0; j < S; ++j) {
+            const int64_t e = base + threadIdx.x + (int64_t)j * kBlock;
+            double ri = 0.;
+            if (e < total) {
+                const int s = (int)(e % S);
+                double a = alpha[0], o = omega[0];
+                int stt = state[0];
+#pragma unroll
+                for (int q = 1; q < S; ++q) { if (s == q) { a = alpha[q]; o = omega[q]; stt = state[q]; } }
+                if (stt != 2) {
+                    const double h = x[e] + a * ph[e];
+                    x[e] = stt == 1 ? h : h + o * sh[e];
+                    ri = stt == 1 ? sv[e] : sv[e] - o * t[e];
+                    r[e] = ri;
+                }
+            }
+            r_tile[threadIdx.x + j * kBlock] = ri;
         }
+        __syncthreads();
+        const int64_t slot = chunk * kBlock + threadIdx.x;
+        if (slot < n && rowid[slot] >= 0) {
+#pragma unroll
+            for (int s = 0; s < S; ++s) acc[s] += r_tile[S * threadIdx.x + s];
+        }
+        __syncthreads();
     }
 #pragma unroll
     for (int s = 0; s < S; ++s) {
@@ -882,33 +909,37 @@ template <int S>
 __global__ __launch_bounds__(kBlock) void gsx_p_k(double *__restrict__ scal, int rho_prev_idx, int rho_idx, const double *__restrict__ r,
                                                   const double *__restrict__ nu, double *__restrict__ p, int64_t n, int guard,
                                                   const double *__restrict__ fold, int fold_count) {
-    __shared__ double lds16[16];
-    double beta[S], omega[S];
+    __shared__ double lds[S * 16];
+    double beta[S], omega[S], rho[S];
     bool act[S];
+    fold_partials_multi<S>(fold, fold_count, lds, rho);
 #pragma unroll
     for (int s = 0; s < S; ++s) {
         double *sc = scal + GX_STRIDE * s;
         const bool frz = gx_frozen(sc, guard);
-        const double rho = fold_partials_block(fold + (size_t)s * fold_count, fold_count, lds16);
         const double rho_prev = sc[rho_prev_idx];
         const double alpha = rho_prev / sc[GX_SUM_NU];
         omega[s] = sc[GX_TS] / sc[GX_TT];
-        beta[s] = rho / rho_prev * alpha / omega[s];
+        beta[s] = rho[s] / rho_prev * alpha / omega[s];
         const bool bad = guard && !(fin_nz(omega[s]) && isfinite(beta[s]));
         act[s] = !frz && !bad;
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             if (!frz) {
-                sc[rho_idx] = rho;
+                sc[rho_idx] = rho[s];
                 if (bad) sc[GX_FROZEN] = 1.;
             } else if (sc[GX_FROZEN2] != 0.) {
                 sc[GX_FROZEN] = 1.;  // the x / r update took x = h, r = s: promote, or the next one would add alpha p^ again (see bicg_p_k)
             }
         }
     }
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t total = (int64_t)S * n, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int s = (int)(e % S);
+        double bt = beta[0], o = omega[0];
+        bool on = act[0];
 #pragma unroll
-        for (int s = 0; s < S; ++s)
-            if (act[s]) p[S * i + s] = r[S * i + s] + beta[s] * (p[S * i + s] - omega[s] * nu[S * i + s]);
+        for (int q = 1; q < S; ++q) { if (s == q) { bt = beta[q]; o = omega[q]; on = act[q]; } }
+        if (on) p[e] = r[e] + bt * (p[e] - o * nu[e]);
     }
 }
 template <int S>

@@ -1116,7 +1116,7 @@ __device__ __forceinline__ bool bicg_frozen3(const double *__restrict__ scal3, i
 // bicg_s_k for three systems: s = r - alpha nu, alpha = rho / sum(nu); fold: the product's partial sums, system s at fold + s * fold_count
 __global__ __launch_bounds__(kBlock) void bicg_s3_k(double *__restrict__ scal3, int rho_idx, const double *__restrict__ r3, const double *__restrict__ nu3,
                                                     double *__restrict__ s3, int64_t n, int guard, const double *__restrict__ fold, int fold_count) {
-    __shared__ double lds16[16];
+    __shared__ double lds16[3 * 16];
     const int64_t n2 = n >> 1, stride = (int64_t)gridDim.x * blockDim.x;
     const double2 *r2 = reinterpret_cast<const double2 *>(r3), *nu2 = reinterpret_cast<const double2 *>(nu3);
     double2 *s2 = reinterpret_cast<double2 *>(s3);
@@ -1126,11 +1126,13 @@ __global__ __launch_bounds__(kBlock) void bicg_s3_k(double *__restrict__ scal3, 
     if (i < n2) { a0 = r2[3 * i]; a1 = r2[3 * i + 1]; a2 = r2[3 * i + 2]; b0 = nu2[3 * i]; b1 = nu2[3 * i + 1]; b2 = nu2[3 * i + 2]; }
     double alpha[3];
     bool act[3];
+    // fold_count == 0 (partitioned operator): fold holds the sums themselves — folded by reduce_partials_k, summed over the ranks
+    double folded[3] = {0., 0., 0.};
+    if (fold_count) fold_partials_multi<3>(fold, fold_count, lds16, folded);  // [r04] the three folds' loads in flight together, two barriers
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
         const bool frz = bicg_frozen3(scal3, s, guard);
-        // fold_count == 0 (partitioned operator): fold holds the sums themselves — folded by reduce_partials_k, summed over the ranks
-        const double sum_nu = fold_count ? fold_partials_block(fold + (size_t)s * fold_count, fold_count, lds16) : fold[s];
+        const double sum_nu = fold_count ? folded[s] : fold[s];
         const double rho = scal3[SC3(rho_idx, s)];
         alpha[s] = rho / sum_nu;
         const bool bad = guard && !(finite_nonzero(rho) && finite_nonzero(sum_nu) && isfinite(alpha[s]));
@@ -1171,18 +1173,20 @@ __global__ __launch_bounds__(kBlock) void bicg_xr3_k(double *__restrict__ scal3,
                                                      const double *__restrict__ s3, const double *__restrict__ t3, double *__restrict__ r3, int64_t n,
                                                      double *__restrict__ partials, int guard, const double *__restrict__ fold, int fold_count) {
     __shared__ double lds[8];
-    __shared__ double lds16[16];
+    __shared__ double lds16[6 * 16];
     const int64_t n2 = n >> 1, stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     double2 *x2 = reinterpret_cast<double2 *>(x3), *r2 = reinterpret_cast<double2 *>(r3);
     const double2 *p2 = reinterpret_cast<const double2 *>(p3), *s2 = reinterpret_cast<const double2 *>(s3), *t2 = reinterpret_cast<const double2 *>(t3);
     double alpha[3], omega[3];
     int state[3];  // 0 = normal, 1 = t = A s vanished or overflowed (x = h, r = s, stop), 2 = frozen (no-op)
+    double folded[6] = {0., 0., 0., 0., 0., 0.};
+    if (fold_count) fold_partials_multi<6>(fold, fold_count, lds16, folded);
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
         const bool frz = guard && scal3[SC3(S_FROZEN, s)] != 0.;
-        const double ts = fold_count ? fold_partials_block(fold + (size_t)(2 * s) * fold_count, fold_count, lds16) : fold[2 * s];
-        const double tt = fold_count ? fold_partials_block(fold + (size_t)(2 * s + 1) * fold_count, fold_count, lds16) : fold[2 * s + 1];
+        const double ts = fold_count ? folded[2 * s] : fold[2 * s];
+        const double tt = fold_count ? folded[2 * s + 1] : fold[2 * s + 1];
         alpha[s] = scal3[SC3(rho_idx, s)] / scal3[SC3(S_SUM_NU, s)];
         omega[s] = ts / tt;
         const bool bad = guard && !(finite_nonzero(tt) && isfinite(omega[s]));
@@ -1272,16 +1276,18 @@ __global__ __launch_bounds__(kBlock) void bicg_xr3_k(double *__restrict__ scal3,
 __global__ __launch_bounds__(kBlock) void bicg_p3_k(double *__restrict__ scal3, int rho_prev_idx, int rho_idx, const double *__restrict__ r3,
                                                     const double *__restrict__ nu3, double *__restrict__ p3, int64_t n, int guard,
                                                     const double *__restrict__ fold, int fold_count) {
-    __shared__ double lds16[16];
+    __shared__ double lds16[3 * 16];
     const int64_t n2 = n >> 1, stride = (int64_t)gridDim.x * blockDim.x;
     double2 *p2 = reinterpret_cast<double2 *>(p3);
     const double2 *r2 = reinterpret_cast<const double2 *>(r3), *nu2 = reinterpret_cast<const double2 *>(nu3);
     double beta[3], omega[3];
     bool act[3];
+    double folded[3] = {0., 0., 0.};
+    if (fold_count) fold_partials_multi<3>(fold, fold_count, lds16, folded);
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
         const bool frz = bicg_frozen3(scal3, s, guard);
-        const double rho = fold_count ? fold_partials_block(fold + (size_t)s * fold_count, fold_count, lds16) : fold[s];
+        const double rho = fold_count ? folded[s] : fold[s];
         const double rho_prev = scal3[SC3(rho_prev_idx, s)];
         const double alpha = rho_prev / scal3[SC3(S_SUM_NU, s)];
         omega[s] = scal3[SC3(S_TS, s)] / scal3[SC3(S_TT, s)];

@@ -55,6 +55,45 @@ __device__ __forceinline__ double fold_partials_block(const double *__restrict__
     return r;
 }
 
+// [r04] NQ such folds at once: quantity q's partial sums at partials + q * count.  All loads are issued first and the workgroup meets
+// at two barriers instead of 2 NQ — a three-system kernel folds 3 or 6 sums before it can start (six dependent round trips and twelve
+// barriers in a row were 10 % of a 1 M-cell vector kernel).  Per quantity the additions are fold_partials_block's: the same bits.
+template <int NQ>
+__device__ __forceinline__ void fold_partials_multi(const double *__restrict__ partials, int count, double *lds /* NQ * 16 doubles */, double (&out)[NQ]) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;  // blockDim.x == 256
+    double a[NQ][4], b[NQ][4];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int vt = (w + 4 * p) * 64 + lane;
+            a[q][p] = vt < count ? partials[(size_t)q * count + vt] : 0.;
+            b[q][p] = vt + 1024 < count ? partials[(size_t)q * count + vt + 1024] : 0.;
+        }
+    }
+    __syncthreads();  // lds may still be read from a previous fold
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int vt = (w + 4 * p) * 64 + lane;
+            double v = 0.;
+            if (vt < count) v += a[q][p];
+            if (vt + 1024 < count) v += b[q][p];
+            v = wave_sum(v);
+            if (lane == 0) lds[q * 16 + w + 4 * p] = v;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        double r = 0.;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) r += lds[q * 16 + i];
+        out[q] = r;
+    }
+}
+
 // XCD-aware slice walk: workgroups b and b+8 share an XCD (MI355X_MICROARCH "Workgroup dispatch"),
 // so XCD g = blockIdx%8 sweeps the contiguous slice range [g*spx, (g+1)*spx): the x-vector
 // window a row block needs (i+-1, i+-nx, i+-nx*ny) then stays inside one XCD's 4 MiB L2 instead

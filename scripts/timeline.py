@@ -65,3 +65,32 @@ for nm, rs in (("level 0 lock-step products", l0), ("level 1 lock-step products"
         d = sorted(r[1] - r[0] for r in rs)
         print("  %s: %d launches, median %.1f us, mean %.1f us, window %.1f .. %.1f ms" % (nm, len(rs), d[len(d) // 2] / 1e3, sum(d) / len(d) / 1e3,
               (min(r[0] for r in rs) - a) / 1e6, (max(r[1] for r in rs) - a) / 1e6))
+
+# ---- [r04] per-stream Gantt of the last iteration: consecutive kernels of one family on one stream merged into a segment (gaps < 0.3 ms
+# bridged), segments >= 1 ms listed: who runs when, and what each set-up thread is waiting behind
+def family2(name):
+    f = family(name)
+    if f:
+        return f
+    if name.startswith(("momentum_k", "face_k", "grad_", "pressure_k", "correction_k", "face_coef_k", "diffusion_k")):
+        return "assembly"
+    if name.startswith(("restrict", "prolong", "interleave", "deinterleave", "vec_", "scale_", "diag_inverse", "fill_k", "count_diff", "nan_to", "reduce_")):
+        return "transfers / scalings"
+    if name.startswith(("rows_compact", "narrow_build", "xsort")):
+        return "Galerkin + mirrors"
+    return "other"
+
+print("per-stream segments of the last iteration (ms from its start): stream: [start-end family (kernel ms, launches)]")
+by_stream = collections.defaultdict(list)
+for r in it:
+    by_stream[r[3]].append(r)
+for sid, rs in sorted(by_stream.items(), key=lambda kv: min(r[0] for r in kv[1])):
+    segs = []
+    for r in sorted(rs):
+        f = family2(r[2])
+        if segs and segs[-1][2] == f and r[0] - segs[-1][1] < 300000:
+            segs[-1][1] = max(segs[-1][1], r[1]); segs[-1][3] += r[1] - r[0]; segs[-1][4] += 1
+        else:
+            segs.append([r[0], r[1], f, r[1] - r[0], 1])
+    txt = ["%.0f-%.0f %s (%.0f ms, %d)" % ((s0 - a) / 1e6, (s1 - a) / 1e6, f, d / 1e6, c) for s0, s1, f, d, c in segs if s1 - s0 >= 1000000]
+    print("  stream %s: %s" % (sid, "; ".join(txt)))
