@@ -25,7 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PMC_FILE = "r03_spmv_pmc.json"  # written by scripts/pmc_summary_r03.py from the rocprofv3 --pmc passes of scripts/gpu_pmc_r03.sh
+PMC_FILE = "r04_spmv_pmc.json"  # written by scripts/pmc_summary_r04.py from the rocprofv3 --pmc passes of scripts/gpu_pmc_r04.sh
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy ceiling)
 REF_CELLS = 400 * 160 * 160
 
@@ -95,7 +95,8 @@ def cpu_baseline(settings_kw, sample=(100, 40, 40), iters=6, mixed_ref_cells=Non
         "rust_toolchain": "present" if shutil.which("cargo") else "absent (ORC itself cannot be built: the port is timed)",
         "kind": "port",
         "sample": "%dx%dx%d %s (%d cells = 1/%d of the workload), %d SIMPLE iterations in %.2f s, status %d; scaled by cells"
-                  % (nx, ny, nz, "blocks of the mixed channel" if mixed_ref_cells else "hex channel", n, ref_cells // n, iters, dt, st) + note,
+                  % (nx, ny, nz, "blocks of the mixed channel" if mixed_ref_cells else "hex channel", n, ref_cells // n, iters, dt, st) + note
+                  + "; the sample times iterations 1-%d from the seeded field (the GPU line times iteration spin-up + 1 of its run; an iteration's cost grows slowly with the state)" % iters,
     }
 
 
@@ -167,6 +168,9 @@ def main():
         raise SystemExit(spawn_ranks(args.gpus))
     if world != args.gpus:
         raise SystemExit("bench.py --gpus %d inside a torch.distributed.run of %d ranks: the two must agree" % (args.gpus, world))
+    if os.environ.get("ORC_BENCH_WATCHDOG"):  # debugging aid: after N seconds a rank prints its Python stacks and exits (a stuck collective shows itself)
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["ORC_BENCH_WATCHDOG"]), exit=True)
 
     dist = None
     if world > 1:
@@ -344,8 +348,14 @@ def main():
               "algorithmic_bytes_per_sweep": 3.0 * gs_bytes, "achieved": 3.0 * gs_bytes / (ms3 * 1e-3) / 1e9, "frac": 3.0 * gs_bytes / (ms3 * 1e-3) / 1e9 / HBM_PEAK_GBS,
               "note": "one sweep = 12 nnz + 20 n (SURVEY 8d) + 8 n (the right-hand side); at ~1 M cells the matrix (62 MB) lives in the 256 MiB "
                       "Infinity Cache and a launch covers 1/n_colors of the rows: these launches are latency-, not HBM-bound"}
+    if gs is not None and args.solver == "multigrid_gs":
+        # the smoother's sweeps start from the current iterate, not from zero: gs_color_sorted_k on every level is what this solver launches
+        gs.update({"kernel": "gs_color_sorted_k (level 0: the smoother's general sweep; gsx_sweep0_k belongs to the bicgstab_gs solver)",
+                   "avg_sweep_ms": gs_ms, "avg_launch_ms": gs_ms / max(gs_colors, 1), "algorithmic_bytes_per_sweep": gs_bytes,
+                   "achieved": gs_bytes / (gs_ms * 1e-3) / 1e9, "frac": gs_bytes / (gs_ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
     key = (args.nx, args.ny, args.nz, args.momentum, args.solver)
     workload_name = ("BASELINE configs[3]" if key == (400, 160, 160, "umist", "multigrid")
+                     else "BASELINE configs[3] as its text reads (AMG V-cycle with a GS smoother: an extension, ORC's smoother is BiCGSTAB)" if key == (400, 160, 160, "umist", "multigrid_gs")
                      else "BASELINE configs[2]" if key == (512, 2016, 1, "quick", "bicgstab_gs") else "custom")
     mixed = args.workload == "config5"
     if mixed:

@@ -1,0 +1,9 @@
+#!/bin/bash
+# r04 evidence run (part 2): BASELINE configs[4] through bench.py — the 5.14 M-cell per-GPU slab on one GPU, and the N-rank entry rehearsed
+# with two ranks on one GPU (host-staged transport, small slabs: a launch rehearsal, not a measurement)
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r04_final
+O=gpurun_out/r04_final
+timeout -k 10 700 python3 bench.py --workload config5 --steps 5 --warmup 1 > $O/config5_bench.json 2> $O/config5.err; echo "config5 rc=$?"; cut -c1-400 $O/config5_bench.json
+ORC_BENCH_HOST_TRANSPORT=1 timeout -k 10 400 python3 bench.py --workload config5 --gpus 2 --nx 60 --ny 30 --nz 30 --steps 2 --warmup 1 --no-cpu-baseline > $O/config5_2ranks_host.json 2> $O/config5_2ranks.err; echo "config5 2 ranks rc=$?"; cut -c1-400 $O/config5_2ranks_host.json
+ORC_BENCH_HOST_TRANSPORT=1 timeout -k 10 400 python3 bench.py --gpus 2 --nx 100 --ny 40 --nz 40 --steps 2 --warmup 1 --no-cpu-baseline > $O/hex_2ranks_host.json 2> $O/hex_2ranks.err; echo "hex 2 ranks rc=$?"; cut -c1-300 $O/hex_2ranks_host.json
