@@ -114,6 +114,11 @@ def spawn_ranks(n):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
     env.setdefault("OMP_NUM_THREADS", "1")
+    if env.get("ORC_BENCH_HOST_TRANSPORT") == "1":
+        # the rehearsal with several ranks on ONE GPU: two processes with four hardware queues each and the lock-step schedule's
+        # main -> three lanes -> main event chain stalled the GPU's queue scheduler (r04: reproducible with 4 and 8 queues per process,
+        # never with 2, never with one process per GPU): keep the rehearsal to two hardware queues per process
+        env.setdefault("GPU_MAX_HW_QUEUES", "2")
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True, bufsize=1)
     line = None
     for out in proc.stdout:  # rank 0 prints exactly one JSON line; anything else a rank writes to stdout goes to our stderr

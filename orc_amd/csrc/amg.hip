@@ -2706,8 +2706,10 @@ int multigrid_arm3_dev(const MatView3 &A3, const double *const b[3], double *con
         V.s1 = dinv3;
         bp3 = bt3;
     }
+    ORC_TRACE("arm3: level-0 solve");
     ORC_TRY(bicgstab3_dev(V, bp3, x3, iteration_count, preconditioner, arena));  // :273-282 (scaled again inside: Q4)
     ORC_TRY(residual3_dev(V, bp3, x3, r3));                                       // :283
+    ORC_TRACE("arm3: level-0 solve queued; joining the hierarchies");
 
     // ---- the hierarchies
     if (!setup_first) join_hierarchies();
@@ -2734,6 +2736,7 @@ int multigrid_arm3_dev(const MatView3 &A3, const double *const b[3], double *con
     }
     static const bool trace = getenv("ORC_AMG_TRACE") != nullptr;
     if (trace) fprintf(stderr, "[amg triple n=%lld] level 1 %s\n", (long long)n, shared ? "in lock-step" : "per system");
+    ORC_TRACE("arm3: hierarchies joined, level 1 %s", shared ? "in lock-step" : "per system");
 
     hipEvent_t ev_main = nullptr, ev_lane[3] = {nullptr, nullptr, nullptr};
     struct Events {
@@ -2790,11 +2793,19 @@ int multigrid_arm3_dev(const MatView3 &A3, const double *const b[3], double *con
         ORC_TRY(arena.alloc(nc3, &e1));
         ORC_TRY(arena.alloc((size_t)3 * kMaxPartials, &partials));
         ORC_TRY(arena.alloc((size_t)4, &norm3));
+        static const int dbg_mask = getenv("ORC_DEBUG_SYNC") ? atoi(getenv("ORC_DEBUG_SYNC")) : 0;  // debugging aid: drain the stream after chosen steps
+        int step_no = 0;
+        auto step = [&](const char *what) { if (dbg_mask & (1 << step_no)) { (void)hipStreamSynchronize(st); ORC_TRACE("arm3 level 1: %s done", what); } ++step_no; };
+        const bool dbg_sync = (dbg_mask & 64) != 0;
+        step("level 0");
         hipLaunchKernelGGL(restrict3_k, dim3(grid_for(nc)), dim3(kBlock), 0, st, (const int *)L0.choice, n, nc, (const double *)r3, r1);  // :82
         ORC_HIP(hipGetLastError());
         ORC_TRY(vec_fill(e1, 0., (int64_t)nc3));                                                                                      // :86
+        step("restriction");
         ORC_TRY(bicgstab3_dev(Ac3, r1, e1, iteration_count, preconditioner, arena));                                                  // :87-96
+        step("pre-smoothing");
         ORC_TRY(residual_norm2_3_dev(Ac3, r1, e1, partials, norm3));                                                                  // :97-105
+        step("residual norm");
         hipLaunchKernelGGL(nan_to_status3_k, dim3(1), dim3(64), 0, st, (const double *)norm3, dev_status, (int)ORC_ERR_MULTIGRID_DIVERGED);
         ORC_HIP(hipGetLastError());
         for (int k = 0; k < 3; ++k) {
@@ -2824,17 +2835,22 @@ int multigrid_arm3_dev(const MatView3 &A3, const double *const b[3], double *con
                 ORC_HIP(hipEventRecord(ev_lane[k], lanes[k].solve_stream));
                 ORC_HIP(hipStreamWaitEvent(st, ev_lane[k], 0));
             }
+            if (dbg_sync) for (int k = 0; k < 3; ++k) { (void)hipStreamSynchronize(lanes[k].solve_stream); ORC_TRACE("arm3 level 1: lane %d levels 2.. done", k); }
             hipLaunchKernelGGL(vec_add3_k, dim3(grid_for(nc)), dim3(kBlock), 0, st, e1, (const double *)ck[0], (const double *)ck[1], (const double *)ck[2], nc);  // e' += ...
             ORC_HIP(hipGetLastError());
+            step("corrections added");
             ORC_TRY(bicgstab3_dev(Ac3, r1, e1, iteration_count, preconditioner, arena));  // :123-132
+            step("post-smoothing");
         }
         hipLaunchKernelGGL(prolong3_k, dim3(grid_for(n)), dim3(kBlock), 0, st, (const int *)L0.choice, (const int *)L0.chooser, n, (const double *)e1, x3);  // :140, :284
         ORC_HIP(hipGetLastError());
         ORC_TRY(deinterleave3_dev(x3, x[0], x[1], x[2], n));
     }
     int h[4] = {0, 0, 0, 0};
+    ORC_TRACE("arm3: coarse parts queued; waiting for the status words");
     ORC_HIP(hipMemcpyAsync(h, dev_status, sizeof(h), hipMemcpyDeviceToHost, st));
     ORC_HIP(hipStreamSynchronize(st));
+    ORC_TRACE("arm3: done (%d %d %d)", h[0], h[1], h[2]);
     for (int k = 0; k < 3; ++k) status_out[k] = h[k];
     return ORC_OK;
 }

@@ -1596,6 +1596,7 @@ int solver_iterate(SolverState &s, uint64_t iterations, double *report) {
     for (uint64_t it = 0; it < iterations; ++it) {
         double peclet[3] = {0., 0., 0.};
         if (s.arena.empty()) ORC_TRY(s.arena.reset());  // between iterations nothing in the solver's own arena is alive
+        ORC_TRACE("iteration %llu: start", (unsigned long long)s.iterations_done);
         if (H.active()) { double *f[4] = {s.u.p, s.v.p, s.w.p, s.p.p}; ORC_TRY(H.exchange(f, 4)); }
         ORC_TRY(k_gradients(s, tvd));
         if (H.active()) { double *g3[3] = {s.gp.p, s.gp.p + n, s.gp.p + 2 * n}; ORC_TRY(H.exchange(g3, 3)); }
@@ -1631,7 +1632,9 @@ int solver_iterate(SolverState &s, uint64_t iterations, double *report) {
         }
         if (triple_ok) {
             // :99-136, the three systems in lock-step on their shared pattern
+            ORC_TRACE("momentum: lock-step solve");
             int st3 = solve_momentum_triple(s, p_late ? std::function<void()>([&] { prep.start(s); }) : std::function<void()>());
+            ORC_TRACE("momentum: lock-step solve returned %d", st3);
             // partitioned: a rank whose set-up thread or coarse level failed locally has still taken part in every level-0 collective;
             // the verdict must be the same on every rank or they part ways at the next one
             if (H.active()) st3 = comm_global_status(st3);
@@ -1653,12 +1656,16 @@ int solver_iterate(SolverState &s, uint64_t iterations, double *report) {
             ORC_TRY(solve_field(s, s.a_w, s.b_w, s.w, 2));              // :125-136
             if (dbg) debug_field(s, "w", s.w);
         }
+        ORC_TRACE("momentum done; joining the p' set-up");
         ORC_TRY(prep.join());
+        ORC_TRACE("p' set-up joined");
         if (H.active()) { double *f[3] = {s.u.p, s.v.p, s.w.p}; ORC_TRY(H.exchange(f, 3)); }
         ORC_TRY(k_pressure_correction(s));                       // :137-148 (the matrix comes out as in the early pass)
         ORC_TRY(vec_fill(s.p_prime.p, 0., s.n));                 // :167
         if (dbg) debug_field(s, "b_p", s.b_p);
+        ORC_TRACE("p' solve");
         ORC_TRY(solve_field(s, s.a_p, s.b_p, s.p_prime, 3));        // :168-179
+        ORC_TRACE("p' solve done");
         if (dbg) debug_field(s, "p_prime", s.p_prime);
         if (H.active()) ORC_TRY(H.exchange(s.p_prime.p));
         double sums[5];

@@ -56,6 +56,12 @@ struct CtxDefaultsScope {
 };
 
 int set_error(int code, const char *fmt, ...);
+// ORC_DEBUG_TRACE=1: progress markers of the SIMPLE driver and the solves on stderr (rank, thread-agnostic): where does a run stand?
+#define ORC_TRACE(...)                                                                     \
+    do {                                                                                   \
+        static const bool on__ = getenv("ORC_DEBUG_TRACE") != nullptr;                     \
+        if (on__) { fprintf(stderr, "[orc trace r%d] ", orc::ctx().rank); fprintf(stderr, __VA_ARGS__); fprintf(stderr, "\n"); fflush(stderr); } \
+    } while (0)
 
 #define ORC_HIP(call)                                                                                     \
     do {                                                                                                  \
