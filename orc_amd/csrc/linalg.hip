@@ -257,6 +257,18 @@ int sell_from_csr_host(int64_t n, int64_t ncols, const int64_t *row_ptr, const i
     }
     ORC_TRY(out.diag_pos.upload(diag.data(), (size_t)n));
     ORC_TRY(out.csr_row_ptr.upload(row_ptr, (size_t)n + 1));
+    // the pattern half of the row-contiguous mirror: CSR itself, addressed per slice (SellDev::rows_*)
+    static const bool l0_mirror = !(getenv("ORC_AMG_L0_MIRROR") && atoi(getenv("ORC_AMG_L0_MIRROR")) == 0);
+    if (l0_mirror && n > 0 && nnz > 0 && nnz < ((int64_t)1 << 31)) {
+        std::vector<long long> rb((size_t)n_slices);
+        std::vector<int32_t> ri((size_t)n), rc((size_t)nnz);
+        for (int32_t s_ = 0; s_ < n_slices; ++s_) rb[(size_t)s_] = (long long)row_ptr[(int64_t)s_ * 64];
+        for (int64_t r = 0; r < n; ++r) ri[(size_t)r] = (int32_t)(row_ptr[r] - row_ptr[(r >> 6) << 6]);
+        for (int64_t q = 0; q < nnz; ++q) rc[(size_t)q] = (int32_t)col[q];
+        ORC_TRY(out.rows_base.upload(rb.data(), rb.size()));
+        ORC_TRY(out.rows_intra.upload(ri.data(), ri.size()));
+        ORC_TRY(out.rows_col.upload(rc.data(), rc.size()));
+    }
     return ORC_OK;
 }
 
@@ -279,6 +291,13 @@ __global__ void sell_export_k(SellDev P, const int64_t *__restrict__ row_ptr, co
 int sell_import_values(const SellMatrix &m, const double *csr_vals_dev, double *sell_vals_dev) {
     if (m.n == 0) return ORC_OK;
     hipLaunchKernelGGL(sell_import_k, dim3(grid_for(m.n)), dim3(kBlock), 0, ctx().stream, m.dev(), m.csr_row_ptr.p, csr_vals_dev, sell_vals_dev);
+    ORC_HIP(hipGetLastError());
+    return ORC_OK;
+}
+// values of a view's padded image -> row-contiguous (CSR) order: the VALUE half of the level-0 row mirror (SellDev::rows_*)
+int sell_rows_values_dev(const SellDev &P, const double *sell_vals_dev, double *rows_vals_dev) {
+    if (P.n == 0 || !P.csr_row_ptr) return ORC_OK;
+    hipLaunchKernelGGL(sell_export_k, dim3(grid_for(P.n)), dim3(kBlock), 0, ctx().stream, P, P.csr_row_ptr, sell_vals_dev, rows_vals_dev);
     ORC_HIP(hipGetLastError());
     return ORC_OK;
 }
@@ -984,6 +1003,55 @@ static int launch_spmv3(const MatView3 &A_in, const double *x3, const Epi3 &epi,
     const int g = spmv_grid(A.P.n_slices);  // the one-system grid: same walk, same partial sums
     if (grid_out) *grid_out = g;
     if (A.P.n == 0) return ORC_OK;
+    // Partitioned level-0 operator [r04]: as launch_spmv does for one system, the rows without a ghost column (HaloPlan::interior_*) are
+    // multiplied on a second stream while the exchange of the interleaved iterate travels; the rows along the cuts follow it on the library
+    // stream.  Same slice ranges, same grids and same layout of the partial sums as the one-system form: per system the same bits.
+    HaloPlan *H = A.halo;
+    const char *ov_env = H ? getenv("ORC_HALO_OVERLAP") : nullptr;  // read per product: tests compare the two forms in one process
+    const bool overlap_on = !(ov_env && atoi(ov_env) == 0);
+    const bool plain_kernel = A.mesh_pattern && A.P.col16 != nullptr && !(A.s1 || A.s2);  // the variant the solves launch (materialised, narrow columns)
+    if (H && overlap_on && plain_kernel && ctx().world > 1 && g >= 64 && (int64_t)(H->interior_hi - H->interior_lo) * 2 >= (int64_t)A.P.n_slices) {
+        const int g_b = std::max(8, (g / 8 / 8) * 8), g_i = std::max(8, ((g - 2 * g_b) / 8) * 8);
+        const int total = g_i + 2 * g_b;
+        if (grid_out) *grid_out = total;
+        if (!H->aux_stream) {
+            hipStream_t st2;
+            hipEvent_t e1, e2;
+            ORC_HIP(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
+            ORC_HIP(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+            ORC_HIP(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+            H->aux_stream = st2; H->ev_ready = e1; H->ev_done = e2;
+        }
+        hipStream_t lib = ctx().stream, aux = (hipStream_t)H->aux_stream;
+        ORC_HIP(hipEventRecord((hipEvent_t)H->ev_ready, lib));
+        ORC_HIP(hipStreamWaitEvent(aux, (hipEvent_t)H->ev_ready, 0));
+        MatView3 V = A;
+        V.part_stride = total;
+        V.slice_lo = H->interior_lo; V.slice_hi = H->interior_hi; V.part_base = 0;
+        const bool exchange_first = !comm_host_transport_active();
+        if (exchange_first) ORC_TRY(H->exchange_interleaved(const_cast<double *>(x3), 3));
+        auto launch = [&](const MatView3 &W, int gg, hipStream_t s) {
+            if (W.nt) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4, true, true, false, true>), dim3(gg), dim3(kBlock), 0, s, W, x3, epi, partials);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4, true, true, false>), dim3(gg), dim3(kBlock), 0, s, W, x3, epi, partials);
+        };
+        launch(V, g_i, aux);
+        ORC_HIP(hipEventRecord((hipEvent_t)H->ev_done, aux));
+        if (!exchange_first) {
+            const int ex = H->exchange_interleaved(const_cast<double *>(x3), 3);
+            if (ex != ORC_OK) {  // the interior product is in flight: the library stream must not run ahead of it
+                (void)hipStreamWaitEvent(lib, (hipEvent_t)H->ev_done, 0);
+                return ex;
+            }
+        }
+        V.slice_lo = 0; V.slice_hi = H->interior_lo; V.part_base = g_i;
+        launch(V, g_b, lib);
+        V.slice_lo = H->interior_hi; V.slice_hi = A.P.n_slices; V.part_base = g_i + g_b;
+        launch(V, g_b, lib);
+        ORC_HIP(hipStreamWaitEvent(lib, (hipEvent_t)H->ev_done, 0));
+        ORC_HIP(hipGetLastError());
+        ctx().halo_overlaps += 1;
+        return ORC_OK;
+    }
     if (A.halo) ORC_TRY(A.halo->exchange_interleaved(const_cast<double *>(x3), 3));  // C1: the ghost entries of the three systems in one message per peer
     static const int chunk = getenv("ORC_SPMV3_CHUNK") ? atoi(getenv("ORC_SPMV3_CHUNK")) : 4;
     if (chunk == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 8>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);

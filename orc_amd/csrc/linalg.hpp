@@ -29,6 +29,14 @@ struct SellDev {
     // level-0 product is bandwidth-bound at the copy ceiling, bytes are what is left.  Other kernels keep `col`.
     const uint16_t *col16 = nullptr;     // [padded]; present only if EVERY depth of EVERY slice spans < 65 536 (all or nothing: no per-slice branch)
     const int32_t *colbase = nullptr;    // [padded / 64]: smallest column of that depth of that slice
+    // [r04] host-built patterns also keep their CSR form as the PATTERN half of a row-contiguous mirror (RowsDev): entry k of row r at
+    // rows_base[r >> 6] + rows_intra[r] + k.  The set-up kernels walk single rows (aggregation, Galerkin merge); in SELL a row's entries sit in
+    // different cache lines (7 lines of columns + 7 of values for an 84-byte hex row); multigrid_prepare_dev adds the values per solve.
+    const long long *rows_base = nullptr;  // [n_slices]
+    const int32_t *rows_intra = nullptr;   // [n]
+    const int32_t *rows_col = nullptr;     // [nnz]
+    const int64_t *csr_row_ptr = nullptr;  // [n + 1] (value export into the mirror)
+    int64_t nnz = 0;                       // stored entries when the host knows them (host-built patterns), else 0
 };
 
 // Zero-padding mirror of a SELL-64 matrix for the wave-cooperative product (coarse AMG levels, whose rows are ragged:
@@ -129,6 +137,8 @@ struct MatView3 {
     // refreshed by ONE exchange of 24 bytes per cell before every product, the reductions are summed over the ranks in one all-reduce
     // of 3 (or 6) scalars — a third of the collectives of three one-system solves (solver.rs:99-136 on a cell-partitioned mesh)
     HaloPlan *halo = nullptr;
+    // the pieces of a product that overlaps its halo exchange (MatView::slice_lo / slice_hi / part_stride / part_base)
+    int32_t slice_lo = 0, slice_hi = -1, part_stride = 0, part_base = 0;
 };
 
 // Owning pattern (built on the host from CSR, e.g. the mesh pattern or a user matrix).
@@ -141,10 +151,13 @@ struct SellMatrix {
     DevBuf<int32_t> row_len, col, diag_pos, colbase;
     DevBuf<uint16_t> col16;
     DevBuf<int64_t> csr_row_ptr;  // for value import/export in CSR (ORC) order
+    DevBuf<long long> rows_base;  // pattern half of the level-0 row mirror (SellDev)
+    DevBuf<int32_t> rows_intra, rows_col;
     SellDev dev() const {
         SellDev d;
         d.n = n; d.ncols = ncols; d.n_slices = n_slices; d.ragged = ragged; d.padded = padded; d.slice_ptr = slice_ptr.p; d.row_len = row_len.p; d.col = col.p; d.diag_pos = diag_pos.p;
         d.col16 = col16.p; d.colbase = colbase.p;
+        d.rows_base = rows_base.p; d.rows_intra = rows_intra.p; d.rows_col = rows_col.p; d.csr_row_ptr = csr_row_ptr.p; d.nnz = nnz;
         return d;
     }
 };
@@ -153,6 +166,7 @@ int sell_from_csr_host(int64_t n, int64_t ncols, const int64_t *row_ptr, const i
 // values: CSR order (device) <-> SELL order (device)
 int sell_import_values(const SellMatrix &m, const double *csr_vals_dev, double *sell_vals_dev);
 int sell_export_values(const SellMatrix &m, const double *sell_vals_dev, double *csr_vals_dev);
+int sell_rows_values_dev(const SellDev &P, const double *sell_vals_dev, double *rows_vals_dev);  // -> the value half of the level-0 row mirror
 
 // Warm start of the AMG set-up: the greedy pairing is a fixed point that the device reaches by iteration from ANY
 // initial state, and a SIMPLE run changes its matrices slowly, so each (equation, level) keeps its last pairing as

@@ -311,7 +311,7 @@ __global__ __launch_bounds__(kBlock) void spmv3_uniform_k(MatView3 A, const doub
     const Vec3d *__restrict__ xv3 = reinterpret_cast<const Vec3d *>(x3);
     const Vec3d *__restrict__ s1v = reinterpret_cast<const Vec3d *>(A.s1);
     const Vec3d *__restrict__ s2v = reinterpret_cast<const Vec3d *>(A.s2);
-    SliceWalk w(A.P.n_slices);
+    SliceWalk w(A.slice_hi >= 0 ? A.slice_hi : A.P.n_slices, A.slice_lo);  // a slice range when the product overlaps its halo exchange (launch_spmv3)
     for (int64_t slice = w.begin; slice < w.end; slice += w.step) {
         const int64_t row = slice * 64 + lane;
         const int64_t base = A.P.slice_ptr[slice];
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(kBlock) void spmv3_uniform_k(MatView3 A, const doub
 #pragma unroll
         for (int q = 0; q < Epi3::kReductions; ++q) {
             const double t = block_sum(red[s][q], lds);
-            if (threadIdx.x == 0) partials[(size_t)(s * Epi3::kReductions + q) * gridDim.x + blockIdx.x] = t;
+            if (threadIdx.x == 0) partials[(size_t)(s * Epi3::kReductions + q) * (A.part_stride > 0 ? A.part_stride : (int)gridDim.x) + A.part_base + blockIdx.x] = t;
         }
     }
 }

@@ -413,39 +413,45 @@ def gpu_triple_partitioned_checks(rank, world):
     parallel.init_host_transport(dist, rank, world)
     L = lib()
     L.orc_debug_collectives.restype = ctypes.c_longlong
-    nx, ny, nzl = 16, 12, 8
-    a, halo, gids = parallel.slab_arrays(nx, ny, nzl, rank, world)
-    ag = hex_channel(nx, ny, nzl * world)
-    set_channel_bcs(a)
-    set_channel_bcs(ag)
-    ug = global_fields(ag)
-    n_own = halo["n_owned"]
+    L.orc_debug_halo_overlaps.restype = ctypes.c_longlong
     ok = True
-    for name, kw, inner in (("multigrid", dict(momentum=5, solver_type=2, iterations=10), 10), ("bicgstab", dict(momentum=5, solver_type=3, iterations=12), 12)):
-        s = NumericalSettings.default(**kw)
-        out, coll = {}, {}
-        for mode in ("triple", "single"):
-            os.environ["ORC_TRIPLE_MOMENTUM"] = "1" if mode == "triple" else "0"
-            os.environ["ORC_HALO_OVERLAP"] = "0"  # the plain product form: the layout of the partial sums the three-system kernel keeps
-            try:
-                sol = Solver(parallel.PartitionedMesh(a, halo), s, 1000.0, 1e-3)
-                sol.set_fields(*[f[gids] for f in ug])
-                st1 = sol.iterate(1, raise_on_error=False)
-                L.orc_debug_collectives(1)
-                st2 = sol.iterate(1, raise_on_error=False)
-                coll[mode] = int(L.orc_debug_collectives(1))
-                out[mode] = (st1, st2, sol.get_fields())
-            finally:
-                del os.environ["ORC_TRIPLE_MOMENTUM"], os.environ["ORC_HALO_OVERLAP"]
-        same = all(np.array_equal(x[:n_own].view(np.uint64), y[:n_own].view(np.uint64)) for x, y in zip(out["triple"][2], out["single"][2]))
-        finite = all(np.isfinite(x[:n_own]).all() for x in out["triple"][2])
-        ratio = coll["triple"] / max(coll["single"], 1)
-        # per solve of `inner` BiCGSTAB iterations: 2 + 2 inner exchanges... counted, not modelled: the bound is what matters
-        good = out["triple"][0] == out["triple"][1] == out["single"][0] == out["single"][1] == 0 and same and finite and ratio <= 0.55
-        if rank == 0:
-            print("  lock-step partitioned %-9s bit-identical to one-system solves: %s; collectives per SIMPLE iteration %d vs %d (%.2f)  %s"
-                  % (name, same, coll["triple"], coll["single"], ratio, "ok" if good else "FAIL"), flush=True)
-        ok = ok and good
+    # (16, 12, 8): 24 slices per rank, every product in the plain form; (40, 26, 16): 260 slices, the level-0 products of BOTH schedules run
+    # their interior rows beside the halo exchange (same slice ranges, same layout of the partial sums: still bit-identical per system)
+    for (nx, ny, nzl), overlap in (((16, 12, 8), "0"), ((40, 26, 16), "1")):
+        a, halo, gids = parallel.slab_arrays(nx, ny, nzl, rank, world)
+        ag = hex_channel(nx, ny, nzl * world)
+        set_channel_bcs(a)
+        set_channel_bcs(ag)
+        ug = global_fields(ag)
+        n_own = halo["n_owned"]
+        for name, kw in (("multigrid", dict(momentum=5, solver_type=2, iterations=10)), ("bicgstab", dict(momentum=5, solver_type=3, iterations=12))):
+            s = NumericalSettings.default(**kw)
+            out, coll, ovl = {}, {}, {}
+            for mode in ("triple", "single"):
+                os.environ["ORC_TRIPLE_MOMENTUM"] = "1" if mode == "triple" else "0"
+                os.environ["ORC_HALO_OVERLAP"] = overlap
+                try:
+                    sol = Solver(parallel.PartitionedMesh(a, halo), s, 1000.0, 1e-3)
+                    sol.set_fields(*[f[gids] for f in ug])
+                    st1 = sol.iterate(1, raise_on_error=False)
+                    L.orc_debug_collectives(1)
+                    before = L.orc_debug_halo_overlaps()
+                    st2 = sol.iterate(1, raise_on_error=False)
+                    coll[mode] = int(L.orc_debug_collectives(1))
+                    ovl[mode] = int(L.orc_debug_halo_overlaps() - before)
+                    out[mode] = (st1, st2, sol.get_fields())
+                finally:
+                    del os.environ["ORC_TRIPLE_MOMENTUM"], os.environ["ORC_HALO_OVERLAP"]
+            same = all(np.array_equal(x[:n_own].view(np.uint64), y[:n_own].view(np.uint64)) for x, y in zip(out["triple"][2], out["single"][2]))
+            finite = all(np.isfinite(x[:n_own]).all() for x in out["triple"][2])
+            ratio = coll["triple"] / max(coll["single"], 1)
+            good = out["triple"][0] == out["triple"][1] == out["single"][0] == out["single"][1] == 0 and same and finite and ratio <= 0.55
+            good = good and ((ovl["triple"] > 0 and ovl["single"] > 0) if overlap == "1" else (ovl["triple"] == 0))
+            if rank == 0:
+                print("  lock-step partitioned %dx%dx%d %-9s bit-identical to one-system solves: %s; collectives per SIMPLE iteration %d vs %d (%.2f); "
+                      "overlapped products %d vs %d  %s" % (nx, ny, nzl, name, same, coll["triple"], coll["single"], ratio, ovl["triple"], ovl["single"], "ok" if good else "FAIL"),
+                      flush=True)
+            ok = ok and good
     parallel.finalize()
     return ok
 

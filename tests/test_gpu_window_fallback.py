@@ -133,3 +133,26 @@ def test_certification_rounds_change_nothing(gpu):
     aggs, rounds = amg_certification()
     assert aggs >= 12, aggs
     assert rounds == aggs, "a certification round changed a pairing: %d rounds for %d aggregations" % (rounds, aggs)
+
+
+def test_level0_row_mirror_does_not_change_a_bit(gpu, monkeypatch):
+    """[r04] The set-up walks single rows of the level-0 matrices through a row-contiguous mirror (the mesh pattern's CSR form + values exported
+    per solve) instead of the SELL image, where every entry of a row is a cache line of its own.  Same entries in the same order: three
+    default-stack SIMPLE iterations with and without it (ORC_AMG_L0_MIRROR=0), lock-step and per-system momentum solves — identical bits."""
+    import helpers as H
+    from orc_amd.mesh import Mesh, hex_channel, set_channel_bcs
+    from orc_amd.settings import NumericalSettings
+    from orc_amd.solver import solve_steady
+    a = set_channel_bcs(hex_channel(40, 24, 16))
+    s = NumericalSettings.default(momentum=5, solver_type=MULTIGRID, iterations=8, momentum_relaxation=0.1, pressure_relaxation=0.001)
+    out = []
+    for mirror, triple in (("1", "1"), ("0", "1"), ("1", "0"), ("0", "0")):
+        monkeypatch.setenv("ORC_AMG_L0_MIRROR", mirror)
+        monkeypatch.setenv("ORC_TRIPLE_MOMENTUM", triple)
+        u, v, w, p = H.seeded_fields(a, seed=11)
+        solve_steady(Mesh(a), u, v, w, p, s, 1000.0, 1e-3, 3)
+        out.append((u, v, w, p))
+    assert np.isfinite(out[0][0]).all()
+    for other in out[1:]:
+        for x, y in zip(out[0], other):
+            assert np.array_equal(x, y)
