@@ -136,9 +136,11 @@ def test_certification_rounds_change_nothing(gpu):
 
 
 def test_level0_row_mirror_does_not_change_a_bit(gpu, monkeypatch):
-    """[r04] The set-up walks single rows of the level-0 matrices through a row-contiguous mirror (the mesh pattern's CSR form + values exported
-    per solve) instead of the SELL image, where every entry of a row is a cache line of its own.  Same entries in the same order: three
-    default-stack SIMPLE iterations with and without it (ORC_AMG_L0_MIRROR=0), lock-step and per-system momentum solves — identical bits."""
+    """[r04] ORC_AMG_L0_MIRROR=1 (off by default: measured, no gain): the set-up walks single rows of the level-0 matrices through a
+    row-contiguous mirror (the mesh pattern's CSR form + values exported per solve) instead of the SELL image.  Same entries in the same order:
+    three default-stack SIMPLE iterations with and without it, lock-step and per-system momentum solves — identical bits.  (The pattern half is
+    built at mesh creation, so the switch is set before the first mesh of this test; run in a process whose earlier meshes lack it the test still
+    compares two runs, both without.)"""
     import helpers as H
     from orc_amd.mesh import Mesh, hex_channel, set_channel_bcs
     from orc_amd.settings import NumericalSettings
