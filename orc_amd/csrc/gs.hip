@@ -677,6 +677,8 @@ __global__ void gsx_out_k(const int *__restrict__ rowid, int64_t n_slots, const 
 
 // kMode 0: r = b - A x, p = r, sum(r)   1: y = A x, sum(y)   2: t = A x, t.aux, t.t      (linear_algebra.rs:250-261)
 // partial sums: quantity q of system s at partials[(s * kRed + q) * gridDim.x + blockIdx.x]
+// (r04, measured and dropped: skipping the value stream and the products of a system the guard has frozen — per-system predicates in these
+// two kernels cost 10-25 % on the unfrozen path (config 3: 28.9 -> 31.3 ms per iteration) and no system of that run is ever frozen)
 template <int S, int kMode>
 __global__ __launch_bounds__(kBlock) void gsx_spmv_k(SlotMat<S> M, const double *__restrict__ x, const double *__restrict__ aux, double *__restrict__ y,
                                                      double *__restrict__ y2, double *__restrict__ partials) {
@@ -871,6 +873,13 @@ __global__ __launch_bounds__(kBlock) void gsx_xr_k(double *__restrict__ scal, in
     const int64_t n_chunks = (n + kBlock - 1) / kBlock, total = (int64_t)S * n;
     for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
         const int64_t base = chunk * (int64_t)S * kBlock;
+        double xv[S], pv[S], hv[S], sv_[S], tv[S];
+#pragma unroll
+        for (int j = 0; j < S; ++j) {  // all loads of the chunk first: S x 5 requests in flight per lane
+            const int64_t e = base + threadIdx.x + (int64_t)j * kBlock;
+            const bool in = e < total;
+            xv[j] = in ? x[e] : 0.; pv[j] = in ? ph[e] : 0.; hv[j] = in ? sh[e] : 0.; sv_[j] = in ? sv[e] : 0.; tv[j] = in ? t[e] : 0.;
+        }
 #pragma unroll
         for (int j = 0; j < S; ++j) {
             const int64_t e = base + threadIdx.x + (int64_t)j * kBlock;
@@ -882,9 +891,9 @@ __global__ __launch_bounds__(kBlock) void gsx_xr_k(double *__restrict__ scal, in
 #pragma unroll
                 for (int q = 1; q < S; ++q) { if (s == q) { a = alpha[q]; o = omega[q]; stt = state[q]; } }
                 if (stt != 2) {
-                    const double h = x[e] + a * ph[e];
-                    x[e] = stt == 1 ? h : h + o * sh[e];
-                    ri = stt == 1 ? sv[e] : sv[e] - o * t[e];
+                    const double h = xv[j] + a * pv[j];
+                    x[e] = stt == 1 ? h : h + o * hv[j];
+                    ri = stt == 1 ? sv_[j] : sv_[j] - o * tv[j];
                     r[e] = ri;
                 }
             }

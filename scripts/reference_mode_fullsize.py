@@ -28,6 +28,8 @@ sys.path.insert(0, ROOT)
 ap = argparse.ArgumentParser()
 ap.add_argument("--nx", type=int, default=400); ap.add_argument("--ny", type=int, default=160); ap.add_argument("--nz", type=int, default=160)
 ap.add_argument("--iterations", type=int, default=3)
+ap.add_argument("--workload", default="hex", choices=["hex", "config5"], help="config5: the mixed tet / hex / poly slab of bench.py --workload config5 "
+                "(--nx 252 --ny 100 --nz 72 --oracle profiles/r04_oracle_trajectory_config5_252x100x72_inplace.json)")
 ap.add_argument("--oracle", default=os.path.join(ROOT, "profiles", "r03_oracle_trajectory_400x160x160_inplace.json"))
 ap.add_argument("--out", default=None)
 args = ap.parse_args()
@@ -43,7 +45,14 @@ ref = json.load(open(args.oracle))
 assert ref["shape"] == [args.nx, args.ny, args.nz], "the oracle file is for another mesh"
 kw = {k: v for k, v in ref["settings"].items()}
 assert kw["frozen_diagonals"] == 0 and kw["breakdown_guard"] == 0
-a = set_channel_bcs(hex_channel(args.nx, args.ny, args.nz))
+if args.workload == "config5":
+    from orc_amd import parallel
+    from orc_amd.mesh import set_mixed_channel_bcs
+    assert ref.get("workload") == "config5", "the oracle file is for another workload"
+    _a, _h, _g, a = parallel.mixed_slab_arrays(args.nx, args.ny, args.nz, 0, 1)
+    set_mixed_channel_bcs(a)
+else:
+    a = set_channel_bcs(hex_channel(args.nx, args.ny, args.nz))
 mesh = Mesh(a)
 f0 = bench.initial_fields(np.asarray(a["cell_centroid"]))
 del a

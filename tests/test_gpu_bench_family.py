@@ -93,6 +93,37 @@ def test_bench_channel_product_default_follows_the_reference_trajectory(gpu, ora
         assert np.linalg.norm(x - y) < 1e-4 * (un if k < 3 else np.linalg.norm(y))
 
 
+def test_midsize_mixed_poly_channel_reference_order_against_the_committed_oracle_run(gpu):
+    """The same for the BASELINE configs[4] family: 60 x 30 x 30 blocks of the mixed tet / pyramid / prism / hex / polyhedral channel (159 510 cells,
+    rows of 5 to 13 entries, generated by parallel.mixed_slab_arrays as bench.py --workload config5 does) in the reference's own mode, three SIMPLE
+    iterations, against SHA-256 hashes, samples and report doubles of the oracle's fields (tests/golden/make_golden_bench_midsize.py --mixed)."""
+    import hashlib
+    import os
+    from conftest import GOLDEN
+    from orc_amd import parallel
+    from orc_amd.mesh import Mesh, set_mixed_channel_bcs
+    from orc_amd.settings import NumericalSettings
+    from orc_amd.solver import Solver
+    g = np.load(os.path.join(GOLDEN, "bench_midsize_mixed_60x30x30.npz"), allow_pickle=False)
+    shape, stride = tuple(int(x) for x in g["shape"]), int(g["stride"])
+    _a, _h, _g, a = parallel.mixed_slab_arrays(*shape, 0, 1)
+    set_mixed_channel_bcs(a)
+    f0 = bench.initial_fields(np.asarray(a["cell_centroid"]))
+    kw = dict(BENCH_KW, frozen_diagonals=0, breakdown_guard=0)
+    s = Solver(Mesh(a), NumericalSettings.default(reduction_order=REFERENCE, **kw), 1000.0, 1e-3)
+    s.set_fields(*f0)
+    for it in (1, 2, 3):
+        st, rep = s.iterate(1, report=True, raise_on_error=False)
+        assert st == 0, "iteration %d" % it
+        for name, x in zip("uvwp", s.get_fields()):
+            x = np.ascontiguousarray(x)
+            sample = g["sample_%s_%d" % (name, it)]
+            worst = float(np.max(np.abs(x[::stride] - sample)) / max(np.max(np.abs(sample)), 1e-300))
+            assert hashlib.sha256(x.tobytes()).digest() == g["sha256_%s_%d" % (name, it)].tobytes(), \
+                "iteration %d, field %s differs from the oracle (largest sampled difference %.3e of the field's scale)" % (it, name, worst)
+        assert same_bits(np.array([rep[0][k] for k in (0, 1, 2, 3, 6, 7)]), g["report_%d" % it]), (it, rep[0], g["report_%d" % it])
+
+
 def test_midsize_bench_channel_reference_order_against_the_committed_oracle_run(gpu):
     """128 x 64 x 64 = 524 288 cells of the bench family in the reference's own mode against the oracle's fields, stored as SHA-256
     hashes + samples by tests/golden/make_golden_bench_midsize.py (two CPU-minutes there, too long for a test).  The size brings in

@@ -48,6 +48,16 @@ def test_lock_step_momentum_solve_on_a_partitioned_mesh(gpu):
     assert "MP_WORKER_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-4000:]
 
 
+def test_lock_step_momentum_solve_on_three_ranks(gpu):
+    """The same with three ranks on the card: the middle rank has two peers, so every interleaved exchange packs and lands two blocks.  (With
+    more than two ranks the all-reduce of three scalars and three all-reduces of one need not associate the ranks' terms alike: the two
+    schedules agree to rounding amplified by the recurrences — measured 7e-10 … 2e-7 with the BiCGSTAB solver, 2e-5 … 1e-2 with the Multigrid arm;
+    sanity bars — and to the bit only at N = 2.)"""
+    r = launch(3, "gpu_triple_partitioned", timeout=900)
+    print(r.stdout[-1500:])
+    assert "MP_WORKER_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-4000:]
+
+
 def test_two_ranks_on_rank_local_mixed_poly_slabs_match_single_rank(gpu):
     """BASELINE configs[4] as an N-rank run (Missing #1): each of two ranks generates ITS slab of the mixed tet / hex /
     poly channel (two ghost block layers, orc_mesh_partition_owner) and the partitioned SIMPLE iterations — Jacobi, BiCGSTAB and the
