@@ -285,10 +285,16 @@ def init_host_transport(dist, rank, world):
         exchange_over_dist(dist, rank, ps, sv, so, sc, rv, ro, rc)
 
     def ar(values, n, op, _user):
+        # every rank's terms are gathered and folded in RANK ORDER: the sum of a scalar does not depend on how many scalars travel
+        # with it (gloo's ring all-reduce starts every chunk at another rank, so for three or more ranks a 3-scalar reduction and three
+        # 1-scalar reductions associate differently) — the lock-step and the one-system schedules stay bit-identical at any world size
         v = np.ctypeslib.as_array(values, shape=(n,))
-        t = torch.from_numpy(v.copy())
-        dist.all_reduce(t, op=dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MAX)
-        v[:] = t.numpy()
+        parts = [torch.empty(n, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(parts, torch.from_numpy(v.copy()))
+        acc = parts[0].numpy().copy()
+        for q in range(1, world):
+            acc = acc + parts[q].numpy() if op == 0 else np.maximum(acc, parts[q].numpy())
+        v[:] = acc
 
     cex, car = _EXCHANGE_FN(ex), _ALLREDUCE_FN(ar)
     _keepalive.extend([cex, car])

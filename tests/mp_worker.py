@@ -443,15 +443,6 @@ def gpu_triple_partitioned_checks(rank, world):
                 finally:
                     del os.environ["ORC_TRIPLE_MOMENTUM"], os.environ["ORC_HALO_OVERLAP"]
             same = all(np.array_equal(x[:n_own].view(np.uint64), y[:n_own].view(np.uint64)) for x, y in zip(out["triple"][2], out["single"][2]))
-            if world > 2:
-                # beyond two ranks an all-reduce of three scalars and three all-reduces of one scalar need not associate the ranks' terms alike
-                # (ring algorithms start every chunk at another rank): the schedules agree to rounding, not to the bit
-                rel = max(np.linalg.norm(x[:n_own] - y[:n_own]) / max(np.linalg.norm(y[:n_own]), 1e-300) for x, y in zip(out["triple"][2], out["single"][2]))
-                # the reference's r_hat_0 = 1 recurrences amplify a last-bit difference by orders of magnitude per solve, the Multigrid arm's 7 solves
-                # per system more than one BiCGSTAB solve (measured: 7e-10 / 2e-7 and 2e-5 / 1e-2 on the two meshes): sanity bars, the sharp check is N = 2
-                same = rel < (1e-5 if name == "bicgstab" else 5e-2)
-                if rank == 0:
-                    print("    (three or more ranks: the schedules differ by %.2e rel-L2)" % rel, flush=True)
             finite = all(np.isfinite(x[:n_own]).all() for x in out["triple"][2])
             ratio = coll["triple"] / max(coll["single"], 1)
             good = out["triple"][0] == out["triple"][1] == out["single"][0] == out["single"][1] == 0 and same and finite and ratio <= 0.55
