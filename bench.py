@@ -202,7 +202,9 @@ def main():
     from orc_amd.solver import Solver
 
     host_transport = os.environ.get("ORC_BENCH_HOST_TRANSPORT") == "1"  # rehearsal on a 1-GPU box: ranks share cuda:0
-    orc_amd.init(0 if host_transport else local_rank)
+    # a launcher that narrows every rank's view to its own card (HIP_VISIBLE_DEVICES per rank) leaves one visible device: ordinal 0
+    n_visible = max(1, int(orc_amd._lib.lib().orc_device_count()))
+    orc_amd.init(0 if host_transport else local_rank % n_visible)
     if world > 1:
         from orc_amd import parallel
         if host_transport:

@@ -330,6 +330,10 @@ int orc_debug_clamp_partials_grid(long long requested);
 int orc_debug_max_partials(void);
 int orc_debug_amg_certification(long long out[2], int reset);
 int orc_debug_xwin_counters(long long out[3], int reset);
+/* [r04] coarse operators of SIBLING systems built by a shared Galerkin pass since the last reset (the u, v, w momentum matrices of a
+ * SIMPLE iteration share their pattern; when v's and w's fine pairings verify as u's, ONE symbolic pass carries the three value sets:
+ * linear_algebra.rs:80-84 per system, bit-identical).  ORC_AMG_SHARED_GALERKIN=0 switches the shared pass off. */
+long long orc_debug_shared_galerkin(int reset);
 /* kernel-level timers accumulated inside orc_solver_iterate when enabled: name/ms pairs */
 int orc_profile_enable(int on);
 int orc_profile_report(char *buf, int64_t buf_len);

@@ -1097,20 +1097,35 @@ __device__ __forceinline__ int group_excl_scan(int v, int &total) {
 // Batching the pairing look-ups of step 4 (speculative second-level loads) and running the LDS searches of a step side by
 // side were measured too: +1.2 ms and +2.1 ms.  Same LDS passes, same order of every sum and output entry: bit-identical.
 // kStop (measurement only): 1 / 4 = leave a row after that step (nothing but a row length is written; the real launch follows)
-template <int G, int kStop = 0>
+// [r04] S systems on ONE fine pattern and ONE pairing (the u, v, w momentum matrices whenever v's and w's fine-level pairings verify as u's:
+// SiblingPairing) share everything symbolic — which candidates there are, where each one merges to, which coarse columns come out and in
+// which order — so one pass carries S value sets through the same LDS passes (MergeSiblings: the values, scalings and outputs of systems
+// 1 .. S-1; system 0 travels in the ordinary arguments).  Per system the products and the order of every sum are those of its own pass:
+// bit-identical (tests/test_gpu_triple.py).  The kernel waits for scattered look-ups most of its time; those are now paid once for three.
+struct MergeSiblings {
+    const double *val[2] = {nullptr, nullptr};    // fine values, addressed like system 0's (SELL image or row-contiguous mirror)
+    const double *s1[2] = {nullptr, nullptr}, *s2[2] = {nullptr, nullptr};  // the views' row scalings (null where system 0 has none)
+    double *s_val[2] = {nullptr, nullptr};        // scratch rows, same offsets as system 0's
+};
+
+template <int G, int kStop = 0, int S = 1>
 __global__ __launch_bounds__(64) void galerkin_merge_k(MatView A, const int *__restrict__ choice, const int *__restrict__ chooser, int64_t n_coarse,
                                                         int cap /* power of two >= 2 * candidates */, int *__restrict__ row_len_c,
                                                         const long long *__restrict__ slice_base, const int *__restrict__ intra_off, int *__restrict__ s_col,
-                                                        double *__restrict__ s_val, const int *__restrict__ list, const int *__restrict__ list_count) {
+                                                        double *__restrict__ s_val, const int *__restrict__ list, const int *__restrict__ list_count,
+                                                        MergeSiblings X) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int kRows = 64 / G;  // coarse rows in flight per wavefront
+    constexpr int kX = S - 1;      // sibling systems
     const int h = cap >> 1;
     const int lane = threadIdx.x & (G - 1), grp = threadIdx.x / G;
-    double *src_val = reinterpret_cast<double *>(smem + (size_t)grp * (size_t)cap * 16);  // candidates in generation order, later T's values
+    double *src_val = reinterpret_cast<double *>(smem + (size_t)grp * (size_t)cap * (size_t)(16 + 8 * kX));  // candidates in generation order, later T's values
     double *m_val = src_val + h;                          // merged candidates
     int *src_col = reinterpret_cast<int *>(m_val + h);    // ... later T's columns
     int *m_col = src_col + h;
     int *U = m_col + h;  // [cap] distinct coarse columns, unsorted
+    double *x_src = reinterpret_cast<double *>(U + cap);  // siblings: [kX][h] candidates / T values, then [kX][h] merged candidates
+    double *x_m = x_src + (size_t)(kX > 0 ? kX : 1) * h;
     const int n_fine = (int)A.P.n;
     const int64_t total_rows = list ? (int64_t)*list_count : n_coarse;
     const int64_t it_step = (int64_t)gridDim.x * kRows;
@@ -1139,6 +1154,7 @@ __global__ __launch_bounds__(64) void galerkin_merge_k(MatView A, const int *__r
             int len[4];
             int64_t rb[4];
             double sc1[4], sc2[4];
+            double xs1[kX > 0 ? kX : 1][4], xs2[kX > 0 ? kX : 1][4];
 #pragma unroll
             for (int a = 0; a < 4; ++a) {  // descriptors of all fine rows at once
                 const bool on = a < R.n;
@@ -1147,15 +1163,23 @@ __global__ __launch_bounds__(64) void galerkin_merge_k(MatView A, const int *__r
                 rb[a] = mirror ? (int64_t)A.rows.slice_base[i >> 6] + A.rows.intra_off[i] : A.P.slice_ptr[i >> 6] + (i & 63);
                 sc1[a] = A.s1 ? A.s1[i] : 1.;
                 sc2[a] = A.s2 ? A.s2[i] : 1.;
+#pragma unroll
+                for (int x = 0; x < kX; ++x) {
+                    xs1[x][a] = X.s1[x] ? X.s1[x][i] : 1.;
+                    xs2[x][a] = X.s2[x] ? X.s2[x][i] : 1.;
+                }
             }
             int c0[4];
             double v0[4];
+            double xv0[kX > 0 ? kX : 1][4];
 #pragma unroll
             for (int a = 0; a < 4; ++a) {  // their first G entries at once
                 const bool in = lane < len[a];
                 const int64_t pos = rb[a] + (int64_t)(in ? lane : 0) * stride;
                 c0[a] = in ? colp[pos] : -1;
                 v0[a] = in ? valp[pos] : 0.;
+#pragma unroll
+                for (int x = 0; x < kX; ++x) xv0[x][a] = in ? X.val[x][pos] : 0.;
             }
             int base = 0;
 #pragma unroll
@@ -1166,8 +1190,19 @@ __global__ __launch_bounds__(64) void galerkin_merge_k(MatView A, const int *__r
                         const int k = k0 + lane;
                         int c = -1;
                         double v = 0.;
-                        if (k0 == 0) { c = c0[a]; v = v0[a]; }
-                        else if (k < len[a]) { const int64_t pos = rb[a] + (int64_t)k * stride; c = colp[pos]; v = valp[pos]; }
+                        double xv[kX > 0 ? kX : 1];
+#pragma unroll
+                        for (int x = 0; x < kX; ++x) xv[x] = 0.;
+                        if (k0 == 0) {
+                            c = c0[a]; v = v0[a];
+#pragma unroll
+                            for (int x = 0; x < kX; ++x) xv[x] = xv0[x][a];
+                        } else if (k < len[a]) {
+                            const int64_t pos = rb[a] + (int64_t)k * stride;
+                            c = colp[pos]; v = valp[pos];
+#pragma unroll
+                            for (int x = 0; x < kX; ++x) xv[x] = X.val[x][pos];
+                        }
                         const int valid = (c >= 0 && c < n_fine) ? 1 : 0;
                         int tot;
                         const int slot = base + group_excl_scan<G>(valid, tot);
@@ -1176,6 +1211,13 @@ __global__ __launch_bounds__(64) void galerkin_merge_k(MatView A, const int *__r
                             if (A.s2) v = sc2[a] * v;
                             src_col[slot] = c;
                             src_val[slot] = w * v;
+#pragma unroll
+                            for (int x = 0; x < kX; ++x) {
+                                double t = xv[x];
+                                if (X.s1[x]) t = xs1[x][a] * t;
+                                if (X.s2[x]) t = xs2[x][a] * t;
+                                x_src[(size_t)x * h + slot] = w * t;
+                            }
                         }
                         base += tot;
                     }
@@ -1201,6 +1243,8 @@ __global__ __launch_bounds__(64) void galerkin_merge_k(MatView A, const int *__r
             if (a != 3 && b4 > b3) rank += lds_lower_bound(src_col + b3, b4 - b3, c);
             m_col[rank] = c;
             m_val[rank] = src_val[e];
+#pragma unroll
+            for (int x = 0; x < kX; ++x) x_m[(size_t)x * h + rank] = x_src[(size_t)x * h + e];
         }
         __syncthreads();
         // ---- 3. runs of equal j -> T (sorted by j) into src_col / src_val
@@ -1214,9 +1258,18 @@ __global__ __launch_bounds__(64) void galerkin_merge_k(MatView A, const int *__r
             if (head) {
                 const int j = m_col[e];
                 double acc = 0. + m_val[e];
-                for (int q = e + 1; q < cnt && m_col[q] == j; ++q) acc += m_val[q];
+                double xacc[kX > 0 ? kX : 1];
+#pragma unroll
+                for (int x = 0; x < kX; ++x) xacc[x] = 0. + x_m[(size_t)x * h + e];
+                for (int q = e + 1; q < cnt && m_col[q] == j; ++q) {
+                    acc += m_val[q];
+#pragma unroll
+                    for (int x = 0; x < kX; ++x) xacc[x] += x_m[(size_t)x * h + q];
+                }
                 src_col[slot] = j;
                 src_val[slot] = acc;
+#pragma unroll
+                for (int x = 0; x < kX; ++x) x_src[(size_t)x * h + slot] = xacc[x];
             }
             cntT += tot;
         }
@@ -1279,15 +1332,24 @@ __global__ __launch_bounds__(64) void galerkin_merge_k(MatView A, const int *__r
             for (int q = 0; q < nU; ++q) rank += U[q] < u ? 1 : 0;
             const RRow RJ = restriction_row(choice, u, A.P.n);
             double acc = 0.;
+            double xacc[kX > 0 ? kX : 1];
+#pragma unroll
+            for (int x = 0; x < kX; ++x) xacc[x] = 0.;
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
                 if (a < RJ.n) {
                     const int p = lds_lower_bound(tj, cntT, RJ.idx[a]);
-                    if (p < cntT && tj[p] == RJ.idx[a]) acc += tv[p] * RJ.w[a];
+                    if (p < cntT && tj[p] == RJ.idx[a]) {
+                        acc += tv[p] * RJ.w[a];
+#pragma unroll
+                        for (int x = 0; x < kX; ++x) xacc[x] += x_src[(size_t)x * h + p] * RJ.w[a];
+                    }
                 }
             }
             s_col[off + rank] = u;
             s_val[off + rank] = acc;
+#pragma unroll
+            for (int x = 0; x < kX; ++x) X.s_val[x][off + rank] = xacc[x];
         }
         if (active && lane == 0) row_len_c[I] = nU;
         __syncthreads();
@@ -1301,7 +1363,9 @@ __global__ __launch_bounds__(64) void galerkin_merge_k(MatView A, const int *__r
 // wavefront moves one slice through an LDS tile of 16 depths x 64 rows: four rows at a time are read with 16 consecutive
 // lanes each (a handful of lines per instruction), the tile is read back depth by depth with lane = row, and both images
 // are written with full-width stores.
+// kValuesOnly [r04]: a sibling system on the same coarse pattern (MergeSiblings) — only val_c / pk_val are written.
 constexpr int kPackDepth = 16;
+template <bool kValuesOnly = false>
 __global__ __launch_bounds__(64) void galerkin_pack_fused_k(SellDev Pc, const long long *__restrict__ slice_base, const int *__restrict__ intra_off,
                                                             const int *__restrict__ s_col, const double *__restrict__ s_val, int *__restrict__ col_c,
                                                             double *__restrict__ val_c, int *__restrict__ diag_c, const int64_t *__restrict__ pk_ptr,
@@ -1329,7 +1393,7 @@ __global__ __launch_bounds__(64) void galerkin_pack_fused_k(SellDev Pc, const lo
                 const long long rsrc = ((long long)__shfl(src_hi, row, 64) << 32) | (long long)(unsigned)__shfl(src_lo, row, 64);
                 const int k = kc + kk;
                 if (k < rlen) {
-                    t_col[kk * 65 + row] = s_col[rsrc + k];
+                    if (!kValuesOnly) t_col[kk * 65 + row] = s_col[rsrc + k];
                     t_val[kk * 65 + row] = s_val[rsrc + k];
                 }
             }
@@ -1339,24 +1403,27 @@ __global__ __launch_bounds__(64) void galerkin_pack_fused_k(SellDev Pc, const lo
             for (int q = 0; q < kend; ++q) {
                 const int k = kc + q;
                 const bool in = k < len;
-                const int c = in ? t_col[q * 65 + lane] : (int)I;
+                const int c = (in && !kValuesOnly) ? t_col[q * 65 + lane] : (int)I;
                 const double v = in ? t_val[q * 65 + lane] : 0.;
                 const int64_t pos = base + (int64_t)k * 64 + lane;
                 if (live) {
-                    col_c[pos] = c;
+                    if (!kValuesOnly) col_c[pos] = c;
                     val_c[pos] = v;
-                    if (in && c == (int)I) d = (int)pos;
+                    if (!kValuesOnly && in && c == (int)I) d = (int)pos;
                 }
                 if (pk_ptr) {
                     const unsigned long long m = __ballot(in);
                     const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                    if (in) { pk_col[pk_off + rank] = c; pk_val[pk_off + rank] = v; }
+                    if (in) {
+                        if (!kValuesOnly) pk_col[pk_off + rank] = c;
+                        pk_val[pk_off + rank] = v;
+                    }
                     pk_off += __popcll(m);
                 }
             }
             __syncthreads();
         }
-        if (live) diag_c[I] = d;
+        if (live && !kValuesOnly) diag_c[I] = d;
     }
 }
 
@@ -1771,11 +1838,17 @@ __global__ void agg_verify_k(MatView A, const int *__restrict__ choice, const in
 SiblingPairing::~SiblingPairing() {
     for (auto &e : ready)
         if (e) (void)hipEventDestroy(e);
+    for (auto &o : offer)
+        if (o.view_ready) (void)hipEventDestroy(o.view_ready);
+    if (ops_ready) (void)hipEventDestroy(ops_ready);
 }
 void SiblingPairing::begin(bool leader_will_run) {
     std::lock_guard<std::mutex> lk(mu);
     for (auto &p : published) p = false;
     leader_done = !leader_will_run;
+    expected_offers = 0;
+    for (auto &o : offer) { o.made = o.ok = o.answered = o.adopted = false; o.view = nullptr; o.arena = o.rows_arena = nullptr; o.level = nullptr; }
+    lead_choice = lead_chooser = nullptr;
 }
 int SiblingPairing::publish(int level, const int *choice, int64_t rows, hipStream_t stream) {
     if (level < 0 || level >= kLevels) return ORC_OK;
@@ -1807,6 +1880,64 @@ void SiblingPairing::finish() {
         leader_done = true;
     }
     cv.notify_all();
+}
+void SiblingPairing::set_expected(int n) {
+    std::lock_guard<std::mutex> lk(mu);
+    expected_offers = n;
+}
+int SiblingPairing::make_offer(int slot, const MatView *view, Arena *arena, Arena *rows_arena, void *level, hipStream_t stream) {
+    if (slot < 0 || slot > 1) return ORC_OK;
+    int st = ORC_OK;
+    Offer &o = offer[slot];
+    if (!o.view_ready && hipEventCreateWithFlags(&o.view_ready, hipEventDisableTiming) != hipSuccess) st = set_error(ORC_ERR_HIP, "hipEventCreate failed");
+    if (st == ORC_OK && hipEventRecord(o.view_ready, stream) != hipSuccess) st = set_error(ORC_ERR_HIP, "hipEventRecord failed");
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        o.made = true;
+        o.ok = st == ORC_OK;
+        o.view = view; o.arena = arena; o.rows_arena = rows_arena; o.level = level;
+    }
+    cv.notify_all();
+    return st;
+}
+void SiblingPairing::withdraw(int slot) {
+    if (slot < 0 || slot > 1) return;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        offer[slot].made = true;
+        offer[slot].ok = false;
+    }
+    cv.notify_all();
+}
+bool SiblingPairing::wait_answer(int slot, hipStream_t stream) {
+    if (slot < 0 || slot > 1) return false;
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [&] { return offer[slot].answered || leader_done; });
+    if (!offer[slot].answered || !offer[slot].adopted) return false;
+    return hipStreamWaitEvent(stream, ops_ready, 0) == hipSuccess;
+}
+int SiblingPairing::collect_offers(Offer *out[2]) {
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [&] { return (int)offer[0].made + (int)offer[1].made >= expected_offers; });
+    int n = 0;
+    for (int q = 0; q < 2; ++q)
+        if (offer[q].made && offer[q].ok) out[n++] = &offer[q];
+    return n;
+}
+int SiblingPairing::answer(const bool adopted[2], const int *choice, const int *chooser, hipStream_t stream) {
+    int st = ORC_OK;
+    if (!ops_ready && hipEventCreateWithFlags(&ops_ready, hipEventDisableTiming) != hipSuccess) st = set_error(ORC_ERR_HIP, "hipEventCreate failed");
+    if (st == ORC_OK && hipEventRecord(ops_ready, stream) != hipSuccess) st = set_error(ORC_ERR_HIP, "hipEventRecord failed");
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        lead_choice = choice; lead_chooser = chooser;
+        for (int q = 0; q < 2; ++q) {
+            offer[q].answered = true;
+            offer[q].adopted = st == ORC_OK && adopted[q];
+        }
+    }
+    cv.notify_all();
+    return st;
 }
 
 // warm: a starting state for the fixed-point iteration (any state is valid).  warm_kind 1: last iteration's pairing of the
@@ -2109,7 +2240,25 @@ __global__ __launch_bounds__(64) void rows_compact_k(const int *__restrict__ row
 // `scratch` (optional): a second arena for everything that is dead when the level is complete — the symbolic bounds, the tier
 // lists and the product's scratch rows, 11 GB of a 10.24 M-row hierarchy's 23 GB — released before returning; the row-contiguous
 // mirror is then a compacted copy in `arena`.  Without it the scratch rows themselves stay alive as the mirror (round 2).
-static int galerkin(const MatView &A, const int *choice, const int *chooser, Arena &arena, CoarseLevel &L, Arena *scratch = nullptr, bool last_level = false) {
+// `sib` / n_sib [r04]: sibling systems on A's pattern that verified THIS pairing as theirs (SiblingPairing): their coarse operators share
+// the pattern this product builds — one symbolic pass, n_sib + 1 value sets (MergeSiblings) — and get their own values in their own
+// arenas; every kernel runs on the calling thread's stream.  Needs `scratch` (the mirrors are then compacted copies, one per system).
+struct GalerkinSibling {
+    const MatView *A = nullptr;  // same pattern (and mirror structure) as the leader's view, its own values and scalings
+    Arena *arena = nullptr;      // the sibling's hierarchy arena: its coarse values
+    Arena *rows_arena = nullptr; // the companion of the sibling's scratch arena: its copy of the transient row-contiguous mirror
+    CoarseLevel *L = nullptr;
+};
+static std::atomic<long long> g_shared_galerkin{0};  // sibling operators built by a shared pass (orc_debug_shared_galerkin)
+long long debug_shared_galerkin(bool reset) {
+    const long long v = g_shared_galerkin.load(std::memory_order_relaxed);
+    if (reset) g_shared_galerkin.store(0, std::memory_order_relaxed);
+    return v;
+}
+
+static int galerkin(const MatView &A, const int *choice, const int *chooser, Arena &arena, CoarseLevel &L, Arena *scratch = nullptr, bool last_level = false,
+                    const GalerkinSibling *sib = nullptr, int n_sib = 0) {
+    if (n_sib < 0 || n_sib > 2 || (n_sib > 0 && (!scratch || !sib))) return set_error(ORC_ERR_BAD_ARGUMENT, "galerkin: bad sibling arguments");
     Arena &tmp = scratch ? *scratch : arena;
     ArenaScope tmp_scope(tmp);  // with `scratch`: unwinds it on every exit; without: re-marked below so that nothing is released
     const int64_t n = A.P.n, nc = n / 2 + n % 2;  // :13
@@ -2175,6 +2324,17 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
     double *s_val;
     ORC_TRY(tmp.alloc((size_t)scratch_cap, &s_col));
     ORC_TRY(tmp.alloc((size_t)scratch_cap, &s_val));
+    MergeSiblings X;
+    const bool fine_mirror = A.rows.col != nullptr;
+    for (int x = 0; x < n_sib; ++x) {
+        const MatView &B = *sib[x].A;
+        if (B.P.n != n || B.P.col != A.P.col || (B.rows.col != nullptr) != fine_mirror || (fine_mirror && B.rows.col != A.rows.col))
+            return set_error(ORC_ERR_BAD_ARGUMENT, "galerkin: a sibling system does not share the leader's pattern");
+        X.val[x] = fine_mirror ? B.rows.val : B.val;
+        X.s1[x] = B.s1;
+        X.s2[x] = B.s2;
+        ORC_TRY(tmp.alloc((size_t)scratch_cap, &X.s_val[x]));
+    }
     lap("galerkin bounds");
     static std::once_flag attr_once;  // several lane threads reach this concurrently
     std::call_once(attr_once, [] {
@@ -2182,15 +2342,25 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&galerkin_merge_k<64, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&galerkin_merge_k<64, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&galerkin_merge_k<64, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&galerkin_merge_k<64, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&galerkin_merge_k<64, 0, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&galerkin_merge_k<32, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&galerkin_merge_k<32, 0, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&galerkin_merge_k<16, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&galerkin_merge_k<16, 0, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
+    if (n_sib > 0 && use_sort) return set_error(ORC_ERR_BAD_ARGUMENT, "galerkin: the sorting form (ORC_GALERKIN_SORT) builds one system per pass");
     // LDS tiers (32 B per list slot): every row was assigned to the narrowest list that is guaranteed to hold it
     if ((size_t)2 * max_cand > (size_t)(64 << (kGalerkinTiers - 1))) return set_error(ORC_ERR_BAD_ARGUMENT, "Galerkin row too long for LDS (%d candidates)", max_cand);
     for (int t = 0; t < kGalerkinTiers && !use_sort; ++t) {
         if (htier[t] == 0) continue;
         const int cap = 64 << t;
-        const int G = tier_group[t];  // narrow rows: two or four coarse rows per wavefront
+        int G = tier_group[t];  // narrow rows: two or four coarse rows per wavefront
+        // a wavefront's lists must fit the LDS of one workgroup: wider groups (fewer rows per wavefront) where the sibling value sets would not
+        while (G < 64 && (size_t)cap * (size_t)(16 + 8 * n_sib) * (size_t)(64 / G) > (size_t)150 * 1024) G <<= 1;
         const int rows_per_wave = 64 / G;
-        const size_t smem = (size_t)cap * 16 * (size_t)rows_per_wave;
+        const size_t smem = (size_t)cap * (size_t)(16 + 8 * n_sib) * (size_t)rows_per_wave;
+        if (smem > (size_t)160 * 1024) return set_error(ORC_ERR_BAD_ARGUMENT, "Galerkin row too long for a shared pass (%d candidates, %d systems)", max_cand, n_sib + 1);
         // 83-88 VGPRs: five wavefronts per SIMD are resident.  Measured (one stream, all tiers of six SIMPLE iterations): 16 per CU 407 ms,
         // 20: 372 ms, 24: 410 ms (the launch no longer fits and its tail runs alone); round 2's kernel at 16: 438 ms
         static const int merge_waves = getenv("ORC_GALERKIN_WAVES") ? atoi(getenv("ORC_GALERKIN_WAVES")) : 20;
@@ -2198,15 +2368,25 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
         const int g = (int)std::min<int64_t>(((int64_t)htier[t] + rows_per_wave - 1) / rows_per_wave, (int64_t)256 * waves_per_cu);
         const int *tl = tier_list + (int64_t)t * nc, *tc = tier_count + t;
         static const bool stages = getenv("ORC_GALERKIN_STAGES") && atoi(getenv("ORC_GALERKIN_STAGES")) != 0;
-#define ORC_MERGE(GG, SS) hipLaunchKernelGGL(HIP_KERNEL_NAME(galerkin_merge_k<GG, SS>), dim3(g), dim3(64), smem, st, A, choice, chooser, nc, cap, row_len, slice_base, intra_off, s_col, s_val, tl, tc)
-        if (stages) {  // measurement: the kernel cut short after steps 1 and 4, then the real launch
-            if (G == 16) { ORC_MERGE(16, 1); ORC_MERGE(16, 4); }
-            else if (G == 32) { ORC_MERGE(32, 1); ORC_MERGE(32, 4); }
-            else { ORC_MERGE(64, 1); ORC_MERGE(64, 4); }
+#define ORC_MERGE(GG, SS, NS) hipLaunchKernelGGL(HIP_KERNEL_NAME(galerkin_merge_k<GG, SS, NS>), dim3(g), dim3(64), smem, st, A, choice, chooser, nc, cap, row_len, slice_base, intra_off, s_col, s_val, tl, tc, X)
+        if (stages && n_sib == 0) {  // measurement: the kernel cut short after steps 1 and 4, then the real launch
+            if (G == 16) { ORC_MERGE(16, 1, 1); ORC_MERGE(16, 4, 1); }
+            else if (G == 32) { ORC_MERGE(32, 1, 1); ORC_MERGE(32, 4, 1); }
+            else { ORC_MERGE(64, 1, 1); ORC_MERGE(64, 4, 1); }
         }
-        if (G == 16) ORC_MERGE(16, 0);
-        else if (G == 32) ORC_MERGE(32, 0);
-        else ORC_MERGE(64, 0);
+        if (n_sib == 0) {
+            if (G == 16) ORC_MERGE(16, 0, 1);
+            else if (G == 32) ORC_MERGE(32, 0, 1);
+            else ORC_MERGE(64, 0, 1);
+        } else if (n_sib == 1) {
+            if (G == 16) ORC_MERGE(16, 0, 2);
+            else if (G == 32) ORC_MERGE(32, 0, 2);
+            else ORC_MERGE(64, 0, 2);
+        } else {
+            if (G == 16) ORC_MERGE(16, 0, 3);
+            else if (G == 32) ORC_MERGE(32, 0, 3);
+            else ORC_MERGE(64, 0, 3);
+        }
 #undef ORC_MERGE
     }
     for (int t = 0; t < kGalerkinTiers && use_sort; ++t) {
@@ -2250,9 +2430,18 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
         ORC_TRY(arena.alloc((size_t)packed_total, &pk_col));
         ORC_TRY(arena.alloc((size_t)packed_total, &pk_val));
     }
-    hipLaunchKernelGGL(galerkin_pack_fused_k, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(n_slices, 256 * 12))), dim3(64), 0, st, Pc, slice_base, intra_off,
+    hipLaunchKernelGGL(galerkin_pack_fused_k<false>, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(n_slices, 256 * 12))), dim3(64), 0, st, Pc, slice_base, intra_off,
                        s_col, s_val, col, val, diag, mirror ? (const int64_t *)pk_ptr : (const int64_t *)nullptr, pk_col, pk_val);
     ORC_HIP(hipGetLastError());
+    double *x_val[2] = {nullptr, nullptr}, *x_pk_val[2] = {nullptr, nullptr};
+    for (int x = 0; x < n_sib; ++x) {  // the siblings' values on the same images
+        ORC_TRY(sib[x].arena->alloc((size_t)std::max<int64_t>(padded, 1), &x_val[x]));
+        if (mirror) ORC_TRY(sib[x].arena->alloc((size_t)packed_total, &x_pk_val[x]));
+        hipLaunchKernelGGL(galerkin_pack_fused_k<true>, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(n_slices, 256 * 12))), dim3(64), 0, st, Pc, slice_base, intra_off,
+                           s_col, (const double *)X.s_val[x], (int *)nullptr, x_val[x], (int *)nullptr, mirror ? (const int64_t *)pk_ptr : (const int64_t *)nullptr, (int *)nullptr,
+                           x_pk_val[x]);
+        ORC_HIP(hipGetLastError());
+    }
     lap("galerkin pack");
     // narrow column image for the levels the uniform kernels multiply (no packed mirror: the first coarse level): 2-byte columns in
     // their products' stream; all or nothing, decided on the host (the kernel variant is a template argument)
@@ -2276,6 +2465,12 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
     L.xw = XWinDev();
     L.xs = XSortDev();
     L.rows = RowsDev();
+    for (int x = 0; x < n_sib; ++x) {
+        CoarseLevel &Lx = *sib[x].L;
+        Lx = CoarseLevel();
+        Lx.P = Pc; Lx.val = x_val[x]; Lx.n = nc; Lx.padded = padded; Lx.rounds = L.rounds;
+        Lx.choice = L.choice; Lx.chooser = L.chooser;
+    }
     static const bool rows_enabled = !(getenv("ORC_AMG_ROWS_MIRROR") && atoi(getenv("ORC_AMG_ROWS_MIRROR")) == 0);
     if (rows_enabled && !scratch) { L.rows.slice_base = slice_base; L.rows.intra_off = intra_off; L.rows.col = s_col; L.rows.val = s_val; }
     if (rows_enabled && scratch && packed_total > 0 && !last_level) {  // exact-size copy; the slices start where the packed mirror's do (pk_ptr); the last level is never aggregated
@@ -2295,6 +2490,21 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
                            (const long long *)slice_base, (const int *)intra_off, (const int *)s_col, (const double *)s_val, (const int64_t *)pk_ptr, r_intra, r_col, r_val);
         ORC_HIP(hipGetLastError());
         L.rows.slice_base = reinterpret_cast<const long long *>(pk_ptr); L.rows.intra_off = r_intra; L.rows.col = r_col; L.rows.val = r_val;
+        for (int x = 0; x < n_sib; ++x) {  // a whole copy per sibling: the leader's is gone when ITS next level is built
+            Arena &xa = (mirror_arena_on && sib[x].rows_arena) ? *sib[x].rows_arena : *sib[x].arena;
+            if (mirror_arena_on && sib[x].rows_arena) xa.release(Arena::Mark{0, 0});
+            int *xr_col, *xr_intra;
+            double *xr_val;
+            ORC_TRY(xa.alloc((size_t)packed_total, &xr_col));
+            ORC_TRY(xa.alloc((size_t)packed_total, &xr_val));
+            ORC_TRY(xa.alloc(ncs, &xr_intra));
+            hipLaunchKernelGGL(rows_compact_k, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(n_slices, 256 * 16))), dim3(64), 0, st, (const int *)row_len, nc, n_slices,
+                               (const long long *)slice_base, (const int *)intra_off, (const int *)s_col, (const double *)X.s_val[x], (const int64_t *)pk_ptr, xr_intra, xr_col, xr_val);
+            ORC_HIP(hipGetLastError());
+            CoarseLevel &Lx = *sib[x].L;
+            Lx.rows.slice_base = reinterpret_cast<const long long *>(pk_ptr); Lx.rows.intra_off = xr_intra; Lx.rows.col = xr_col; Lx.rows.val = xr_val;
+            Lx.rows_transient = mirror_arena_on && sib[x].rows_arena != nullptr;
+        }
     }
     if (mirror) {
         L.pk.ptr = pk_ptr; L.pk.col = pk_col; L.pk.val = pk_val; L.pk.total = packed_total;
@@ -2309,6 +2519,12 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
         hipLaunchKernelGGL(xwin_build_k, dim3((unsigned)std::min<int64_t>(n_blocks, 2048)), dim3(kBlock), 0, st, Pc, L.pk, wcol, wsize, lidx, n_blocks, win_cap, bit_words);
         ORC_HIP(hipGetLastError());
         L.xw.wcol = wcol; L.xw.wsize = wsize; L.xw.lidx = lidx;
+        for (int x = 0; x < n_sib; ++x) {  // same structure, own values
+            CoarseLevel &Lx = *sib[x].L;
+            Lx.pk = L.pk;
+            Lx.pk.val = x_pk_val[x];
+            Lx.xw = L.xw;
+        }
         static const bool xwin_stats = getenv("ORC_XWIN_STATS") && atoi(getenv("ORC_XWIN_STATS")) != 0;
         if (xwin_stats) {
             unsigned long long *d_st, h_st[5];
@@ -2326,6 +2542,7 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
         // 227-244, same box), while building the image costs +45-65 ms and 11 GB per SIMPLE iteration — the window product is not
         // bound by instruction issue after all.  Kept behind the switch with its exactness test.  (read per call: the test switches it)
         const bool xsort_on = getenv("ORC_SPMV_XSORT") && atoi(getenv("ORC_SPMV_XSORT")) != 0;
+        if (xsort_on && n_sib > 0) return set_error(ORC_ERR_BAD_ARGUMENT, "galerkin: the length-sorted image (ORC_SPMV_XSORT) is built one system per pass");
         if (xsort_on) {
             int *perm, *slen;
             int64_t *sptr;
@@ -2346,6 +2563,7 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
     }
     lap("galerkin mirrors");
     if (!scratch) tmp_scope.mark = tmp.mark();  // the scratch rows ARE the mirror: everything stays
+    if (n_sib > 0) g_shared_galerkin.fetch_add(n_sib, std::memory_order_relaxed);
     return ORC_OK;
 }
 
@@ -2494,6 +2712,13 @@ int multigrid_prepare_dev(const MatView &A_in, int preconditioner, Arena &arena,
     H = AmgHierarchy();
     const int64_t n = A_in.P.n;
     H.n_fine = n;
+    // a follower (roles 2, 3) SPEAKS on every path — an offer or a withdrawal — because the leader waits for every follower it expects
+    struct SpeakGuard {
+        SiblingPairing *s;
+        int slot;
+        bool spoken = false;
+        ~SpeakGuard() { if (s && !spoken) s->withdraw(slot); }
+    } speak{(sibling && sibling_role >= 2) ? sibling : nullptr, sibling_role - 2};
     static const bool scratch_on = !(getenv("ORC_AMG_SCRATCH") && atoi(getenv("ORC_AMG_SCRATCH")) == 0);  // 0: everything in `arena` (round 2)
     if (!scratch_on) scratch = nullptr;
     if (n == 0) return ORC_OK;
@@ -2524,26 +2749,95 @@ int multigrid_prepare_dev(const MatView &A_in, int preconditioner, Arena &arena,
         else return set_error(ORC_ERR_BAD_ARGUMENT, "more than two nested Jacobi scalings");
     }
     const uint64_t max_levels = 3;  // MULTIGRID_COARSENING_LEVELS, :10
+    // [r04] one Galerkin pass for the momentum systems that share the fine pairing (SiblingPairing::make_offer ...; ORC_AMG_SHARED_GALERKIN=0:
+    // every system multiplies for itself, r03).  Read per call: the tests compare the two forms.
+    const bool share_on = !(getenv("ORC_AMG_SHARED_GALERKIN") && atoi(getenv("ORC_AMG_SHARED_GALERKIN")) == 0) && scratch != nullptr &&
+                          !(getenv("ORC_GALERKIN_SORT") && atoi(getenv("ORC_GALERKIN_SORT")) != 0) && !(getenv("ORC_SPMV_XSORT") && atoi(getenv("ORC_SPMV_XSORT")) != 0);
     for (uint64_t level = 1; level <= max_levels; ++level) {
         const MatView &A = views[level - 1];
         const int64_t nf = A.P.n;
         AmgHierarchy::Level &h = H.level[level - 1];
+        CoarseLevel L;
+        bool adopted = false;
+        if (sibling && sibling_role >= 2 && level == 1) {  // a follower always speaks: the leader waits for every expected follower
+            const int slot = sibling_role - 2;
+            speak.spoken = true;
+            if (share_on && sibling->make_offer(slot, &views[0], &arena, scratch ? &scratch->companion() : nullptr, &L, ctx().stream) == ORC_OK) {
+                adopted = sibling->wait_answer(slot, ctx().stream);
+            } else {
+                sibling->withdraw(slot);
+            }
+        }
+        if (adopted) {  // the leader has built this level on ITS pattern with this system's values (L) and vouches for the pairing
+            h.choice = const_cast<int *>(sibling->lead_choice);
+            h.chooser = const_cast<int *>(sibling->lead_chooser);
+            L.rounds = 1;
+        } else {
         ORC_TRY(arena.alloc((size_t)std::max<int64_t>(nf, 1), &h.choice));
         ORC_TRY(arena.alloc((size_t)std::max<int64_t>(nf, 1), &h.chooser));
-        CoarseLevel L;
         const int *warm = nullptr;
-        if (sibling && sibling_role == 2 && level == 1) warm = sibling->wait((int)level, nf, ctx().stream);
+        if (sibling && sibling_role >= 2 && level == 1) warm = sibling->wait((int)level, nf, ctx().stream);
         // the aggregation's work lists (48 bytes per row) are dead when it returns: they live in `scratch` when there is one
         Arena &agg_arena = scratch ? *scratch : arena;
         const Arena::Mark agg_mark = agg_arena.mark();
         const int agg_st = aggregate(A, agg_arena, h.choice, h.chooser, &L.rounds, warm, 2);
         if (scratch) scratch->release(agg_mark);
-        if (sibling && sibling_role == 1 && level == 1) {
+        GalerkinSibling gs[2];
+        int n_sib = 0;
+        bool took[2] = {false, false};
+        const bool leads = sibling && sibling_role == 1 && level == 1;
+        if (leads) {
             if (agg_st == ORC_OK) ORC_TRY(sibling->publish((int)level, h.choice, nf, ctx().stream));
-            sibling->finish();
+            if (agg_st == ORC_OK && share_on) {
+                SiblingPairing::Offer *offers[2] = {nullptr, nullptr};
+                const int n_off = sibling->collect_offers(offers);
+                if (n_off > 0 && nf > 0) {  // is this pairing the fixed point of the offered matrices too?  (agg_verify_k: one pass each)
+                    hipStream_t st = ctx().stream;
+                    ArenaScope vscope(*scratch);
+                    int *taken_by;
+                    AggCounters *C;
+                    ORC_TRY(scratch->alloc((size_t)nf, &taken_by));
+                    ORC_TRY(scratch->alloc((size_t)2, &C));
+                    ORC_HIP(hipMemsetAsync(C, 0, 2 * sizeof(AggCounters), st));
+                    const int g = grid_for(nf);
+                    hipLaunchKernelGGL(agg_reset_k, dim3(g), dim3(kBlock), 0, st, taken_by, nf);
+                    hipLaunchKernelGGL(agg_scatter_k, dim3(g), dim3(kBlock), 0, st, (const int *)h.choice, taken_by, nf);
+                    for (int q = 0; q < n_off; ++q) {
+                        const MatView &B = *offers[q]->view;
+                        if (B.P.n != nf || B.P.col != A.P.col) continue;
+                        ORC_HIP(hipStreamWaitEvent(st, offers[q]->view_ready, 0));
+                        hipLaunchKernelGGL(agg_verify_k, dim3(g), dim3(kBlock), 0, st, B, (const int *)h.choice, (const int *)taken_by, C + q);
+                    }
+                    ORC_HIP(hipGetLastError());
+                    AggCounters hc[2];
+                    ORC_HIP(hipMemcpyAsync(hc, C, sizeof(hc), hipMemcpyDeviceToHost, st));
+                    ORC_HIP(hipStreamSynchronize(st));
+                    static const bool trace_v = getenv("ORC_AMG_TRACE") != nullptr;
+                    for (int q = 0; q < n_off; ++q) {
+                        const MatView &B = *offers[q]->view;
+                        const bool same = B.P.n == nf && B.P.col == A.P.col && hc[q].changed == 0;
+                        if (trace_v) fprintf(stderr, "[amg sibling n=%lld] offered system %d: rows that would change: %d\n", (long long)nf, (int)(offers[q] - sibling->offer), hc[q].changed);
+                        if (!same) continue;
+                        gs[n_sib].A = offers[q]->view;
+                        gs[n_sib].arena = offers[q]->arena;
+                        gs[n_sib].rows_arena = offers[q]->rows_arena;
+                        gs[n_sib].L = static_cast<CoarseLevel *>(offers[q]->level);
+                        took[offers[q] - sibling->offer] = true;
+                        ++n_sib;
+                    }
+                }
+            }
         }
-        ORC_TRY(agg_st);
-        ORC_TRY(galerkin(A, h.choice, h.chooser, arena, L, scratch, level == max_levels));
+        int gal_st = agg_st;
+        if (gal_st == ORC_OK) gal_st = galerkin(A, h.choice, h.chooser, arena, L, scratch, level == max_levels, gs, n_sib);
+        if (leads) {
+            const bool none[2] = {false, false};
+            const int ans_st = sibling->answer(gal_st == ORC_OK ? took : none, h.choice, h.chooser, ctx().stream);
+            sibling->finish();
+            if (gal_st == ORC_OK) gal_st = ans_st;
+        }
+        ORC_TRY(gal_st);
+        }
         // a mirror in the companion arena lives until the next level is built: the hierarchy does not carry it
         h.P = L.P; h.val = L.val; h.pk = L.pk; h.xw = L.xw; h.xs = L.xs; h.rows = L.rows_transient ? RowsDev() : L.rows; h.n = L.n; h.padded = L.padded; h.rounds = L.rounds;
         H.n_levels = (int)level;
@@ -2661,7 +2955,9 @@ int multigrid_arm3_dev(const MatView3 &A3, const double *const b[3], double *con
             lanes[k].scratch_arena->release(Arena::Mark{0, 0});
             stp = lanes[k].scratch_arena->reset();  // nothing of the previous set-up is alive: a fragmented reservation becomes one chunk
         }
-        if (stp == ORC_OK) stp = multigrid_prepare_dev(plain[k], preconditioner, *lanes[k].hier_arena, lanes[k].hierarchy, sibling, k == 0 ? 1 : 2, lanes[k].scratch_arena);
+        // roles: 1 = leader (u), 2 / 3 = followers (slots 0 / 1 of the shared Galerkin pass)
+        if (stp == ORC_OK) stp = multigrid_prepare_dev(plain[k], preconditioner, *lanes[k].hier_arena, lanes[k].hierarchy, sibling, k == 0 ? 1 : k + 1, lanes[k].scratch_arena);
+        else if (k > 0 && sibling) sibling->withdraw(k - 1);  // the leader waits for every follower it was told to expect
         if (k == 0 && sibling) sibling->finish();  // whatever happened to u: v and w must not wait for a level that will not come
         if (hipStreamSynchronize(local[k].stream) != hipSuccess && stp == ORC_OK) stp = set_error(ORC_ERR_HIP, "stream synchronisation failed in a set-up thread");
         // test hook (tests/mp_worker.py, mode gpu_lane_error): ORC_DEBUG_INJECT_LANE_ERROR="rank:lane" fails that rank's set-up thread
@@ -2678,11 +2974,15 @@ int multigrid_arm3_dev(const MatView3 &A3, const double *const b[3], double *con
         std::thread *t;
         ~Joiner() { for (int k = 0; k < 3; ++k) if (t[k].joinable()) t[k].join(); }
     } joiner{th};
-    for (int k = 0; k < 3; ++k) {
+    // followers first: the leader is told how many of them will speak (a follower without a thread runs after the join, when the leader
+    // is through, and multiplies for itself)
+    int n_follower_threads = 0;
+    for (int k = 2; k >= 0; --k) {
         local[k] = g;
         local[k].stream = lanes[k].setup_stream;
         local[k].last_error.clear();
-        try { th[k] = std::thread(prepare, k); } catch (...) { /* no thread to be had: prepared below, before the join */ }
+        if (k == 0 && sibling) sibling->set_expected(n_follower_threads);
+        try { th[k] = std::thread(prepare, k); if (k > 0) ++n_follower_threads; } catch (...) { /* no thread to be had: prepared below, before the join */ }
     }
 
     // ORC_TRIPLE_SETUP_FIRST=1 (measurement): the three set-ups run with the chip to themselves, the level-0 solve follows (beside the

@@ -97,14 +97,14 @@ int orc_iterative_solve3(int64_t n, const int64_t *row_ptr, const int64_t *col_i
         if (st == ORC_OK) st = deinterleave3_dev(x3, dx[0].p, dx[1].p, dx[2].p, n);
     } else {
         TripleLane lanes[3];
-        Arena hier[3], vec[3];
+        Arena hier[3], vec[3], scratch[3];  // (scratch: the set-ups' transient storage, as in the solver's lanes — and what the shared Galerkin pass needs)
         SiblingPairing sibling;
         hipStream_t streams[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         for (int k = 0; k < 6 && st == ORC_OK; ++k)
             if (hipStreamCreateWithFlags(&streams[k], hipStreamNonBlocking) != hipSuccess) st = set_error(ORC_ERR_HIP, "hipStreamCreate failed");
         for (int k = 0; k < 3; ++k) {
             lanes[k].setup_stream = streams[2 * k]; lanes[k].solve_stream = streams[2 * k + 1];
-            lanes[k].hier_arena = &hier[k]; lanes[k].vec_arena = &vec[k];
+            lanes[k].hier_arena = &hier[k]; lanes[k].vec_arena = &vec[k]; lanes[k].scratch_arena = &scratch[k];
             lanes[k].symmetric = pat.symmetric;
         }
         const double *bb[3] = {db[0].p, db[1].p, db[2].p};

@@ -225,6 +225,29 @@ struct SiblingPairing {
     int publish(int level, const int *choice, int64_t rows, hipStream_t stream);  // leader, after its aggregation of `level`
     const int *wait(int level, int64_t rows, hipStream_t stream);                 // follower; null = start from scratch
     void finish();                     // leader, on every exit from its solve
+
+    // [r04] One Galerkin pass for the systems that share the fine pairing (multigrid_prepare_dev; amg.hip: GalerkinSibling).  A follower
+    // OFFERS its fine view and arenas and blocks; the leader, through with its fine aggregation, COLLECTS the offers, checks its pairing
+    // against every offered matrix (agg_verify_k), builds the first coarse operators of all that agree in one pass and ANSWERS; a follower
+    // whose answer is "adopted" continues with the second level, any other one falls back to wait() and its own product.  All hand-overs
+    // go through mu / cv, so the leader may allocate in a blocked follower's arenas.
+    struct Offer {
+        bool made = false, ok = false;          // made: the follower has spoken (ok = false: it withdrew)
+        const MatView *view = nullptr;
+        Arena *arena = nullptr, *rows_arena = nullptr;
+        hipEvent_t view_ready = nullptr;        // recorded on the follower's stream once its view (scalings) is complete
+        bool answered = false, adopted = false;
+        void *level = nullptr;                  // CoarseLevel the leader fills (owned by the follower's stack frame)
+    } offer[2];
+    int expected_offers = 0;                    // followers that WILL speak (set before the leader starts: set_expected)
+    hipEvent_t ops_ready = nullptr;             // recorded on the leader's stream behind the shared pass
+    const int *lead_choice = nullptr, *lead_chooser = nullptr;  // the leader's own arrays (alive as long as its hierarchy)
+    void set_expected(int n);
+    int make_offer(int slot, const MatView *view, Arena *arena, Arena *rows_arena, void *level, hipStream_t stream);  // follower
+    void withdraw(int slot);                                                                                          // follower, instead of an offer
+    bool wait_answer(int slot, hipStream_t stream);  // follower: true = its level was built by the leader (stream waits for it)
+    int collect_offers(Offer *out[2]);               // leader: blocks until every expected follower has spoken; returns how many offered
+    int answer(const bool adopted[2], const int *choice, const int *chooser, hipStream_t stream);  // leader
 };
 
 struct SolveStats {

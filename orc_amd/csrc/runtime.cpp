@@ -7,6 +7,7 @@
 namespace orc {
 long long debug_xsort_products();  // linalg.hip
 void debug_amg_certification(long long out[2], bool reset);  // amg.hip
+long long debug_shared_galerkin(bool reset);                   // amg.hip
 int debug_xwin_counters(long long out[3], bool reset);       // amg.hip
 
 static thread_local Ctx *t_ctx_override = nullptr;
@@ -229,6 +230,7 @@ int orc_debug_amg_certification(long long out[2], int reset) {
     orc::debug_amg_certification(out, reset != 0);
     return ORC_OK;
 }
+long long orc_debug_shared_galerkin(int reset) { return orc::debug_shared_galerkin(reset != 0); }
 int orc_debug_xwin_counters(long long out[3], int reset) {
     if (!out) return orc::set_error(ORC_ERR_BAD_ARGUMENT, "null argument");
     ORC_TRY(orc::ensure_init());

@@ -143,6 +143,13 @@ def xwin_counters(reset=False):
     return out[0], out[1], out[2]
 
 
+def shared_galerkin(reset=False):
+    """Test hook: sibling coarse operators built by a shared Galerkin pass since the last reset (two per lock-step momentum solve)"""
+    f = lib().orc_debug_shared_galerkin
+    f.restype = C.c_longlong
+    return int(f(C.c_int(1 if reset else 0)))
+
+
 def amg_certification(reset=False):
     """Test hook: (aggregations certified after their cascades, certification rounds in total); equal = nothing was changed"""
     out = (C.c_longlong * 2)()

@@ -30,7 +30,13 @@ def three_systems(shape, distinct_pairings=False, seed=1):
     n = a0.shape[0]
     mats = [a0]
     for k in (1, 2):
-        if distinct_pairings:
+        if distinct_pairings == "scaled":
+            # every row times a positive factor of its own: other values, the same order inside every row, hence the SAME greedy pairing
+            # (linear_algebra.rs:38-52 compares the entries of one row) — the case the shared Galerkin pass is for
+            a = a0.copy()
+            scale = 1.0 + 0.5 * np.abs(splitmix64_uniform(n, seed + 1000 * k))
+            a.data = a0.data * np.repeat(scale, np.diff(a0.indptr))
+        elif distinct_pairings:
             a = fv_like_matrix(*shape, seed=seed + 10 * k)
             assert np.array_equal(a.indptr, a0.indptr) and np.array_equal(a.indices, a0.indices)
         else:
@@ -59,23 +65,62 @@ def test_bicgstab_three_systems_bit_identical_to_one_at_a_time(gpu, shape, preco
 
 
 @pytest.mark.parametrize("shape", [(20, 17, 9), (64, 40, 12), (33, 9, 4)])
-@pytest.mark.parametrize("distinct", [False, True])
+@pytest.mark.parametrize("distinct", [False, True, "scaled"])
 @pytest.mark.parametrize("precond", [PRE_JACOBI, PRE_NONE])
 def test_multigrid_arm_three_systems_bit_identical(gpu, shape, distinct, precond):
-    """Shared pairings (level 1 in lock-step as well) and distinct pairings (per-system coarse parts): either way the bits of
-    three separate Multigrid solves."""
-    from orc_amd.linear_algebra import iterative_solve, iterative_solve3
+    """Shared pairings ("scaled": level 1 in lock-step as well, its three operators from ONE Galerkin pass), pairings that differ in a few rows
+    (False: the perturbed systems) and distinct pairings (per-system coarse parts): either way the bits of three separate Multigrid solves."""
+    from orc_amd.linear_algebra import iterative_solve, iterative_solve3, shared_galerkin
     mats, bs, xs = three_systems(shape, distinct_pairings=distinct)
     for iters in (6, 50):
         x3 = [x.copy() for x in xs]
+        shared_galerkin(reset=True)
         st, st3 = iterative_solve3(mats, bs, x3, iters, MULTIGRID, 0.5, 1e-3, precond)
         assert st == 0
+        # [r04] shared pairings: ONE Galerkin pass built the first coarse operators of all three systems (two sibling operators)
+        if distinct == "scaled":
+            assert shared_galerkin() == 2
+        elif distinct:
+            assert shared_galerkin() == 0
         for k in range(3):
             x1 = xs[k].copy()
             st1 = iterative_solve(mats[k], bs[k], x1, iters, MULTIGRID, 0.5, 1e-3, precond, raise_on_error=False)
             assert st1 == st3[k], "system %d" % k
             if st1 == 0:
                 assert same_bits(x3[k], x1), "system %d, %d iterations" % (k, iters)
+
+
+@pytest.mark.parametrize("shape", [(20, 17, 9), (64, 40, 12)])
+@pytest.mark.parametrize("odd_one", [1, 2])
+def test_shared_galerkin_pass_with_one_sibling_and_switched_off(gpu, monkeypatch, shape, odd_one):
+    """[r04] The shared Galerkin pass (amg.hip: MergeSiblings; linear_algebra.rs:80-84 per system) with TWO value sets: one of v / w has a
+    pairing of its own and multiplies for itself, the other rides with u.  And ORC_AMG_SHARED_GALERKIN=0 (every system for itself, r03)
+    gives the same bits."""
+    from orc_amd.linear_algebra import iterative_solve, iterative_solve3, shared_galerkin
+    near, bs, xs = three_systems(shape, distinct_pairings="scaled")
+    far, bs_far, _ = three_systems(shape, distinct_pairings=True)
+    mats = list(near)
+    mats[odd_one] = far[odd_one]
+    bs = list(bs)
+    bs[odd_one] = bs_far[odd_one]
+    results = {}
+    for switch in ("1", "0"):
+        monkeypatch.setenv("ORC_AMG_SHARED_GALERKIN", switch)
+        x3 = [x.copy() for x in xs]
+        shared_galerkin(reset=True)
+        st, st3 = iterative_solve3(mats, bs, x3, 10, MULTIGRID, 0.5, 1e-3, PRE_JACOBI)
+        assert st == 0
+        assert shared_galerkin() == (1 if switch == "1" else 0)
+        results[switch] = (st3, x3)
+    monkeypatch.delenv("ORC_AMG_SHARED_GALERKIN")
+    assert results["1"][0] == results["0"][0]
+    for k in range(3):
+        x1 = xs[k].copy()
+        st1 = iterative_solve(mats[k], bs[k], x1, 10, MULTIGRID, 0.5, 1e-3, PRE_JACOBI, raise_on_error=False)
+        assert st1 == results["1"][0][k]
+        if st1 == 0:
+            assert same_bits(results["1"][1][k], x1), "system %d (shared pass)" % k
+            assert same_bits(results["0"][1][k], x1), "system %d (every system for itself)" % k
 
 
 def test_breakdown_guard_acts_per_system(gpu):
