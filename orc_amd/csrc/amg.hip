@@ -2159,10 +2159,34 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
                 fprintf(stderr, "[amg chase n=%lld] launches %d evaluations %d left %d finished %d\n", (long long)n, launches, stot, h.cur, h.finished);
             }
             fin = h.finished != 0;
+            bool verified_clean = false;
             if (!fin) {  // certification / completion: exact first takers from scratch, every row evaluated
                 hipLaunchKernelGGL(agg_reset_k, dim3(g), dim3(kBlock), 0, st, taken_by, n);
                 hipLaunchKernelGGL(agg_scatter_k, dim3(g), dim3(kBlock), 0, st, choice, taken_by, n);
-                hipLaunchKernelGGL(tail_seed_k, dim3(1), dim3(1), 0, st, T, (int)n);
+                // [r04] the cascades ran out (nothing left to evaluate): the certifying round is expected to change nothing, and "would any
+                // row choose differently against the exact table?" is one coalesced pass (agg_verify_k: the sibling check's kernel) instead of a
+                // lock-step round's evaluate / commit / update / rotate over every row.  Only a state that is NOT the fixed point goes through
+                // the lock-step rounds (ORC_AMG_CERTIFY_ROUND=1: always, r03).
+                const bool quick = h.cur == 0 && !(getenv("ORC_AMG_CERTIFY_ROUND") && atoi(getenv("ORC_AMG_CERTIFY_ROUND")) != 0);
+                if (quick) {
+                    AggCounters hc;
+                    ORC_HIP(hipMemsetAsync(C, 0, sizeof(AggCounters), st));
+                    hipLaunchKernelGGL(agg_verify_k, dim3(g), dim3(kBlock), 0, st, A, (const int *)choice, (const int *)taken_by, C);
+                    ORC_HIP(hipGetLastError());
+                    ORC_HIP(hipMemcpyAsync(&hc, C, sizeof(hc), hipMemcpyDeviceToHost, st));
+                    ORC_HIP(hipStreamSynchronize(st));
+                    verified_clean = hc.changed == 0;
+                    if (trace) fprintf(stderr, "[amg certify n=%lld] one verification pass: %d rows would change\n", (long long)n, hc.changed);
+                }
+                if (verified_clean) {
+                    fin = true;
+                    g_cert_aggregations.fetch_add(1, std::memory_order_relaxed);
+                    g_cert_rounds.fetch_add(1, std::memory_order_relaxed);
+                    rounds += 1;
+                    lap("certification pass");
+                } else {
+                    hipLaunchKernelGGL(tail_seed_k, dim3(1), dim3(1), 0, st, T, (int)n);
+                }
             }
         }
         int cert_batches = 0;
@@ -2192,8 +2216,8 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
             g_cert_aggregations.fetch_add(1, std::memory_order_relaxed);
             g_cert_rounds.fetch_add(h.rounds, std::memory_order_relaxed);
         }
-        if (trace && chase_enabled) fprintf(stderr, "[amg certify n=%lld] lock-step rounds %d\n", (long long)n, h.rounds);
-        rounds += h.rounds;
+        if (trace && chase_enabled && cert_batches > 0) fprintf(stderr, "[amg certify n=%lld] lock-step rounds %d\n", (long long)n, h.rounds);
+        if (cert_batches > 0) rounds += h.rounds;  // (a clean verification pass has counted itself)
     }
     ORC_HIP(hipMemsetAsync(chooser, 0xff, sizeof(int) * (size_t)n, st));
     hipLaunchKernelGGL(chooser_k, dim3(g), dim3(kBlock), 0, st, choice, chooser, n);
