@@ -640,12 +640,27 @@ __global__ __launch_bounds__(kBlock) void tail_chase_k(MatView A, int *choice, u
     int *next = T->parity ? list_a : list_b;
     const int lane = threadIdx.x & (G - 1);  // lane inside the group
     int steps = 0;
-    while (steps < max_steps) {  // rows are claimed one at a time: a group that is through with a short cascade takes the next
-        int idx = 0;             // (rows nobody claims before the budgets run out are carried over by chase_carry_k)
-        if (lane == 0) idx = atomicAdd(&T->fetch, 1);
-        idx = __shfl(idx, 0, G);
-        if (idx >= count) break;
-        int i = cur[idx];
+    // [r04] The list is a queue behind ONE counter, and same-address atomics retire at 11.4 ns per wave-instruction on this chip
+    // (scripts/microbench/atomic_rate.hip): a million claims of one row each are 3-11 ms of nothing but the counter, and the 8 192
+    // wavefronts of a launch that finds a short list still paid 93 us to learn that it is empty.  So a group claims SEVERAL rows per
+    // atomic — the list spread over twice the launch's groups, 1 to 16 rows a claim, so short lists still fan out over the chip — and looks
+    // at the counter with a plain load before it adds to it; rows it claimed and did not reach go to the next list below.
+    const int n_groups = (int)gridDim.x * (kBlock / G);
+    const int claim = max(1, min(16, count / (2 * n_groups)));
+    int c_idx = 0, c_left = 0;  // this group's claimed entries [c_idx, c_idx + c_left)
+    while (steps < max_steps) {  // (rows nobody claims before the budgets run out are carried over by chase_carry_k)
+        if (c_left == 0) {
+            if (ld_i(&T->fetch) >= count) break;
+            int b = 0;
+            if (lane == 0) b = atomicAdd(&T->fetch, claim);
+            b = __shfl(b, 0, G);
+            if (b >= count) break;
+            c_idx = b;
+            c_left = min(claim, count - b);
+        }
+        int i = cur[c_idx];
+        ++c_idx;
+        --c_left;
         while (i >= 0) {
             if (steps >= max_steps) {  // hand the row (still queued) to the next launch
                 if (lane == 0) next[atomicAdd(&T->next, 1)] = i;
@@ -697,7 +712,17 @@ __global__ __launch_bounds__(kBlock) void tail_chase_k(MatView A, int *choice, u
             i = cont;
         }
     }
-    if (lane == 0 && steps) atomicAdd(&T->changed, steps);  // statistics: evaluations of this launch
+    if (c_left > 0) {  // claimed and not reached (the step budget ran out first): still queued, the next launch takes them
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&T->next, c_left);
+        base = __shfl(base, 0, G);
+        for (int e = lane; e < c_left; e += G) next[base + e] = cur[c_idx + e];
+    }
+    // statistics (evaluations of this launch): one atomic per wavefront
+    int s = lane == 0 ? steps : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(&T->changed, s);
 }
 
 // rows of the current list that no group claimed (every budget ran out first) move to the next list
@@ -1431,14 +1456,24 @@ __global__ __launch_bounds__(64) void galerkin_pack_fused_k(SellDev Pc, const lo
 // entries (every candidate spawns <= 2 products), so the scratch offset of row I is the exclusive prefix sum of 2c:
 // computed here per 64-row slice (wave scan) + slice totals, finished by scan_i64_k.  No allocator atomics.
 constexpr int kGalerkinTiers = 7;  // LDS list capacities 64 << t, t = 0..6 (2 KB .. 128 KB per wavefront)
+// [r04] The tier lists are appended to behind one counter per tier, and same-address atomics retire at 11.4 ns per wave-instruction
+// (scripts/microbench/atomic_rate.hip): one append per slice and tier was the kernel — 80 000 slices on the first level, 0.74-1.06 ms of a
+// pass that moves 100 MB.  Now a wavefront keeps the tiers of all its slices in LDS (kBoundIters of them at most: the launch is sized for
+// that), counts them, reserves ONE range per tier and writes its rows there in a second walk over the LDS bytes.
+constexpr int kBoundIters = 32;
 __global__ __launch_bounds__(64) void galerkin_bound_k(SellDev P, const int *__restrict__ choice, int64_t n_coarse, int *__restrict__ out_max,
                                                        unsigned long long *__restrict__ out_sum, int *__restrict__ intra_off,
                                                        long long *__restrict__ slice_tot, int *__restrict__ tier_count, int *__restrict__ tier_list, int min_tier) {
+    __shared__ signed char tiers[kBoundIters][64];
     const int lane = threadIdx.x;
     const int64_t n_slices = (n_coarse + 63) / 64;
     int mx = 0;
     unsigned long long sm = 0;
-    for (int64_t s = blockIdx.x; s < n_slices; s += gridDim.x) {
+    int cnt[kGalerkinTiers];
+#pragma unroll
+    for (int t = 0; t < kGalerkinTiers; ++t) cnt[t] = 0;
+    int it = 0;
+    for (int64_t s = blockIdx.x; s < n_slices && it < kBoundIters; s += gridDim.x, ++it) {
         const int64_t I = s * 64 + lane;
         int c = 0;
         if (I < n_coarse) {
@@ -1459,13 +1494,29 @@ __global__ __launch_bounds__(64) void galerkin_bound_k(SellDev P, const int *__r
             tier = min_tier;  // sorting kernel: 128 slots (4 KB) at least, 16 wavefronts per CU already saturate the narrow rows
             while (tier < kGalerkinTiers - 1 && (64 << tier) < 2 * c) ++tier;
         }
+        tiers[it][lane] = (signed char)tier;
+#pragma unroll
+        for (int t = 0; t < kGalerkinTiers; ++t) cnt[t] += __popcll(__ballot(tier == t));  // wave-uniform
+    }
+    int base[kGalerkinTiers];
+#pragma unroll
+    for (int t = 0; t < kGalerkinTiers; ++t) {
+        base[t] = 0;
+        if (cnt[t] > 0) {  // wave-uniform
+            if (lane == 0) base[t] = atomicAdd(&tier_count[t], cnt[t]);
+            base[t] = __shfl(base[t], 0, 64);
+        }
+    }
+    it = 0;
+    for (int64_t s = blockIdx.x; s < n_slices && it < kBoundIters; s += gridDim.x, ++it) {
+        const int64_t I = s * 64 + lane;
+        const int tier = tiers[it][lane];
+#pragma unroll
         for (int t = 0; t < kGalerkinTiers; ++t) {
             const unsigned long long m = __ballot(tier == t);
             if (m == 0ull) continue;
-            int base = 0;
-            if (lane == 0) base = atomicAdd(&tier_count[t], __popcll(m));
-            base = __shfl(base, 0, 64);
-            if (tier == t) tier_list[(int64_t)t * n_coarse + base + __popcll(m & ((1ull << lane) - 1ull))] = (int)I;
+            if (tier == t) tier_list[(int64_t)t * n_coarse + base[t] + __popcll(m & ((1ull << lane) - 1ull))] = (int)I;
+            base[t] += __popcll(m);
         }
     }
 #pragma unroll
@@ -2332,7 +2383,9 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
     ORC_TRY(tmp.alloc((size_t)kGalerkinTiers + 1, &tier_count));
     ORC_TRY(tmp.alloc((size_t)kGalerkinTiers * ncs, &tier_list));
     ORC_HIP(hipMemsetAsync(tier_count, 0, (kGalerkinTiers + 1) * sizeof(int), st));
-    hipLaunchKernelGGL(galerkin_bound_k, dim3((unsigned)std::min<int64_t>(n_slices, 8192)), dim3(64), 0, st, A.P, choice, nc, flags, counters + 1, intra_off,
+    // (a wavefront walks at most kBoundIters slices: the grid grows with the level beyond 8 192 x kBoundIters slices = 16.8 M coarse rows)
+    const int64_t bound_grid = std::max<int64_t>(std::min<int64_t>(std::max<int64_t>(n_slices, 1), 8192), ((int64_t)n_slices + kBoundIters - 1) / kBoundIters);
+    hipLaunchKernelGGL(galerkin_bound_k, dim3((unsigned)bound_grid), dim3(64), 0, st, A.P, choice, nc, flags, counters + 1, intra_off,
                        slice_tot, tier_count, tier_list, use_sort ? 1 : 0);
     hipLaunchKernelGGL(scan_i64_k, dim3(1), dim3(kScanThreads), 0, st, slice_tot, (int64_t)n_slices, slice_base);
     int hflags[4];

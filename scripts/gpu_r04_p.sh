@@ -8,4 +8,4 @@ rc=$?
 tail -4 gpurun_out/r04p_tests.log
 if [ $rc -ne 0 ]; then grep -E "Error|assert|FAILED" gpurun_out/r04p_tests.log | head -20; exit $rc; fi
 timeout -k 10 300 python bench.py --steps 5 --warmup 2 > gpurun_out/r04p_bench_on.json 2> gpurun_out/r04p_bench_on.err && python -c "import json;d=json.load(open('gpurun_out/r04p_bench_on.json'));print('verification pass  ', d['ms_per_step'], d['step_ms'])" &&
-ORC_AMG_CERTIFY_ROUND=1 timeout -k 10 300 python bench.py --steps 5 --warmup 2 > gpurun_out/r04p_bench_off.json 2> gpurun_out/r04p_bench_off.err && python -c "import json;d=json.load(open('gpurun_out/r04p_bench_off.json'));print('certification round', d['ms_per_step'], d['step_ms'])"
+ORC_AMG_CERTIFY_ROUND=0 timeout -k 10 300 python bench.py --steps 5 --warmup 2 > gpurun_out/r04p_bench_off.json 2> gpurun_out/r04p_bench_off.err && python -c "import json;d=json.load(open('gpurun_out/r04p_bench_off.json'));print('second run         ', d['ms_per_step'], d['step_ms'])"
