@@ -631,6 +631,9 @@ __device__ __forceinline__ void chase_touch2(const MatView &A, const int *choice
     }
 }
 
+// rows per claim of a cascade launch: the list spread over twice the launch's groups, 1 to 16
+__device__ __forceinline__ int chase_claim(int count, int n_groups) { return max(1, min(16, count / (2 * n_groups))); }
+
 template <int G>
 __global__ __launch_bounds__(kBlock) void tail_chase_k(MatView A, int *choice, unsigned long long *tb, int *ver, int *flag, TailCounters *T, int *list_a,
                                                        int *list_b, int max_steps) {
@@ -641,18 +644,21 @@ __global__ __launch_bounds__(kBlock) void tail_chase_k(MatView A, int *choice, u
     const int lane = threadIdx.x & (G - 1);  // lane inside the group
     int steps = 0;
     // [r04] The list is a queue behind ONE counter, and same-address atomics retire at 11.4 ns per wave-instruction on this chip
-    // (scripts/microbench/atomic_rate.hip): a million claims of one row each are 3-11 ms of nothing but the counter, and the 8 192
-    // wavefronts of a launch that finds a short list still paid 93 us to learn that it is empty.  So a group claims SEVERAL rows per
-    // atomic — the list spread over twice the launch's groups, 1 to 16 rows a claim, so short lists still fan out over the chip — and looks
-    // at the counter with a plain load before it adds to it; rows it claimed and did not reach go to the next list below.
+    // (scripts/microbench/atomic_rate.hip): the 8 192 wavefronts of a launch paid 93 us for their first claims alone, however short the
+    // list.  So every group OWNS a first share of the list by its index — `claim` rows, the list spread over twice the launch's groups,
+    // 1 to 16 rows a claim — and only what lies beyond those shares is claimed through the counter, `claim` rows per atomic.  (A plain-load
+    // look at the counter before every claim was measured too: +14 % on the cascades — most claims are single-step rows, and the look is one
+    // more round trip for each of them.)  Rows a group owns or claimed and did not reach go to the next list below.
     const int n_groups = (int)gridDim.x * (kBlock / G);
-    const int claim = max(1, min(16, count / (2 * n_groups)));
-    int c_idx = 0, c_left = 0;  // this group's claimed entries [c_idx, c_idx + c_left)
+    const int claim = chase_claim(count, n_groups);
+    const int static_end = n_groups * claim;  // (chase_carry_k computes the same)
+    int c_idx = ((int)blockIdx.x * (kBlock / G) + (int)threadIdx.x / G) * claim;  // this group's entries [c_idx, c_idx + c_left)
+    int c_left = max(0, min(claim, count - c_idx));
     while (steps < max_steps) {  // (rows nobody claims before the budgets run out are carried over by chase_carry_k)
         if (c_left == 0) {
-            if (ld_i(&T->fetch) >= count) break;
+            if (static_end >= count) break;  // the static shares were the whole list
             int b = 0;
-            if (lane == 0) b = atomicAdd(&T->fetch, claim);
+            if (lane == 0) b = static_end + atomicAdd(&T->fetch, claim);
             b = __shfl(b, 0, G);
             if (b >= count) break;
             c_idx = b;
@@ -726,9 +732,13 @@ __global__ __launch_bounds__(kBlock) void tail_chase_k(MatView A, int *choice, u
 }
 
 // rows of the current list that no group claimed (every budget ran out first) move to the next list
-__global__ void chase_carry_k(TailCounters *T, const int *list_a, const int *list_b, int *out_a, int *out_b) {
+__global__ void chase_carry_k(TailCounters *T, const int *list_a, const int *list_b, int *out_a, int *out_b, int n_groups /* of the cascade launch before */) {
     if (T->finished) return;
-    const int count = T->cur, from = min(T->fetch, count);
+    const int count = T->cur;
+    if (count == 0) return;
+    // what the launch's groups owned by index or claimed through the counter is theirs to hand on; the rest of the list was never looked at
+    const long long taken = (long long)n_groups * chase_claim(count, n_groups) + (long long)T->fetch;
+    const int from = (int)min((long long)count, taken);
     const int *cur = T->parity ? list_b : list_a;
     int *next = T->parity ? out_a : out_b;
     for (int idx = from + blockIdx.x * blockDim.x + threadIdx.x; idx < count; idx += gridDim.x * blockDim.x) next[atomicAdd(&T->next, 1)] = cur[idx];
@@ -1622,6 +1632,7 @@ __global__ __launch_bounds__(kBlock) void xwin_build_k(SellDev P, PackedDev pk, 
     __shared__ unsigned short wpre[kXBitWords];  // exclusive prefix of the word population counts (windows hold <= 4096)
     __shared__ int s_min, s_max, s_part[kBlock];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned long long n_built = 0, n_capped = 0, n_spanned = 0;  // thread 0's tallies: ONE atomic per counter and workgroup at the end
     for (int64_t b = blockIdx.x; b < n_blocks; b += gridDim.x) {
         const int64_t row = b * kXWinRows + tid;
         const bool live = row < P.n;
@@ -1641,9 +1652,10 @@ __global__ __launch_bounds__(kBlock) void xwin_build_k(SellDev P, PackedDev pk, 
             __syncthreads();
             continue;
         }
-        if (tid == 0) atomicAdd(&g_xwin_counters[0], 1ull);
+        ++n_built;
         if (words > bit_words) {
-            if (tid == 0) { wsize[b] = -1; atomicAdd(&g_xwin_counters[2], 1ull); }
+            if (tid == 0) wsize[b] = -1;
+            ++n_spanned;
             __syncthreads();
             continue;
         }
@@ -1669,7 +1681,8 @@ __global__ __launch_bounds__(kBlock) void xwin_build_k(SellDev P, PackedDev pk, 
         const int total = s_part[kBlock - 1];
         if (total > win_cap) {
             __syncthreads();
-            if (tid == 0) { wsize[b] = -1; atomicAdd(&g_xwin_counters[1], 1ull); }
+            if (tid == 0) wsize[b] = -1;
+            ++n_capped;
             __syncthreads();
             continue;
         }
@@ -1704,6 +1717,11 @@ __global__ __launch_bounds__(kBlock) void xwin_build_k(SellDev P, PackedDev pk, 
             }
         }
         __syncthreads();
+    }
+    if (tid == 0) {
+        if (n_built) atomicAdd(&g_xwin_counters[0], n_built);
+        if (n_capped) atomicAdd(&g_xwin_counters[1], n_capped);
+        if (n_spanned) atomicAdd(&g_xwin_counters[2], n_spanned);
     }
 }
 
@@ -2185,7 +2203,7 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
                     if (group == 16) hipLaunchKernelGGL(tail_chase_k<16>, dim3(chase_grid), dim3(kBlock), 0, st, A, choice, tb, ver, flag, T, listA, listB, chase_steps);
                     else if (group == 32) hipLaunchKernelGGL(tail_chase_k<32>, dim3(chase_grid), dim3(kBlock), 0, st, A, choice, tb, ver, flag, T, listA, listB, chase_steps);
                     else hipLaunchKernelGGL(tail_chase_k<64>, dim3(chase_grid), dim3(kBlock), 0, st, A, choice, tb, ver, flag, T, listA, listB, chase_steps);
-                    hipLaunchKernelGGL(chase_carry_k, dim3(64), dim3(kBlock), 0, st, T, (const int *)listA, (const int *)listB, listA, listB);
+                    hipLaunchKernelGGL(chase_carry_k, dim3(64), dim3(kBlock), 0, st, T, (const int *)listA, (const int *)listB, listA, listB, chase_grid * (kBlock / group));
                     hipLaunchKernelGGL(chase_rotate_k, dim3(1), dim3(1), 0, st, T, steps_total);
                 }
                 launches += chase_batch;
