@@ -137,10 +137,11 @@ struct TailCounters {
     int first;     // first round: every row is evaluated, no list
     int finished;  // a round without a change has been seen: the fixed point is certified
     int fetch;     // cascades: next unclaimed entry of the current list (groups claim rows as they become free)
+    int moved;     // cascades, statistics: evaluations that changed their row's partner (all launches of an aggregation)
 };
 
 __global__ void tail_seed_k(TailCounters *T, int n) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) { T->cur = n; T->changed = 0; T->next = 0; T->rounds = 0; T->parity = 1; T->first = 1; T->finished = 0; T->fetch = 0; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { T->cur = n; T->changed = 0; T->next = 0; T->rounds = 0; T->parity = 1; T->first = 1; T->finished = 0; T->fetch = 0; T->moved = 0; }
 }
 
 // One atomicAdd per wavefront instead of one per lane: the lanes that want a slot are counted with a ballot, the
@@ -233,6 +234,11 @@ __device__ __forceinline__ int group_eval_row_g(const MatView &A, const int *__r
     return bj;
 }
 
+// [r04] What the sweep leaves to the cascades is NOT its seams: walking 3 ... 32 adjacent slices per group, and reading the first-taker table
+// past the vector L1, leave the same 2.7 M of 10.24 M rows away from the fixed point (ORC_AMG_TRACE "[amg distance]", scripts/gpu_r04_t.sh).  On
+// the channel the fixed point differs from the arg-min state in a triangle at the end of every grid line — the last row of line j has no
+// downstream neighbour and takes the one above, which displaces the last-but-one row of line j + 1, and so on (scripts/analysis/
+// pairing_structure.py) — chains of up to min(nx, ny) links that hop nx - 1 rows each: no slice-local order resolves them.
 template <int G>
 __global__ __launch_bounds__(kBlock) void agg_sweep_group_k(MatView A, int *__restrict__ choice, int *__restrict__ taken_by, const unsigned char *__restrict__ active,
                                                             unsigned char *__restrict__ active_next, AggCounters *C, int all_active) {
@@ -654,6 +660,7 @@ __global__ __launch_bounds__(kBlock) void tail_chase_k(MatView A, int *choice, u
     const int static_end = n_groups * claim;  // (chase_carry_k computes the same)
     int c_idx = ((int)blockIdx.x * (kBlock / G) + (int)threadIdx.x / G) * claim;  // this group's entries [c_idx, c_idx + c_left)
     int c_left = max(0, min(claim, count - c_idx));
+    int moved = 0;
     while (steps < max_steps) {  // (rows nobody claims before the budgets run out are carried over by chase_carry_k)
         if (c_left == 0) {
             if (static_end >= count) break;  // the static shares were the whole list
@@ -702,6 +709,7 @@ __global__ __launch_bounds__(kBlock) void tail_chase_k(MatView A, int *choice, u
             const int nv = bj;
             int cont = -1, was = 0;
             if (nv != old) {
+                ++moved;
                 const int jj[2] = {old, nv};
                 const ChaseGeom geo(A, jj);  // in flight together with the commit
                 if (lane == 0) st_i(choice + i, nv);
@@ -725,10 +733,10 @@ __global__ __launch_bounds__(kBlock) void tail_chase_k(MatView A, int *choice, u
         for (int e = lane; e < c_left; e += G) next[base + e] = cur[c_idx + e];
     }
     // statistics (evaluations of this launch): one atomic per wavefront
-    int s = lane == 0 ? steps : 0;
+    int s = lane == 0 ? steps : 0, mv = lane == 0 ? moved : 0;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if ((threadIdx.x & 63) == 0 && s) atomicAdd(&T->changed, s);
+    for (int off = 32; off > 0; off >>= 1) { s += __shfl_down(s, off, 64); mv += __shfl_down(mv, off, 64); }
+    if ((threadIdx.x & 63) == 0 && s) { atomicAdd(&T->changed, s); if (mv) atomicAdd(&T->moved, mv); }
 }
 
 // rows of the current list that no group claimed (every budget ran out first) move to the next list
@@ -2100,6 +2108,7 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
             // (8 / 16 / 32 lanes by row length was the first choice: 103 ms over the sweeps of six iterations on one stream; 8 on every
             // level: 90 ms; 4: 101 ms; 16: 98 ms — more slices in flight beat fewer passes per row)
             const int G = group_env >= 0 ? group_env : (avg <= 0. ? 0 : 8);
+            // adjacent slices per group: ORC_AMG_SWEEP_BLOCK (0 = strided); the launch shrinks to the groups that have a piece
             const int gg = grid_for((int64_t)A.P.n_slices * std::max(G, 1));
             if (G == 4) hipLaunchKernelGGL(agg_sweep_group_k<4>, dim3(gg), dim3(kBlock), 0, st, A, choice, taken_by, cur, nxt, C, all_active);
             else if (G == 8) hipLaunchKernelGGL(agg_sweep_group_k<8>, dim3(gg), dim3(kBlock), 0, st, A, choice, taken_by, cur, nxt, C, all_active);
@@ -2122,6 +2131,14 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
         if (rounds > 8 * 1000 * 1000) return set_error(ORC_ERR_BAD_ARGUMENT, "aggregation did not reach its fixed point");
     }
     lap("bulk sweeps");
+    int *dbg_after_sweep = nullptr, *dbg_after_round = nullptr, *dbg_count = nullptr;  // trace only: how far from the fixed point the phases leave the state
+    if (trace_t && n > 0) {
+        ORC_TRY(arena.alloc((size_t)n, &dbg_after_sweep));
+        ORC_TRY(arena.alloc((size_t)n, &dbg_after_round));
+        ORC_TRY(arena.alloc((size_t)2, &dbg_count));
+        ORC_HIP(hipMemcpyAsync(dbg_after_sweep, choice, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, st));
+        ORC_HIP(hipMemcpyAsync(dbg_after_round, choice, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, st));
+    }
     if (sym) {
         // ---- tail phase: exact taken_by once, then row-level rounds
         int *flag, *listA, *listB, *ch_row, *ch_new, *ch_old, *ch_t_old, *ch_t_new;
@@ -2184,6 +2201,7 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
             ORC_TRY(arena.alloc((size_t)64, &steps_total));
             ORC_HIP(hipMemsetAsync(steps_total, 0, sizeof(int), st));
             hipLaunchKernelGGL(chase_convert_k, dim3(g), dim3(kBlock), 0, st, (const int *)taken_by, tb, ver, n);
+            if (dbg_after_round) ORC_HIP(hipMemcpyAsync(dbg_after_round, choice, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, st));
             lap("first lock-step round");
             // lanes per cascade: the narrowest group that covers a typical row in one pass
             const int group_env = getenv("ORC_AMG_CHASE_GROUP") ? atoi(getenv("ORC_AMG_CHASE_GROUP")) : 0;
@@ -2197,7 +2215,13 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
                 const double avg_len = n > 0 ? (double)stored / (double)n : 0.;
                 group = avg_len <= 14. ? 16 : (avg_len <= 28. ? 32 : 64);
             }
-            int launches = 0, first_list = -1;
+            int launches = 0, first_list = -1, list0 = -1;
+            if (trace) {  // the list the first lock-step round left
+                TailCounters h0;
+                ORC_HIP(hipMemcpyAsync(&h0, T, sizeof(h0), hipMemcpyDeviceToHost, st));
+                ORC_HIP(hipStreamSynchronize(st));
+                list0 = h0.cur;
+            }
             for (;;) {
                 for (int b = 0; b < chase_batch; ++b) {
                     if (group == 16) hipLaunchKernelGGL(tail_chase_k<16>, dim3(chase_grid), dim3(kBlock), 0, st, A, choice, tb, ver, flag, T, listA, listB, chase_steps);
@@ -2225,7 +2249,8 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
             if (trace) {
                 int stot = 0;
                 ORC_HIP(hipMemcpy(&stot, steps_total, sizeof(int), hipMemcpyDeviceToHost));
-                fprintf(stderr, "[amg chase n=%lld] launches %d evaluations %d left %d finished %d\n", (long long)n, launches, stot, h.cur, h.finished);
+                fprintf(stderr, "[amg chase n=%lld] launches %d evaluations %d (%d changed their row) first list %d left %d finished %d\n", (long long)n, launches, stot, h.moved,
+                        list0, h.cur, h.finished);
             }
             fin = h.finished != 0;
             bool verified_clean = false;
@@ -2287,6 +2312,15 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
         }
         if (trace && chase_enabled && cert_batches > 0) fprintf(stderr, "[amg certify n=%lld] lock-step rounds %d\n", (long long)n, h.rounds);
         if (cert_batches > 0) rounds += h.rounds;  // (a clean verification pass has counted itself)
+    }
+    if (dbg_count) {
+        int hd[2] = {0, 0};
+        ORC_HIP(hipMemsetAsync(dbg_count, 0, 2 * sizeof(int), st));
+        hipLaunchKernelGGL(count_diff_k, dim3(g), dim3(kBlock), 0, st, (const int *)dbg_after_sweep, (const int *)choice, n, dbg_count);
+        hipLaunchKernelGGL(count_diff_k, dim3(g), dim3(kBlock), 0, st, (const int *)dbg_after_round, (const int *)choice, n, dbg_count + 1);
+        ORC_HIP(hipMemcpyAsync(hd, dbg_count, sizeof(hd), hipMemcpyDeviceToHost, st));
+        ORC_HIP(hipStreamSynchronize(st));
+        fprintf(stderr, "[amg distance n=%lld] rows whose partner differs from the fixed point: %d after the sweeps, %d after the first lock-step round\n", (long long)n, hd[0], hd[1]);
     }
     ORC_HIP(hipMemsetAsync(chooser, 0xff, sizeof(int) * (size_t)n, st));
     hipLaunchKernelGGL(chooser_k, dim3(g), dim3(kBlock), 0, st, choice, chooser, n);
