@@ -102,7 +102,9 @@ struct SliceWalk {
     int64_t begin, end, step;
     __device__ __forceinline__ SliceWalk(int32_t n_slices, int32_t first = 0) {  // slices [first, n_slices)
         const int waves = blockDim.x >> 6;
-        const int wave = threadIdx.x >> 6;
+        // (the wavefront's index is the same in all its lanes; said so explicitly, the slice index, the slice's base and width and the narrow
+        // column image's per-depth bases live in scalar registers and are fetched through the scalar cache instead of by 64-lane vector loads)
+        const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
         if ((gridDim.x & 7) == 0 && gridDim.x >= 8) {
             const int xcd = blockIdx.x & 7, bl = blockIdx.x >> 3, nb = gridDim.x >> 3;
             const int64_t spx = ((int64_t)(n_slices - first) + 7) / 8;
