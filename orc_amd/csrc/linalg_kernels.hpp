@@ -493,7 +493,7 @@ __global__ __launch_bounds__(kBlock) void spmv_xwin_k(MatView A, const double *_
     __shared__ double lds[8];
     __shared__ double xs[kXWinCap];
     if (skip_flags && (skip_flags[0] != 0. || skip_flags[1] != 0.)) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // (scalar: the slice's descriptors go through the scalar cache)
     double r0 = 0., r1 = 0.;
     const int64_t n_blocks = ((int64_t)A.P.n_slices + 3) >> 2;
     int64_t b_begin, b_end, b_step;
