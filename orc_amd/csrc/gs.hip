@@ -316,7 +316,7 @@ __global__ __launch_bounds__(kBlock) void gs_color_sorted_k(const int64_t *__res
                                                             int *__restrict__ status) {
     const int lane = threadIdx.x & 63;
     const int waves = blockDim.x >> 6;
-    for (int sidx = slice_lo + blockIdx.x * waves + (threadIdx.x >> 6); sidx < slice_hi; sidx += gridDim.x * waves) {
+    for (int sidx = slice_lo + blockIdx.x * waves + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); sidx < slice_hi; sidx += gridDim.x * waves) {  // (scalar: see SliceWalk)
         const int64_t slot = (int64_t)sidx * 64 + lane;
         const int i = rowid[slot];
         const int len = i >= 0 ? row_len[slot] : 0;
@@ -754,7 +754,7 @@ __global__ __launch_bounds__(kBlock) void gsx_sweep0_k(SlotMat<S> M, const doubl
     const int lane = threadIdx.x & 63;
     const int waves = blockDim.x >> 6;
     const int first_slot = slice_lo * 64;
-    for (int sidx = slice_lo + blockIdx.x * waves + (threadIdx.x >> 6); sidx < slice_hi; sidx += gridDim.x * waves) {
+    for (int sidx = slice_lo + blockIdx.x * waves + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); sidx < slice_hi; sidx += gridDim.x * waves) {  // (scalar: see SliceWalk)
         const int64_t slot = (int64_t)sidx * 64 + lane;
         const int i = M.rowid[slot];
         const int len = i >= 0 ? M.row_len[slot] : 0;
