@@ -604,7 +604,7 @@ __global__ __launch_bounds__(kBlock) void bicg_xr_k(double *__restrict__ scal, i
                                                     const double *__restrict__ t, double *__restrict__ r, int64_t n,
                                                     double *__restrict__ partials, int guard, const double *__restrict__ fold, int fold_count) {
     __shared__ double lds[8];
-    __shared__ double lds16[16];
+    __shared__ double lds16[32];
     if (guard && scal[S_FROZEN] != 0.) return;
     // the first pairs of every thread are requested before the folds (their round trips overlap)
     const int64_t n2 = n >> 1, stride = (int64_t)gridDim.x * blockDim.x;
@@ -615,8 +615,9 @@ __global__ __launch_bounds__(kBlock) void bicg_xr_k(double *__restrict__ scal, i
     if (i0 < n2) { xv = x2[i0]; pv = p2[i0]; sv = s2[i0]; tv = t2[i0]; }
     double ts, tt;
     if (fold) {  // t.s and t.t from the product's two partial arrays (fold != partials: this kernel writes its own sums)
-        ts = fold_partials_block(fold, fold_count, lds16);
-        tt = fold_partials_block(fold + fold_count, fold_count, lds16);
+        double both[2];
+        fold_partials_multi<2>(fold, fold_count, lds16, both);  // [r04] the two folds' loads in flight together, two barriers instead of four: the same bits
+        ts = both[0]; tt = both[1];
         if (blockIdx.x == 0 && threadIdx.x == 0) { scal[S_TS] = ts; scal[S_TT] = tt; }
     } else {
         ts = scal[S_TS]; tt = scal[S_TT];

@@ -571,27 +571,33 @@ __global__ __launch_bounds__(kBlock) void spmv_xwin_k(MatView A, const double *_
             double acc = 0.;
             if (ws >= 0) {
                 // two chunks in flight: the loads of chunk k0 + 8 are issued before chunk k0 is consumed (with 40 KB of LDS
-                // per workgroup only 16 waves fit a CU, so each has to keep more bytes in flight)
-                if (kDebug != 3 && width > 0) issue(0, c, v);
-                for (int k0 = 0; k0 < width; k0 += 8) {
-                    const bool more = k0 + 8 < width;
-                    if (more) issue(k0 + 8, cn, vn);
+                // per workgroup only 16 waves fit a CU, so each has to keep more bytes in flight).
+                // [r04] ... and they have to STAY in flight: r03's loop copied the second register set into the first at the end of every
+                // pass, and a copy reads its source — `s_waitcnt vmcnt(0)` in front of the copies (listing), i.e. every pass ended by
+                // waiting for the chunk it had just requested.  Now the two register sets take turns (the loop is unrolled by two): a pass
+                // waits for the OLDER chunk only (vmcnt retires in order), the younger one travels while it is multiplied.
+                auto consume = [&](int k0, const int (&cc)[8], const double (&vv)[8]) {
                     double xv[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) xv[u] = xs[c[u]];
+                    for (int u = 0; u < 8; ++u) xv[u] = xs[cc[u]];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
-                        double t = v[u];
+                        double t = vv[u];
                         if (kScaled && A.s1) t = s1 * t;
                         if (kScaled && A.s2) t = s2 * t;
                         const double next = acc + t * xv[u];
                         acc = (k0 + u < len) ? next : acc;
                     }
-                    if (more) {
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) { c[u] = cn[u]; v[u] = vn[u]; }
-                    }
+                };
+                if (kDebug != 3 && width > 0) issue(0, c, v);
+                int k0 = 0;
+                for (; k0 + 8 < width; k0 += 16) {  // at the top: chunk k0 is on its way into (c, v)
+                    issue(k0 + 8, cn, vn);
+                    consume(k0, c, v);
+                    if (k0 + 16 < width) issue(k0 + 16, c, v);
+                    consume(k0 + 8, cn, vn);
                 }
+                if (k0 < width) consume(k0, c, v);
             } else {
                 for (int k0 = 0; k0 < width; k0 += 8) {
                     int cg[8];
