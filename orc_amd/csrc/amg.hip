@@ -1152,7 +1152,7 @@ struct MergeSiblings {
 };
 
 template <int G, int kStop = 0, int S = 1>
-__global__ __launch_bounds__(64) void galerkin_merge_k(MatView A, const int *__restrict__ choice, const int *__restrict__ chooser, int64_t n_coarse,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S == 1 ? 6 : 4))) void galerkin_merge_k(MatView A, const int *__restrict__ choice, const int *__restrict__ chooser, int64_t n_coarse,
                                                         int cap /* power of two >= 2 * candidates */, int *__restrict__ row_len_c,
                                                         const long long *__restrict__ slice_base, const int *__restrict__ intra_off, int *__restrict__ s_col,
                                                         double *__restrict__ s_val, const int *__restrict__ list, const int *__restrict__ list_count,
@@ -1162,12 +1162,14 @@ __global__ __launch_bounds__(64) void galerkin_merge_k(MatView A, const int *__r
     constexpr int kX = S - 1;      // sibling systems
     const int h = cap >> 1;
     const int lane = threadIdx.x & (G - 1), grp = threadIdx.x / G;
-    double *src_val = reinterpret_cast<double *>(smem + (size_t)grp * (size_t)cap * (size_t)(16 + 8 * kX));  // candidates in generation order, later T's values
+    double *src_val = reinterpret_cast<double *>(smem + (size_t)grp * (size_t)cap * (size_t)(12 + 8 * kX));  // candidates in generation order, later T's values
     double *m_val = src_val + h;                          // merged candidates
     int *src_col = reinterpret_cast<int *>(m_val + h);    // ... later T's columns
     int *m_col = src_col + h;
-    int *U = m_col + h;  // [cap] distinct coarse columns, unsorted
-    double *x_src = reinterpret_cast<double *>(U + cap);  // siblings: [kX][h] candidates / T values, then [kX][h] merged candidates
+    // [cap] distinct coarse columns, unsorted: written by step 4, when the merged candidates (last read by step 3) are dead — the list lives
+    // in their values' place [r04: 12 instead of 16 bytes of LDS per list slot]
+    int *U = reinterpret_cast<int *>(m_val);
+    double *x_src = reinterpret_cast<double *>(m_col + h);  // siblings: [kX][h] candidates / T values, then [kX][h] merged candidates
     double *x_m = x_src + (size_t)(kX > 0 ? kX : 1) * h;
     const int n_fine = (int)A.P.n;
     const int64_t total_rows = list ? (int64_t)*list_count : n_coarse;
@@ -2486,13 +2488,17 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
         const int cap = 64 << t;
         int G = tier_group[t];  // narrow rows: two or four coarse rows per wavefront
         // a wavefront's lists must fit the LDS of one workgroup: wider groups (fewer rows per wavefront) where the sibling value sets would not
-        while (G < 64 && (size_t)cap * (size_t)(16 + 8 * n_sib) * (size_t)(64 / G) > (size_t)150 * 1024) G <<= 1;
+        while (G < 64 && (size_t)cap * (size_t)(12 + 8 * n_sib) * (size_t)(64 / G) > (size_t)150 * 1024) G <<= 1;
         const int rows_per_wave = 64 / G;
-        const size_t smem = (size_t)cap * (size_t)(16 + 8 * n_sib) * (size_t)rows_per_wave;
+        const size_t smem = (size_t)cap * (size_t)(12 + 8 * n_sib) * (size_t)rows_per_wave;
         if (smem > (size_t)160 * 1024) return set_error(ORC_ERR_BAD_ARGUMENT, "Galerkin row too long for a shared pass (%d candidates, %d systems)", max_cand, n_sib + 1);
         // 83-88 VGPRs: five wavefronts per SIMD are resident.  Measured (one stream, all tiers of six SIMPLE iterations): 16 per CU 407 ms,
         // 20: 372 ms, 24: 410 ms (the launch no longer fits and its tail runs alone); round 2's kernel at 16: 438 ms
-        static const int merge_waves = getenv("ORC_GALERKIN_WAVES") ? atoi(getenv("ORC_GALERKIN_WAVES")) : 20;
+        // [r04] 80 VGPRs (amdgpu_waves_per_eu(6): 12-24 bytes of scratch per lane) and 12 instead of 16 bytes of LDS per list slot: six wavefronts per
+        // SIMD are resident, 24 per CU (r03: 83-88 VGPRs, five per SIMD; 16 per CU 407 ms over six iterations, 20: 372 ms, 24: 410 ms as the launch
+        // no longer fitted); the shared pass for sibling systems carries three value sets in 128 VGPRs: four per SIMD
+        static const int merge_waves_env = getenv("ORC_GALERKIN_WAVES") ? atoi(getenv("ORC_GALERKIN_WAVES")) : 0;
+        const int merge_waves = merge_waves_env > 0 ? merge_waves_env : (n_sib == 0 ? 24 : 16);
         const int waves_per_cu = (int)std::max<size_t>(1, std::min<size_t>((size_t)merge_waves, (size_t)(150 * 1024) / smem));
         const int g = (int)std::min<int64_t>(((int64_t)htier[t] + rows_per_wave - 1) / rows_per_wave, (int64_t)256 * waves_per_cu);
         const int *tl = tier_list + (int64_t)t * nc, *tc = tier_count + t;
