@@ -2184,7 +2184,16 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
         // spreads them over the whole chip again (unbounded: a few wavefronts with long cascades work alone — 477 ms of
         // cascades per 3.25 iterations against 321 ms at 96; 16: 525 ms, launches dominate)
         const int chase_steps = getenv("ORC_AMG_CHASE_STEPS") ? atoi(getenv("ORC_AMG_CHASE_STEPS")) : 96;
-        const int chase_grid = clamp_partials_grid(getenv("ORC_AMG_CHASE_GRID") ? atoi(getenv("ORC_AMG_CHASE_GRID")) : 2048);
+        // [r04] a launch no larger than what is RESIDENT on an empty chip (68 VGPRs: seven wavefronts per SIMD, 1 792 workgroups of the 2 048 r03
+        // launched): a workgroup that waits for a slot owns a first share of the list (above) whose rows then wait with it — measured on one box,
+        // interleaved: 2 048 workgroups 788.8 / 780.4 ms per SIMPLE iteration, 1 792: 783.2 / 776.2, 1 024: 787.7 / 780.4
+        static const int chase_resident = [] {
+            int per_cu = 0, dev = 0, cus = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, tail_chase_k<16>, kBlock, 0) != hipSuccess || per_cu <= 0) return 2048;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 2048;
+            return std::min(2048, per_cu * cus);
+        }();
+        const int chase_grid = clamp_partials_grid(getenv("ORC_AMG_CHASE_GRID") ? atoi(getenv("ORC_AMG_CHASE_GRID")) : chase_resident);
         const int chase_launches = getenv("ORC_AMG_CHASE_LAUNCHES") ? atoi(getenv("ORC_AMG_CHASE_LAUNCHES")) : 1024;
         const int chase_batch = getenv("ORC_AMG_CHASE_BATCH") ? std::max(1, atoi(getenv("ORC_AMG_CHASE_BATCH"))) : 2;  // launches per host read
         static const bool trace = getenv("ORC_AMG_TRACE") != nullptr;
