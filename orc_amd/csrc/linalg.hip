@@ -1056,20 +1056,28 @@ static int launch_spmv3(const MatView3 &A_in, const double *x3, const Epi3 &epi,
         return ORC_OK;
     }
     if (A.halo) ORC_TRY(A.halo->exchange_interleaved(const_cast<double *>(x3), 3));  // C1: the ghost entries of the three systems in one message per peer
+    // [r04] ORC_SPMV3_LAUNCH = W: W resident workgroups walk the one-system grid's shares (MatView3::vgrid, spmv3_uniform_k) and write ITS partial
+    // sums — the same bits (tests/test_gpu_triple.py).  OFF by default, measured on one box, interleaved: alone the product gains (2 048 workgroups
+    // 517 us, 1 024 walking 2 048 shares 499-507 us: 82 VGPRs let five workgroups live on a CU and the launch's last three per CU ran on a half-empty
+    // chip), but the SIMPLE iteration loses 14 ms (778-784 -> 792-799 ms): beside the set-up kernels of the other streams a product with half the
+    // wavefronts gets less of the memory system, and the lock-step solve is the critical path of that phase.  Read per launch: the tests compare the forms.
+    const int launch_env = getenv("ORC_SPMV3_LAUNCH") ? atoi(getenv("ORC_SPMV3_LAUNCH")) : 0;
+    int g_launch = g;
+    if (launch_env >= 8 && (launch_env & 7) == 0 && launch_env < g && (g & 7) == 0) { A.vgrid = g; g_launch = launch_env; }
     static const int chunk = getenv("ORC_SPMV3_CHUNK") ? atoi(getenv("ORC_SPMV3_CHUNK")) : 4;
-    if (chunk == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 8>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
-    else if (chunk == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 2>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
+    if (chunk == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 8>), dim3(g_launch), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
+    else if (chunk == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 2>), dim3(g_launch), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
     else if (A.mesh_pattern) {
         const bool narrow = A.P.col16 != nullptr, scaled = A.s1 || A.s2;
-        if (narrow && !scaled && A.nt) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4, true, true, false, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
-        else if (narrow && !scaled) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4, true, true, false>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
-        else if (narrow) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4, true, true, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
-        else if (!scaled) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4, true, false, false>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
-    } else if (!(A.s1 || A.s2) && A.P.col16 && A.nt) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4, false, true, false, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
-    else if (!(A.s1 || A.s2) && A.P.col16) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4, false, true, false>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
-    else if (!(A.s1 || A.s2)) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4, false, false, false>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
+        if (narrow && !scaled && A.nt) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4, true, true, false, true>), dim3(g_launch), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
+        else if (narrow && !scaled) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4, true, true, false>), dim3(g_launch), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
+        else if (narrow) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4, true, true, true>), dim3(g_launch), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
+        else if (!scaled) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4, true, false, false>), dim3(g_launch), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4, true>), dim3(g_launch), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
+    } else if (!(A.s1 || A.s2) && A.P.col16 && A.nt) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4, false, true, false, true>), dim3(g_launch), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
+    else if (!(A.s1 || A.s2) && A.P.col16) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4, false, true, false>), dim3(g_launch), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
+    else if (!(A.s1 || A.s2)) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4, false, false, false>), dim3(g_launch), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4>), dim3(g_launch), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
     ORC_HIP(hipGetLastError());
     return ORC_OK;
 }

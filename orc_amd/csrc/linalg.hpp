@@ -139,6 +139,7 @@ struct MatView3 {
     HaloPlan *halo = nullptr;
     // the pieces of a product that overlaps its halo exchange (MatView::slice_lo / slice_hi / part_stride / part_base)
     int32_t slice_lo = 0, slice_hi = -1, part_stride = 0, part_base = 0;
+    int32_t vgrid = 0;  // > 0: the launch walks the shares of a grid of this many workgroups and writes ITS partial sums (launch_spmv3 sets it)
 };
 
 // Owning pattern (built on the host from CSR, e.g. the mesh pattern or a user matrix).

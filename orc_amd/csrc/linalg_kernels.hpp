@@ -100,13 +100,16 @@ __device__ __forceinline__ void fold_partials_multi(const double *__restrict__ p
 // of being fetched by all eight.  Pure speed: any placement gives the same result.
 struct SliceWalk {
     int64_t begin, end, step;
-    __device__ __forceinline__ SliceWalk(int32_t n_slices, int32_t first = 0) {  // slices [first, n_slices)
+    // block / grid: the workgroup this walk belongs to — the launch's own (default) or a VIRTUAL one: a launch of fewer, resident workgroups walks
+    // the shares of a larger grid one after the other and writes that grid's partial sums (spmv3_uniform_k: MatView3::vgrid)
+    __device__ __forceinline__ SliceWalk(int32_t n_slices, int32_t first = 0) : SliceWalk(n_slices, first, (int)blockIdx.x, (int)gridDim.x) {}
+    __device__ __forceinline__ SliceWalk(int32_t n_slices, int32_t first, int block, int grid) {  // slices [first, n_slices)
         const int waves = blockDim.x >> 6;
         // (the wavefront's index is the same in all its lanes; said so explicitly, the slice index, the slice's base and width and the narrow
         // column image's per-depth bases live in scalar registers and are fetched through the scalar cache instead of by 64-lane vector loads)
         const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-        if ((gridDim.x & 7) == 0 && gridDim.x >= 8) {
-            const int xcd = blockIdx.x & 7, bl = blockIdx.x >> 3, nb = gridDim.x >> 3;
+        if ((grid & 7) == 0 && grid >= 8) {
+            const int xcd = block & 7, bl = block >> 3, nb = grid >> 3;
             const int64_t spx = ((int64_t)(n_slices - first) + 7) / 8;
             const int64_t lo = (int64_t)first + (int64_t)xcd * spx;
             int64_t hi = lo + spx;
@@ -115,9 +118,9 @@ struct SliceWalk {
             end = hi;
             step = (int64_t)nb * waves;
         } else {
-            begin = (int64_t)first + (int64_t)blockIdx.x * waves + wave;
+            begin = (int64_t)first + (int64_t)block * waves + wave;
             end = n_slices;
-            step = (int64_t)gridDim.x * waves;
+            step = (int64_t)grid * waves;
         }
     }
 };
@@ -309,11 +312,16 @@ template <class Epi3, int kChunk = 4, bool kMesh = false, bool kNarrow = false, 
 __global__ __launch_bounds__(kBlock) void spmv3_uniform_k(MatView3 A, const double *__restrict__ x3, Epi3 epi, double *__restrict__ partials) {
     __shared__ double lds[8];
     const int lane = threadIdx.x & 63;
-    double red[3][2] = {{0., 0.}, {0., 0.}, {0., 0.}};
     const Vec3d *__restrict__ xv3 = reinterpret_cast<const Vec3d *>(x3);
     const Vec3d *__restrict__ s1v = reinterpret_cast<const Vec3d *>(A.s1);
     const Vec3d *__restrict__ s2v = reinterpret_cast<const Vec3d *>(A.s2);
-    SliceWalk w(A.slice_hi >= 0 ? A.slice_hi : A.P.n_slices, A.slice_lo);  // a slice range when the product overlaps its halo exchange (launch_spmv3)
+    // [r04] vgrid: the grid whose shares and partial sums this launch produces (launch_spmv3, ORC_SPMV3_LAUNCH: fewer, resident workgroups walk the
+    // shares of the one-system product's grid, whose partial sums the three-system product must reproduce bit for bit — same rows per share, same
+    // order, same sums; measured, off by default: see launch_spmv3).
+    const int vgrid = A.vgrid > 0 ? A.vgrid : (int)gridDim.x;
+    for (int vb = blockIdx.x; vb < vgrid; vb += gridDim.x) {
+    double red[3][2] = {{0., 0.}, {0., 0.}, {0., 0.}};
+    SliceWalk w(A.slice_hi >= 0 ? A.slice_hi : A.P.n_slices, A.slice_lo, vb, vgrid);  // a slice range when the product overlaps its halo exchange (launch_spmv3)
     for (int64_t slice = w.begin; slice < w.end; slice += w.step) {
         const int64_t row = slice * 64 + lane;
         const int64_t base = A.P.slice_ptr[slice];
@@ -366,8 +374,9 @@ __global__ __launch_bounds__(kBlock) void spmv3_uniform_k(MatView3 A, const doub
 #pragma unroll
         for (int q = 0; q < Epi3::kReductions; ++q) {
             const double t = block_sum(red[s][q], lds);
-            if (threadIdx.x == 0) partials[(size_t)(s * Epi3::kReductions + q) * (A.part_stride > 0 ? A.part_stride : (int)gridDim.x) + A.part_base + blockIdx.x] = t;
+            if (threadIdx.x == 0) partials[(size_t)(s * Epi3::kReductions + q) * (A.part_stride > 0 ? A.part_stride : vgrid) + A.part_base + vb] = t;
         }
+    }
     }
 }
 
