@@ -1636,14 +1636,22 @@ constexpr int kXBitWords = 8192;  // 262144 columns of span
 // the blocks through both branches and compare with the oracle (tests/test_gpu_window_fallback.py).  g_xwin_counters: blocks
 // built / without a window because of the cap / because of the span, since the last reset (orc_debug_xwin_counters).
 __device__ unsigned long long g_xwin_counters[3];
+// [r04] Two passes: the first with a bitmap of kXBitWordsSmall words (25 KB of LDS: six workgroups per CU instead of three) takes every block whose
+// columns span at most 131 072 and marks the others pending (wsize = -2); the second, with the full bitmap, runs only if any block is pending and
+// looks at those only.  (ORC_AMG_TRACE "[amg windows]": with 2 048 words half of the channel's level-2 / 3 blocks were left to the second pass.)
+constexpr int kXBitWordsSmall = 4096;
+template <int kWords, bool kSecond>
 __global__ __launch_bounds__(kBlock) void xwin_build_k(SellDev P, PackedDev pk, int *__restrict__ wcol, int *__restrict__ wsize,
-                                                       unsigned short *__restrict__ lidx, int64_t n_blocks, int win_cap, int bit_words) {
-    __shared__ unsigned bits[kXBitWords];
-    __shared__ unsigned short wpre[kXBitWords];  // exclusive prefix of the word population counts (windows hold <= 4096)
+                                                       unsigned short *__restrict__ lidx, int64_t n_blocks, int win_cap, int bit_words, int pass_words,
+                                                       int *__restrict__ pending /* blocks the first pass left to the second */) {
+    if (kSecond && *pending == 0) return;
+    __shared__ unsigned bits[kWords];
+    __shared__ unsigned short wpre[kWords];  // exclusive prefix of the word population counts (windows hold <= 4096)
     __shared__ int s_min, s_max, s_part[kBlock];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     unsigned long long n_built = 0, n_capped = 0, n_spanned = 0;  // thread 0's tallies: ONE atomic per counter and workgroup at the end
     for (int64_t b = blockIdx.x; b < n_blocks; b += gridDim.x) {
+        if (kSecond && wsize[b] != -2) continue;  // workgroup-uniform: done by the first pass
         const int64_t row = b * kXWinRows + tid;
         const bool live = row < P.n;
         const int len = live ? P.row_len[row] : 0;
@@ -1662,8 +1670,13 @@ __global__ __launch_bounds__(kBlock) void xwin_build_k(SellDev P, PackedDev pk, 
             __syncthreads();
             continue;
         }
+        if (!kSecond && words <= bit_words && words > pass_words) {  // the full bitmap's business (pass_words <= kWords: ORC_XWIN_SMALL_BITWORDS, a test hook)
+            if (tid == 0) { wsize[b] = -2; atomicAdd(pending, 1); }
+            __syncthreads();
+            continue;
+        }
         ++n_built;
-        if (words > bit_words) {
+        if (words > bit_words || words > kWords) {
             if (tid == 0) wsize[b] = -1;
             ++n_spanned;
             __syncthreads();
@@ -2660,7 +2673,21 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
         ORC_TRY(arena.alloc((size_t)packed_total, &lidx));
         const int win_cap = getenv("ORC_XWIN_CAP") ? std::max(1, std::min(kXWinCap, atoi(getenv("ORC_XWIN_CAP")))) : kXWinCap;  // (per call: test hook)
         const int bit_words = getenv("ORC_XWIN_BITWORDS") ? std::max(1, std::min(kXBitWords, atoi(getenv("ORC_XWIN_BITWORDS")))) : kXBitWords;
-        hipLaunchKernelGGL(xwin_build_k, dim3((unsigned)std::min<int64_t>(n_blocks, 2048)), dim3(kBlock), 0, st, Pc, L.pk, wcol, wsize, lidx, n_blocks, win_cap, bit_words);
+        const int small_words = getenv("ORC_XWIN_SMALL_BITWORDS") ? std::max(1, std::min(kXBitWordsSmall, atoi(getenv("ORC_XWIN_SMALL_BITWORDS")))) : kXBitWordsSmall;
+        int *pending;
+        ORC_TRY(tmp.alloc((size_t)1, &pending));
+        ORC_HIP(hipMemsetAsync(pending, 0, sizeof(int), st));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(xwin_build_k<kXBitWordsSmall, false>), dim3((unsigned)std::min<int64_t>(n_blocks, 2048)), dim3(kBlock), 0, st, Pc, L.pk, wcol, wsize, lidx,
+                           n_blocks, win_cap, bit_words, small_words, pending);
+        if (bit_words > small_words)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(xwin_build_k<kXBitWords, true>), dim3((unsigned)std::min<int64_t>(n_blocks, 2048)), dim3(kBlock), 0, st, Pc, L.pk, wcol, wsize, lidx,
+                               n_blocks, win_cap, bit_words, kXBitWords, pending);
+        if (trace_t) {
+            int hp = 0;
+            ORC_HIP(hipMemcpyAsync(&hp, pending, sizeof(int), hipMemcpyDeviceToHost, st));
+            ORC_HIP(hipStreamSynchronize(st));
+            fprintf(stderr, "[amg windows n=%lld] %lld blocks, %d left to the full bitmap\n", (long long)nc, (long long)n_blocks, hp);
+        }
         ORC_HIP(hipGetLastError());
         L.xw.wcol = wcol; L.xw.wsize = wsize; L.xw.lidx = lidx;
         for (int x = 0; x < n_sib; ++x) {  // same structure, own values

@@ -37,6 +37,9 @@ def _bits(x):
 
 @pytest.mark.parametrize("cap,bitwords,expect", [
     (None, None, "all"),        # every block has its window (the test-size default)
+    (None, -100, "all"),        # [r04] the windows are built in two passes (small bitmap first, the full one for wider blocks): a first pass of 100 words
+                                # (3 200 columns of span) leaves part of the blocks to the second — same windows, same counters, same products
+    (None, -1, "all"),          # ... and a first pass that takes nothing
     (2000, None, "some_cap"),   # windows of 2 000 entries: 21 of the 44 blocks fall back (their windows hold 1 000 - 2 600), the others keep theirs
     (300, None, "most_cap"),    # next to none fits
     (None, 200, "some_span"),   # bitmap of 200 words = 6 400 columns of span: 6 of level 2's 30 blocks take the span branch
@@ -47,7 +50,9 @@ def test_coarse_products_bit_exact_through_every_window_branch(gpu, oracle, monk
     levels = _levels((64, 40, 12))
     if cap is not None:
         monkeypatch.setenv("ORC_XWIN_CAP", str(cap))
-    if bitwords is not None:
+    if bitwords is not None and bitwords < 0:
+        monkeypatch.setenv("ORC_XWIN_SMALL_BITWORDS", str(-bitwords))
+    elif bitwords is not None:
         monkeypatch.setenv("ORC_XWIN_BITWORDS", str(bitwords))
     seen_mirror = 0
     tot = [0, 0, 0]
