@@ -1603,6 +1603,63 @@ __global__ __launch_bounds__(kBlock) void slice_sizes_k(const int *__restrict__ 
         if (lane == 0) { w_sell[s] = (int64_t)mx * 64; w_pk[s] = ((int64_t)sum + 15) & ~(int64_t)15; }
     }
 }
+// [r04] The same scans over the whole chip: one workgroup walking 80 000 slice totals took 0.1-0.2 ms (its threads' contiguous shares are
+// 64 different cache lines per load instruction) — on the set-up's dependent chain, in front of a host read, six times per hierarchy.  Three
+// small launches instead: per-chunk sums (coalesced), a scan of the <= kScanBlocks sums, per-chunk scans from their bases.  Integer sums: exact.
+constexpr int kScanBlocks = 128;
+__global__ __launch_bounds__(kScanThreads) void scan_part_k(const long long *__restrict__ in_a, const long long *__restrict__ in_b, int64_t n, int64_t chunk,
+                                                            long long *__restrict__ part /* [2][kScanBlocks] sums, then [2] totals */) {
+    __shared__ long long buf[kScanThreads];
+    const int64_t lo = (int64_t)blockIdx.x * chunk, hi = std::min<int64_t>(n, lo + chunk);
+    long long sa = 0, sb = 0;
+    for (int64_t e = lo + threadIdx.x; e < hi; e += kScanThreads) { sa += in_a[e]; if (in_b) sb += in_b[e]; }
+    long long ta, tb;
+    (void)block_excl_scan(sa, buf, ta);
+    (void)block_excl_scan(sb, buf, tb);
+    if (threadIdx.x == 0) { part[blockIdx.x] = ta; part[kScanBlocks + blockIdx.x] = tb; }
+}
+__global__ __launch_bounds__(kScanThreads) void scan_mid_k(long long *__restrict__ part, int n_blocks) {
+    __shared__ long long buf[kScanThreads];
+    const int t = threadIdx.x;
+    const long long va = t < n_blocks ? part[t] : 0, vb = t < n_blocks ? part[kScanBlocks + t] : 0;
+    long long ta, tb;
+    const long long ra = block_excl_scan(va, buf, ta);
+    const long long rb = block_excl_scan(vb, buf, tb);
+    if (t < n_blocks) { part[t] = ra; part[kScanBlocks + t] = rb; }
+    if (t == 0) { part[2 * kScanBlocks] = ta; part[2 * kScanBlocks + 1] = tb; }
+}
+__global__ __launch_bounds__(kScanThreads) void scan_write_k(const long long *__restrict__ in_a, const long long *__restrict__ in_b, int64_t n, int64_t chunk,
+                                                             const long long *__restrict__ part, long long *__restrict__ out_a, long long *__restrict__ out_b,
+                                                             int write_totals /* out[n] = total */) {
+    __shared__ long long buf[kScanThreads];
+    const int64_t lo = (int64_t)blockIdx.x * chunk, hi = std::min<int64_t>(n, lo + chunk);
+    long long base_a = part[blockIdx.x], base_b = part[kScanBlocks + blockIdx.x];
+    for (int64_t t0 = lo; t0 < hi; t0 += kScanThreads) {  // (workgroup-uniform trip count)
+        const int64_t e = t0 + threadIdx.x;
+        const long long va = e < hi ? in_a[e] : 0, vb = (in_b && e < hi) ? in_b[e] : 0;
+        long long ta, tb = 0;
+        const long long ra = block_excl_scan(va, buf, ta);
+        long long rb = 0;
+        if (in_b) rb = block_excl_scan(vb, buf, tb);
+        if (e < hi) { out_a[e] = base_a + ra; if (in_b) out_b[e] = base_b + rb; }
+        base_a += ta;
+        base_b += tb;
+    }
+    if (write_totals && blockIdx.x == 0 && threadIdx.x == 0) { out_a[n] = part[2 * kScanBlocks]; if (in_b) out_b[n] = part[2 * kScanBlocks + 1]; }
+}
+// out_a (and out_b) = exclusive prefix sums of in_a (in_b; null: one table); write_totals: out[n] = the sum.  `part`: 2 * kScanBlocks + 2 words.
+static int scan_excl_dev(const long long *in_a, const long long *in_b, int64_t n, long long *out_a, long long *out_b, bool write_totals, long long *part, hipStream_t st) {
+    const int64_t n1 = std::max<int64_t>(n, 1);
+    int64_t chunk = (n1 + kScanBlocks - 1) / kScanBlocks;
+    chunk = ((chunk + kScanThreads - 1) / kScanThreads) * kScanThreads;
+    const int n_blocks = (int)((n1 + chunk - 1) / chunk);
+    hipLaunchKernelGGL(scan_part_k, dim3(n_blocks), dim3(kScanThreads), 0, st, in_a, in_b, n, chunk, part);
+    hipLaunchKernelGGL(scan_mid_k, dim3(1), dim3(kScanThreads), 0, st, part, n_blocks);
+    hipLaunchKernelGGL(scan_write_k, dim3(n_blocks), dim3(kScanThreads), 0, st, in_a, in_b, n, chunk, (const long long *)part, out_a, out_b, write_totals ? 1 : 0);
+    ORC_HIP(hipGetLastError());
+    return ORC_OK;
+}
+
 // exclusive scans of two tables at once, totals in out[n]; contiguous shares per thread as in scan_i64_k
 __global__ __launch_bounds__(kScanThreads) void scan2_i64_k(const int64_t *__restrict__ in_a, const int64_t *__restrict__ in_b, int n, int64_t *__restrict__ out_a,
                                                     int64_t *__restrict__ out_b) {
@@ -2463,7 +2520,9 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
     const int64_t bound_grid = std::max<int64_t>(std::min<int64_t>(std::max<int64_t>(n_slices, 1), 8192), ((int64_t)n_slices + kBoundIters - 1) / kBoundIters);
     hipLaunchKernelGGL(galerkin_bound_k, dim3((unsigned)bound_grid), dim3(64), 0, st, A.P, choice, nc, flags, counters + 1, intra_off,
                        slice_tot, tier_count, tier_list, use_sort ? 1 : 0);
-    hipLaunchKernelGGL(scan_i64_k, dim3(1), dim3(kScanThreads), 0, st, slice_tot, (int64_t)n_slices, slice_base);
+    long long *scan_part;
+    ORC_TRY(tmp.alloc((size_t)2 * kScanBlocks + 2, &scan_part));
+    ORC_TRY(scan_excl_dev(slice_tot, nullptr, (int64_t)n_slices, slice_base, nullptr, false, scan_part, st));
     int hflags[4];
     unsigned long long hcount[2];
     ORC_HIP(hipMemcpyAsync(hflags, flags, sizeof(hflags), hipMemcpyDeviceToHost, st));
@@ -2561,7 +2620,9 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
     ORC_TRY(tmp.alloc((size_t)n_slices + 1, &w_sell));
     ORC_TRY(tmp.alloc((size_t)n_slices + 1, &w_pk));
     hipLaunchKernelGGL(slice_sizes_k, dim3((unsigned)std::min<int64_t>(((int64_t)n_slices + 3) / 4, 4096)), dim3(kBlock), 0, st, row_len, nc, n_slices, w_sell, w_pk);
-    hipLaunchKernelGGL(scan2_i64_k, dim3(1), dim3(kScanThreads), 0, st, (const int64_t *)w_sell, (const int64_t *)w_pk, n_slices, slice_ptr, pk_ptr);
+    static_assert(sizeof(long long) == sizeof(int64_t), "64-bit tables");
+    ORC_TRY(scan_excl_dev(reinterpret_cast<const long long *>(w_sell), reinterpret_cast<const long long *>(w_pk), (int64_t)n_slices, reinterpret_cast<long long *>(slice_ptr),
+                          reinterpret_cast<long long *>(pk_ptr), true, scan_part, st));
     ORC_HIP(hipGetLastError());
     int64_t padded = 0, packed_total = 0;
     ORC_HIP(hipMemcpyAsync(&packed_total, pk_ptr + n_slices, sizeof(int64_t), hipMemcpyDeviceToHost, st));
