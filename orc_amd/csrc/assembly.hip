@@ -585,7 +585,22 @@ __global__ __launch_bounds__(kBlock) void momentum_k(MeshDev M, SellDev P, Momen
     const int64_t n = M.n_cells;
     double pe_sum = 0., pe_min = INFINITY, pe_max = -INFINITY;
     const bool tvd = A.momentum >= ORC_MOMENTUM_TVD_LUD;
-    GRID_STRIDE(idx, kInplace ? I.count : M.n_own) {
+    // [r04] Cells in blocks of one workgroup; XCD g (workgroups g, g + 8, ...) walks a contiguous eighth of the blocks.  With the plain grid
+    // stride neighbouring blocks — the two cells of every y- and z-face — sit on different XCDs, each XCD's L2 fetches the face's geometry, flux
+    // and the neighbour's fields for itself, and the kernel moved 3.2x its algorithmic bytes (18.3 GB against 5.8 GB).
+    const int64_t n_items = kInplace ? I.count : M.n_own;
+    const int64_t n_blk = (n_items + blockDim.x - 1) / blockDim.x;
+    int64_t vb = blockIdx.x, vb_end = n_blk, vb_step = gridDim.x;
+    if (!kInplace && (gridDim.x & 7) == 0 && gridDim.x >= 8) {
+        const int64_t per = (n_blk + 7) / 8;
+        const int xcd = blockIdx.x & 7;
+        vb = (int64_t)xcd * per + (blockIdx.x >> 3);
+        vb_end = (int64_t)(xcd + 1) * per < n_blk ? (int64_t)(xcd + 1) * per : n_blk;
+        vb_step = gridDim.x >> 3;
+    }
+    for (; vb < vb_end; vb += vb_step) {
+        const int64_t idx = vb * blockDim.x + threadIdx.x;
+        if (idx >= n_items) break;
         const int64_t c = kInplace ? (int64_t)I.cells[idx] : idx;
         V3 s_u = mk(0., 0., 0.);  // get_momentum_source_term (solver.rs:698-701)
         const int dpos = P.diag_pos[c];
