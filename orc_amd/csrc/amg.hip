@@ -1492,8 +1492,12 @@ __global__ __launch_bounds__(64) void galerkin_bound_k(SellDev P, const int *__r
     int cnt[kGalerkinTiers];
 #pragma unroll
     for (int t = 0; t < kGalerkinTiers; ++t) cnt[t] = 0;
+    // (a wavefront takes ADJACENT slices, so that the tier lists come out in row order: neighbouring list entries — what concurrent merge
+    // wavefronts work on — are neighbouring coarse rows)
+    const int64_t per_wave = (n_slices + gridDim.x - 1) / gridDim.x;  // <= kBoundIters by the launch's size
+    const int64_t s_lo = (int64_t)blockIdx.x * per_wave, s_hi = s_lo + per_wave < n_slices ? s_lo + per_wave : n_slices;
     int it = 0;
-    for (int64_t s = blockIdx.x; s < n_slices && it < kBoundIters; s += gridDim.x, ++it) {
+    for (int64_t s = s_lo; s < s_hi && it < kBoundIters; ++s, ++it) {
         const int64_t I = s * 64 + lane;
         int c = 0;
         if (I < n_coarse) {
@@ -1528,7 +1532,7 @@ __global__ __launch_bounds__(64) void galerkin_bound_k(SellDev P, const int *__r
         }
     }
     it = 0;
-    for (int64_t s = blockIdx.x; s < n_slices && it < kBoundIters; s += gridDim.x, ++it) {
+    for (int64_t s = s_lo; s < s_hi && it < kBoundIters; ++s, ++it) {
         const int64_t I = s * 64 + lane;
         const int tier = tiers[it][lane];
 #pragma unroll
