@@ -1474,7 +1474,7 @@ __global__ __launch_bounds__(64) void galerkin_pack_fused_k(SellDev Pc, const lo
 
 // Per coarse row: candidate count c = sum of the lengths of its (<= 4) fine rows.  2c bounds the row's coarse
 // entries (every candidate spawns <= 2 products), so the scratch offset of row I is the exclusive prefix sum of 2c:
-// computed here per 64-row slice (wave scan) + slice totals, finished by scan_i64_k.  No allocator atomics.
+// computed here per 64-row slice (wave scan) + slice totals, finished by scan_excl_dev.  No allocator atomics.
 constexpr int kGalerkinTiers = 7;  // LDS list capacities 64 << t, t = 0..6 (2 KB .. 128 KB per wavefront)
 // [r04] The tier lists are appended to behind one counter per tier, and same-address atomics retire at 11.4 ns per wave-instruction
 // (scripts/microbench/atomic_rate.hip): one append per slice and tier was the kernel — 80 000 slices on the first level, 0.74-1.06 ms of a
@@ -1551,11 +1551,9 @@ __global__ __launch_bounds__(64) void galerkin_bound_k(SellDev P, const int *__r
     if (lane == 0) { atomicMax(out_max, mx); atomicAdd(out_sum, sm); }
 }
 
-// exclusive scan of n int64 values by one workgroup (n = number of slices: tens of thousands)
-// [r03] every thread owns a contiguous share: it sums it, the workgroup's sums are scanned in LDS, it writes its share's running
-// sums — three round trips of independent loads instead of one per 1024-element chunk behind twenty barriers (80 chunks at 5 M
-// coarse rows).  And 256 threads, not 1024: beside the products of another stream a 16-wavefront workgroup waits for a CU with
-// four free slots on every SIMD (100 us alone, 0.6-1.2 ms in the concurrent schedule, most of it before its first instruction).
+// exclusive scan of one value per thread across a workgroup of kScanThreads (the building block of scan_excl_dev below).  256 threads, not
+// 1024: beside the products of another stream a 16-wavefront workgroup waits for a CU with four free slots on every SIMD (100 us alone,
+// 0.6-1.2 ms in the concurrent schedule, most of it before its first instruction).
 constexpr int kScanThreads = 256;
 __device__ __forceinline__ long long block_excl_scan(long long v, long long *buf /*[kScanThreads]*/, long long &total) {
     const int t = threadIdx.x;
@@ -1572,24 +1570,10 @@ __device__ __forceinline__ long long block_excl_scan(long long v, long long *buf
     __syncthreads();
     return r;
 }
-__global__ __launch_bounds__(kScanThreads) void scan_i64_k(const long long *__restrict__ in, int64_t n, long long *__restrict__ out) {
-    __shared__ long long buf[kScanThreads];
-    const int64_t per = (n + kScanThreads - 1) / kScanThreads;
-    const int64_t lo = std::min<int64_t>(n, (int64_t)threadIdx.x * per), hi = std::min<int64_t>(n, lo + per);
-    long long s = 0;
-    for (int64_t e = lo; e < hi; ++e) s += in[e];
-    long long total;
-    long long run = block_excl_scan(s, buf, total);
-    for (int64_t e = lo; e < hi; ++e) {
-        const long long v = in[e];
-        out[e] = run;
-        run += v;
-    }
-}
 
 // slice widths -> slice_ptr and packed sizes -> pk_ptr.
 // One wavefront per slice reduces its 64 row lengths (SELL width * 64 and the packed size rounded up to 16 elements =
-// 128 bytes), then ONE workgroup scans both tables (a single workgroup reading all n row lengths itself took 0.9 + 1.4 ms
+// 128 bytes), then both tables are scanned (scan_excl_dev; a single workgroup reading all n row lengths itself took 0.9 + 1.4 ms
 // per level at 5 M rows).
 __global__ __launch_bounds__(kBlock) void slice_sizes_k(const int *__restrict__ row_len, int64_t n, int n_slices, int64_t *__restrict__ w_sell,
                                                         int64_t *__restrict__ w_pk) {
@@ -1664,26 +1648,6 @@ static int scan_excl_dev(const long long *in_a, const long long *in_b, int64_t n
     return ORC_OK;
 }
 
-// exclusive scans of two tables at once, totals in out[n]; contiguous shares per thread as in scan_i64_k
-__global__ __launch_bounds__(kScanThreads) void scan2_i64_k(const int64_t *__restrict__ in_a, const int64_t *__restrict__ in_b, int n, int64_t *__restrict__ out_a,
-                                                    int64_t *__restrict__ out_b) {
-    __shared__ long long buf[kScanThreads];
-    const int per = (n + kScanThreads - 1) / kScanThreads;
-    const int lo = min(n, (int)threadIdx.x * per), hi = min(n, lo + per);
-    long long sa = 0, sb = 0;
-    for (int e = lo; e < hi; ++e) { sa += (long long)in_a[e]; sb += (long long)in_b[e]; }
-    long long ta, tb;
-    long long ra = block_excl_scan(sa, buf, ta);
-    long long rb = block_excl_scan(sb, buf, tb);
-    for (int e = lo; e < hi; ++e) {
-        const long long va = (long long)in_a[e], vb = (long long)in_b[e];
-        out_a[e] = (int64_t)ra;
-        out_b[e] = (int64_t)rb;
-        ra += va;
-        rb += vb;
-    }
-    if (threadIdx.x == 0) { out_a[n] = (int64_t)ta; out_b[n] = (int64_t)tb; }
-}
 
 // ---- packed mirror of the coarse operator (PackedDev, linalg.hpp): what the level's ~200 products stream
 // ---- LDS x windows of the packed mirror (XWinDev, linalg.hpp): per block of 256 rows the ascending list of distinct
