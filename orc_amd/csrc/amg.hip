@@ -641,7 +641,7 @@ __device__ __forceinline__ void chase_touch2(const MatView &A, const int *choice
 __device__ __forceinline__ int chase_claim(int count, int n_groups) { return max(1, min(16, count / (2 * n_groups))); }
 
 template <int G>
-__global__ __launch_bounds__(kBlock) void tail_chase_k(MatView A, int *choice, unsigned long long *tb, int *ver, int *flag, TailCounters *T, int *list_a,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8))) void tail_chase_k(MatView A, int *choice, unsigned long long *tb, int *ver, int *flag, TailCounters *T, int *list_a,
                                                        int *list_b, int max_steps) {
     const int count = T->cur;
     if (T->finished || count == 0) return;
@@ -2222,9 +2222,10 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
         // spreads them over the whole chip again (unbounded: a few wavefronts with long cascades work alone — 477 ms of
         // cascades per 3.25 iterations against 321 ms at 96; 16: 525 ms, launches dominate)
         const int chase_steps = getenv("ORC_AMG_CHASE_STEPS") ? atoi(getenv("ORC_AMG_CHASE_STEPS")) : 96;
-        // [r04] a launch no larger than what is RESIDENT on an empty chip (68 VGPRs: seven wavefronts per SIMD, 1 792 workgroups of the 2 048 r03
-        // launched): a workgroup that waits for a slot owns a first share of the list (above) whose rows then wait with it — measured on one box,
-        // interleaved: 2 048 workgroups 788.8 / 780.4 ms per SIMPLE iteration, 1 792: 783.2 / 776.2, 1 024: 787.7 / 780.4
+        // [r04] a launch no larger than what is RESIDENT on an empty chip: a workgroup that waits for a slot owns a first share of the list (above)
+        // whose rows then wait with it.  At 68 VGPRs (seven wavefronts per SIMD) that was 1 792 workgroups of the 2 048 r03 launched — one box,
+        // interleaved: 2 048 workgroups 788.8 / 780.4 ms per SIMPLE iteration, 1 792: 783.2 / 776.2, 1 024: 787.7 / 780.4 —; the kernel is now held
+        // at 64 VGPRs (amdgpu_waves_per_eu(8): 16 bytes of scratch per lane), eight per SIMD, all 2 048 resident: 777.5 / 778.0 -> 776.3 / 771.7
         static const int chase_resident = [] {
             int per_cu = 0, dev = 0, cus = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, tail_chase_k<16>, kBlock, 0) != hipSuccess || per_cu <= 0) return 2048;
