@@ -2929,9 +2929,10 @@ int multigrid_prepare_dev(const MatView &A_in, int preconditioner, Arena &arena,
     }
     MatView views[4];
     views[0] = A_in;
-    // [r04] level 0 CAN get a row-contiguous mirror too (its pattern half is the mesh pattern's CSR form, built at mesh creation when
-    // ORC_AMG_L0_MIRROR=1; the values are exported here, one coalesced-read pass): the aggregation and the first Galerkin product walk single
-    // rows, and in SELL every entry of a row is a cache line of its own.  Measured: no gain in any phase, so it is off by default.
+    // [r04] level 0 gets a row-contiguous mirror too (its pattern half is the mesh pattern's CSR form, built at mesh creation unless
+    // ORC_AMG_L0_MIRROR=0; the values are exported here, one coalesced-read pass): the aggregation and the first Galerkin product walk single
+    // rows, and in SELL every entry of a row is a cache line of its own.  No gain on one stream, -10 ... -14 ms in the concurrent iteration
+    // (sell_from_csr_host).
     if (!views[0].rows.col && A_in.P.rows_col && A_in.P.rows_base && A_in.val && A_in.P.csr_row_ptr && A_in.P.nnz > 0) {
         const char *e = getenv("ORC_AMG_L0_MIRROR");  // (per call: the tests compare the forms)
         if (!(e && atoi(e) == 0)) {

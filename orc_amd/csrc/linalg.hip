@@ -258,9 +258,11 @@ int sell_from_csr_host(int64_t n, int64_t ncols, const int64_t *row_ptr, const i
     ORC_TRY(out.diag_pos.upload(diag.data(), (size_t)n));
     ORC_TRY(out.csr_row_ptr.upload(row_ptr, (size_t)n + 1));
     // the pattern half of the row-contiguous mirror: CSR itself, addressed per slice (SellDev::rows_*)
-    // (measured at 10.24 M cells, r04: not a millisecond in any set-up phase, 2.8 GB more — the walks of 64 consecutive rows share their SELL
-    // lines and L2 serves them; OFF by default, ORC_AMG_L0_MIRROR=1 builds it)
-    static const bool l0_mirror = getenv("ORC_AMG_L0_MIRROR") && atoi(getenv("ORC_AMG_L0_MIRROR")) != 0;
+    // (r04, measured twice at 10.24 M cells.  First half of the round: not a millisecond in any set-up phase on one stream — the walks are
+    // latency-bound either way — and 2.8 GB more: off.  End of the round, with the set-up's counters and launches out of the way, in the CONCURRENT
+    // iteration: 788.3 / 780.9 -> 774.0 / 771.4 ms on one box — a row is 2 cache lines instead of 15, and the fine level's sweeps and cascades
+    // stop taking ~150 GB per iteration from the products beside them.  ON by default; ORC_AMG_L0_MIRROR=0 leaves it out.)
+    static const bool l0_mirror = !(getenv("ORC_AMG_L0_MIRROR") && atoi(getenv("ORC_AMG_L0_MIRROR")) == 0);
     if (l0_mirror && n > 0 && nnz > 0 && nnz < ((int64_t)1 << 31)) {
         std::vector<long long> rb((size_t)n_slices);
         std::vector<int32_t> ri((size_t)n), rc((size_t)nnz);

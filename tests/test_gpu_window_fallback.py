@@ -141,7 +141,7 @@ def test_certification_rounds_change_nothing(gpu):
 
 
 def test_level0_row_mirror_does_not_change_a_bit(gpu, monkeypatch):
-    """[r04] ORC_AMG_L0_MIRROR=1 (off by default: measured, no gain): the set-up walks single rows of the level-0 matrices through a
+    """[r04] ORC_AMG_L0_MIRROR (on by default since the end of round 4; 0: off): the set-up walks single rows of the level-0 matrices through a
     row-contiguous mirror (the mesh pattern's CSR form + values exported per solve) instead of the SELL image.  Same entries in the same order:
     three default-stack SIMPLE iterations with and without it, lock-step and per-system momentum solves — identical bits.  (The pattern half is
     built at mesh creation, so the switch is set before the first mesh of this test; run in a process whose earlier meshes lack it the test still
