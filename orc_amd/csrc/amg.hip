@@ -82,6 +82,53 @@ __global__ void agg_init_k(MatView A, int *__restrict__ choice, unsigned char *_
     }
 }
 
+// ---- preference lists [r04] ------------------------------------------------------------------------------------------
+// A row's decision is "the most negative entry whose column no earlier row holds" — the FIRST free column in the row's order of preference
+// (value ascending, position ascending: the strict <, first-wins scan of linear_algebra.rs:37-52).  That order does not change while the pairing is
+// sought, so the pass that computes the starting state (the unconstrained arg-min = the first preference) keeps the row's EIGHT most preferred
+// columns: prefs[8 i .. 8 i + 7] (-1 = fewer; bit 30 of entry 7 = the row has more candidates than listed).  An evaluation then reads one 32-byte
+// line and probes <= 8 first takers instead of reading the row (2-4 lines) and probing every column (15 / 34 on the channel's coarse levels): the
+// look-ups are most of the scattered lines the set-ups take from the products beside them.  When every listed column is taken and the row has
+// more, the full scan decides (exact either way: an unlisted column ranks behind every listed one).
+constexpr int kPrefs = 8;
+constexpr int kPrefMore = 1 << 30;
+__global__ void agg_init_prefs_k(MatView A, int *__restrict__ choice, unsigned char *__restrict__ active, unsigned char *__restrict__ active_next,
+                                 int *__restrict__ prefs) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < A.P.n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int len = A.P.row_len[i];
+        const int64_t base = A.P.slice_ptr[i >> 6] + (i & 63);  // (the SELL image: lane = row, coalesced)
+        double bv[kPrefs];
+        int bj[kPrefs];
+#pragma unroll
+        for (int q = 0; q < kPrefs; ++q) { bv[q] = 1.7976931348623157e308; bj[q] = -1; }
+        int cand = 0;
+        for (int k = 0; k < len; ++k) {
+            const int64_t pos = base + (int64_t)k * 64;
+            const int j = A.P.col[pos];
+            if (j == i || j >= A.P.n) continue;
+            const double a = view_value(A, i, pos);
+            if (!(a < 1.7976931348623157e308)) continue;  // (the scan's "a < best" starts from Float::MAX: such an entry — or a NaN — is never chosen)
+            ++cand;
+            // its place: in front of the first listed entry it is strictly smaller than — an entry equal to a listed one stays behind it (it came
+            // later in the row) — and everything from there on moves one place back
+            int pos_q = kPrefs;
+#pragma unroll
+            for (int q = kPrefs - 1; q >= 0; --q)
+                if (a < bv[q]) pos_q = q;
+#pragma unroll
+            for (int q = kPrefs - 1; q >= 1; --q)
+                if (q > pos_q) { bv[q] = bv[q - 1]; bj[q] = bj[q - 1]; }
+#pragma unroll
+            for (int q = 0; q < kPrefs; ++q)
+                if (q == pos_q) { bv[q] = a; bj[q] = j; }
+        }
+        choice[i] = bj[0];
+#pragma unroll
+        for (int q = 0; q < kPrefs; ++q) prefs[i * kPrefs + q] = (q == kPrefs - 1 && cand > kPrefs && bj[q] >= 0) ? (bj[q] | kPrefMore) : bj[q];
+        if ((i & 63) == 0) { active[i >> 6] = 1; active_next[i >> 6] = 0; }
+    }
+}
+
 // one thread = one slice, rows in ascending order
 __global__ void agg_sweep_k(MatView A, int *__restrict__ choice, int *__restrict__ taken_by, const unsigned char *__restrict__ active,
                             unsigned char *__restrict__ active_next, AggCounters *C, int all_active) {
@@ -234,6 +281,34 @@ __device__ __forceinline__ int group_eval_row_g(const MatView &A, const int *__r
     return bj;
 }
 
+// the group's answer from the preference list; lanes beyond the list idle.  scan_row: the list ran out and the row has more candidates
+template <int G>
+__device__ __forceinline__ int group_eval_pref(const int *__restrict__ prefs, const int *__restrict__ taken_by, int64_t i, int gl, bool &scan_row) {
+    scan_row = false;
+    const int shift = (threadIdx.x & 63) & ~(G - 1);
+    for (int q0 = 0; q0 < kPrefs; q0 += G) {
+        const int q = q0 + gl;
+        int j = -1;
+        bool more = false;
+        if (q < kPrefs) {
+            const int raw = prefs[i * kPrefs + q];
+            more = raw >= 0 && (raw & kPrefMore) != 0;
+            j = raw >= 0 ? (raw & ~kPrefMore) : -1;
+        }
+        const bool is_free = j >= 0 && taken_by[j] >= i;
+        const unsigned long long all = __ballot(is_free);
+        const unsigned long long mine = G == 64 ? all : ((all >> shift) & ((1ull << G) - 1ull));
+        if (mine) return __shfl(j, __ffsll((long long)mine) - 1, G);
+        const unsigned long long ended_all = __ballot(q < kPrefs && j < 0);  // the list ended inside this batch: every candidate is taken
+        const unsigned long long ended = G == 64 ? ended_all : ((ended_all >> shift) & ((1ull << G) - 1ull));
+        if (ended) return -1;
+        const unsigned long long more_all = __ballot(more);
+        const unsigned long long more_g = G == 64 ? more_all : ((more_all >> shift) & ((1ull << G) - 1ull));
+        if (q0 + G >= kPrefs) { scan_row = more_g != 0ull; return -1; }
+    }
+    return -1;
+}
+
 // [r04] What the sweep leaves to the cascades is NOT its seams: walking 3 ... 32 adjacent slices per group, and reading the first-taker table
 // past the vector L1, leave the same 2.7 M of 10.24 M rows away from the fixed point (ORC_AMG_TRACE "[amg distance]", scripts/gpu_r04_t.sh).  On
 // the channel the fixed point differs from the arg-min state in a triangle at the end of every grid line — the last row of line j has no
@@ -241,7 +316,8 @@ __device__ __forceinline__ int group_eval_row_g(const MatView &A, const int *__r
 // pairing_structure.py) — chains of up to min(nx, ny) links that hop nx - 1 rows each: no slice-local order resolves them.
 template <int G>
 __global__ __launch_bounds__(kBlock) void agg_sweep_group_k(MatView A, int *__restrict__ choice, int *__restrict__ taken_by, const unsigned char *__restrict__ active,
-                                                            unsigned char *__restrict__ active_next, AggCounters *C, int all_active) {
+                                                            unsigned char *__restrict__ active_next, AggCounters *C, int all_active,
+                                                            const int *__restrict__ prefs /* preference lists (agg_init_prefs_k) or null */) {
     const int64_t n = A.P.n;
     const int gl = threadIdx.x & (G - 1);
     const int64_t groups = ((int64_t)gridDim.x * blockDim.x) / G;
@@ -250,7 +326,14 @@ __global__ __launch_bounds__(kBlock) void agg_sweep_group_k(MatView A, int *__re
         if (!all_active && !active[s]) continue;
         const int64_t lo = s * 64, hi = lo + 64 < n ? lo + 64 : n;
         for (int64_t i = lo; i < hi; ++i) {
-            const int nv = group_eval_row_g<G>(A, taken_by, i, gl);
+            int nv;
+            if (prefs) {
+                bool scan_row;
+                nv = group_eval_pref<G>(prefs, taken_by, i, gl, scan_row);
+                if (scan_row) nv = group_eval_row_g<G>(A, taken_by, i, gl);
+            } else {
+                nv = group_eval_row_g<G>(A, taken_by, i, gl);
+            }
             const int old = choice[i];
             if (nv == old) continue;
             if (gl == 0) {
@@ -281,7 +364,8 @@ __global__ __launch_bounds__(kBlock) void agg_sweep_group_k(MatView A, int *__re
 // row, 16 beyond — was the first guess; measured, 4 lanes are the fastest on every level (ORC_AMG_EVAL_GROUP overrides).
 template <int G>
 __global__ void tail_eval_k(MatView A, const int *__restrict__ choice, const int *__restrict__ taken_by, const int *__restrict__ list_a,
-                            const int *__restrict__ list_b, TailCounters *T, int *__restrict__ flag, int *__restrict__ ch_row, int *__restrict__ ch_new) {
+                            const int *__restrict__ list_b, TailCounters *T, int *__restrict__ flag, int *__restrict__ ch_row, int *__restrict__ ch_new,
+                            const int *__restrict__ prefs /* preference lists or null */) {
     if (T->finished) return;
     const int count = T->cur;
     const int *__restrict__ list = T->first ? nullptr : (T->parity ? list_b : list_a);
@@ -289,7 +373,14 @@ __global__ void tail_eval_k(MatView A, const int *__restrict__ choice, const int
     const int64_t groups = ((int64_t)gridDim.x * blockDim.x) / G;
     for (int64_t idx = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G; idx < count; idx += groups) {
         const int i = list ? list[idx] : (int)idx;
-        const int nv = group_eval_row_g<G>(A, taken_by, i, gl);
+        int nv;
+        if (prefs) {
+            bool scan_row;
+            nv = group_eval_pref<G>(prefs, taken_by, i, gl, scan_row);
+            if (scan_row) nv = group_eval_row_g<G>(A, taken_by, i, gl);
+        } else {
+            nv = group_eval_row_g<G>(A, taken_by, i, gl);
+        }
         bool changed = false;
         if (gl == 0) {
             flag[i] = 0;
@@ -2117,6 +2208,14 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
         ORC_HIP(hipMemsetAsync(C, 0, sizeof(AggCounters), st));
         warm = nullptr;  // not this matrix's pairing: from scratch
     }
+    // preference lists for the sweep and the lock-step evaluations, where rows are long (with the mesh pattern's 7 entries per row a list saves no
+    // look-up); ORC_AMG_PREFS=0: every evaluation scans its row (r03); ORC_AMG_PREFS_MIN_LEN: stored entries per row from which on (12).  Per call.
+    int *prefs = nullptr;
+    const int prefs_min_len = getenv("ORC_AMG_PREFS_MIN_LEN") ? atoi(getenv("ORC_AMG_PREFS_MIN_LEN")) : 12;
+    if (!(getenv("ORC_AMG_PREFS") && atoi(getenv("ORC_AMG_PREFS")) == 0) && n > 0 && A.P.padded >= (int64_t)prefs_min_len * n) {
+        ORC_TRY(arena.alloc((size_t)n * kPrefs, &prefs));
+        hipLaunchKernelGGL(agg_init_prefs_k, dim3(g), dim3(kBlock), 0, st, A, choice, act_a, act_b, prefs);
+    } else
     hipLaunchKernelGGL(agg_init_k, dim3(g), dim3(kBlock), 0, st, A, choice, act_a, act_b);  // also resets the slice flags
     if (warm) ORC_HIP(hipMemcpyAsync(choice, warm, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, st));
     int rounds = 0;
@@ -2150,10 +2249,10 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
             const int G = group_env >= 0 ? group_env : (avg <= 0. ? 0 : 8);
             // adjacent slices per group: ORC_AMG_SWEEP_BLOCK (0 = strided); the launch shrinks to the groups that have a piece
             const int gg = grid_for((int64_t)A.P.n_slices * std::max(G, 1));
-            if (G == 4) hipLaunchKernelGGL(agg_sweep_group_k<4>, dim3(gg), dim3(kBlock), 0, st, A, choice, taken_by, cur, nxt, C, all_active);
-            else if (G == 8) hipLaunchKernelGGL(agg_sweep_group_k<8>, dim3(gg), dim3(kBlock), 0, st, A, choice, taken_by, cur, nxt, C, all_active);
-            else if (G == 16) hipLaunchKernelGGL(agg_sweep_group_k<16>, dim3(gg), dim3(kBlock), 0, st, A, choice, taken_by, cur, nxt, C, all_active);
-            else if (G == 32) hipLaunchKernelGGL(agg_sweep_group_k<32>, dim3(gg), dim3(kBlock), 0, st, A, choice, taken_by, cur, nxt, C, all_active);
+            if (G == 4) hipLaunchKernelGGL(agg_sweep_group_k<4>, dim3(gg), dim3(kBlock), 0, st, A, choice, taken_by, cur, nxt, C, all_active, (const int *)prefs);
+            else if (G == 8) hipLaunchKernelGGL(agg_sweep_group_k<8>, dim3(gg), dim3(kBlock), 0, st, A, choice, taken_by, cur, nxt, C, all_active, (const int *)prefs);
+            else if (G == 16) hipLaunchKernelGGL(agg_sweep_group_k<16>, dim3(gg), dim3(kBlock), 0, st, A, choice, taken_by, cur, nxt, C, all_active, (const int *)prefs);
+            else if (G == 32) hipLaunchKernelGGL(agg_sweep_group_k<32>, dim3(gg), dim3(kBlock), 0, st, A, choice, taken_by, cur, nxt, C, all_active, (const int *)prefs);
             else hipLaunchKernelGGL(agg_sweep_k, dim3(gs), dim3(64), 0, st, A, choice, taken_by, cur, nxt, C, all_active);
             hipLaunchKernelGGL(agg_rotate_k, dim3(1), dim3(1), 0, st, C, snap + b);
             ORC_HIP(hipMemsetAsync(cur, 0, (size_t)A.P.n_slices, st));
@@ -2210,10 +2309,10 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
         (void)eval_avg;
         const int eval_group = eval_group_env ? eval_group_env : 4;  // one stream, all levels of six iterations: 16 lanes 95 ms, 8: 67 ms, 4: 58 ms
         auto launch_eval = [&](int ge) {
-            if (eval_group == 4) hipLaunchKernelGGL(tail_eval_k<4>, dim3(ge), dim3(kBlock), 0, st, A, choice, taken_by, (const int *)listA, (const int *)listB, T, flag, ch_row, ch_new);
-            else if (eval_group == 8) hipLaunchKernelGGL(tail_eval_k<8>, dim3(ge), dim3(kBlock), 0, st, A, choice, taken_by, (const int *)listA, (const int *)listB, T, flag, ch_row, ch_new);
-            else if (eval_group == 32) hipLaunchKernelGGL(tail_eval_k<32>, dim3(ge), dim3(kBlock), 0, st, A, choice, taken_by, (const int *)listA, (const int *)listB, T, flag, ch_row, ch_new);
-            else hipLaunchKernelGGL(tail_eval_k<16>, dim3(ge), dim3(kBlock), 0, st, A, choice, taken_by, (const int *)listA, (const int *)listB, T, flag, ch_row, ch_new);
+            if (eval_group == 4) hipLaunchKernelGGL(tail_eval_k<4>, dim3(ge), dim3(kBlock), 0, st, A, choice, taken_by, (const int *)listA, (const int *)listB, T, flag, ch_row, ch_new, (const int *)prefs);
+            else if (eval_group == 8) hipLaunchKernelGGL(tail_eval_k<8>, dim3(ge), dim3(kBlock), 0, st, A, choice, taken_by, (const int *)listA, (const int *)listB, T, flag, ch_row, ch_new, (const int *)prefs);
+            else if (eval_group == 32) hipLaunchKernelGGL(tail_eval_k<32>, dim3(ge), dim3(kBlock), 0, st, A, choice, taken_by, (const int *)listA, (const int *)listB, T, flag, ch_row, ch_new, (const int *)prefs);
+            else hipLaunchKernelGGL(tail_eval_k<16>, dim3(ge), dim3(kBlock), 0, st, A, choice, taken_by, (const int *)listA, (const int *)listB, T, flag, ch_row, ch_new, (const int *)prefs);
         };
         // (read per call, not cached: the tests run one process through the lock-step-only form, a starved cascade phase
         // that hands over to the lock-step rounds unfinished, and the default)
