@@ -733,7 +733,7 @@ __device__ __forceinline__ int chase_claim(int count, int n_groups) { return max
 
 template <int G>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8))) void tail_chase_k(MatView A, int *choice, unsigned long long *tb, int *ver, int *flag, TailCounters *T, int *list_a,
-                                                       int *list_b, int max_steps) {
+                                                       int *list_b, int max_steps, const int *__restrict__ prefs) {
     const int count = T->cur;
     if (T->finished || count == 0) return;
     const int *cur = T->parity ? list_b : list_a;
@@ -776,7 +776,25 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8))) voi
             if (lane == 0) st_i(flag + i, 2);
             const int old = ld_i(choice + i);  // only the owner writes it
             // ---- evaluate (group_eval_row over the wavefront, against the versioned table)
-            const int len = A.P.row_len[i];
+            // [r04] from the row's preference list where the level has one (agg_init_prefs_k): one 32-byte line and <= 8 look-ups instead of
+            // the row and one look-up per entry; the full scan only when every listed column is taken and the row has more
+            bool scan_row = prefs == nullptr;
+            int pref_nv = -1;
+            if (prefs) {
+                int j = -1;
+                bool more = false;
+                if (lane < kPrefs) {
+                    const int raw = prefs[(int64_t)i * kPrefs + lane];
+                    more = raw >= 0 && (raw & kPrefMore) != 0;
+                    j = raw >= 0 ? (raw & ~kPrefMore) : -1;
+                }
+                chase_fence();  // the flag store is performed before the table is read
+                const bool is_free = j >= 0 && first_taker(tb, j) >= i;
+                const unsigned long long mine = group_ballot<G>(is_free);
+                if (mine) pref_nv = __shfl(j, __ffsll((long long)mine) - 1, G);
+                else if (!group_ballot<G>(lane < kPrefs && j < 0)) scan_row = group_ballot<G>(more) != 0ull;  // (the list did not end: more behind it?)
+            }
+            const int len = scan_row ? A.P.row_len[i] : 0;
             const RowWalk W(A, i);
             double best = 1.7976931348623157e308;  // Float::MAX
             int bk = 0x7fffffff, bj = -1;
@@ -797,7 +815,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8))) voi
                 const int oj = __shfl_xor(bj, off, G);
                 if (ob < best || (ob == best && ok < bk)) { best = ob; bk = ok; bj = oj; }
             }
-            const int nv = bj;
+            const int nv = scan_row ? bj : pref_nv;
             int cont = -1, was = 0;
             if (nv != old) {
                 ++moved;
@@ -2373,9 +2391,9 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
             }
             for (;;) {
                 for (int b = 0; b < chase_batch; ++b) {
-                    if (group == 16) hipLaunchKernelGGL(tail_chase_k<16>, dim3(chase_grid), dim3(kBlock), 0, st, A, choice, tb, ver, flag, T, listA, listB, chase_steps);
-                    else if (group == 32) hipLaunchKernelGGL(tail_chase_k<32>, dim3(chase_grid), dim3(kBlock), 0, st, A, choice, tb, ver, flag, T, listA, listB, chase_steps);
-                    else hipLaunchKernelGGL(tail_chase_k<64>, dim3(chase_grid), dim3(kBlock), 0, st, A, choice, tb, ver, flag, T, listA, listB, chase_steps);
+                    if (group == 16) hipLaunchKernelGGL(tail_chase_k<16>, dim3(chase_grid), dim3(kBlock), 0, st, A, choice, tb, ver, flag, T, listA, listB, chase_steps, (const int *)prefs);
+                    else if (group == 32) hipLaunchKernelGGL(tail_chase_k<32>, dim3(chase_grid), dim3(kBlock), 0, st, A, choice, tb, ver, flag, T, listA, listB, chase_steps, (const int *)prefs);
+                    else hipLaunchKernelGGL(tail_chase_k<64>, dim3(chase_grid), dim3(kBlock), 0, st, A, choice, tb, ver, flag, T, listA, listB, chase_steps, (const int *)prefs);
                     hipLaunchKernelGGL(chase_carry_k, dim3(64), dim3(kBlock), 0, st, T, (const int *)listA, (const int *)listB, listA, listB, chase_grid * (kBlock / group));
                     hipLaunchKernelGGL(chase_rotate_k, dim3(1), dim3(1), 0, st, T, steps_total);
                 }
