@@ -2226,10 +2226,11 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
         ORC_HIP(hipMemsetAsync(C, 0, sizeof(AggCounters), st));
         warm = nullptr;  // not this matrix's pairing: from scratch
     }
-    // preference lists for the sweep and the lock-step evaluations, where rows are long (with the mesh pattern's 7 entries per row a list saves no
-    // look-up); ORC_AMG_PREFS=0: every evaluation scans its row (r03); ORC_AMG_PREFS_MIN_LEN: stored entries per row from which on (12).  Per call.
+    // preference lists for the sweep's, the lock-step rounds' and the cascades' evaluations.  ORC_AMG_PREFS=0: every evaluation scans its row (r03);
+    // ORC_AMG_PREFS_MIN_LEN: stored entries per row from which on (5: every level of the channel — with the mesh pattern's 7 entries per row a list
+    // saves no look-up, only the row's own lines, and still pays: 767.0 / 768.5 / 757.5 -> 758.9 / 761.5 / 759.1 ms against lists from 12 on).  Per call.
     int *prefs = nullptr;
-    const int prefs_min_len = getenv("ORC_AMG_PREFS_MIN_LEN") ? atoi(getenv("ORC_AMG_PREFS_MIN_LEN")) : 12;
+    const int prefs_min_len = getenv("ORC_AMG_PREFS_MIN_LEN") ? atoi(getenv("ORC_AMG_PREFS_MIN_LEN")) : 5;
     if (!(getenv("ORC_AMG_PREFS") && atoi(getenv("ORC_AMG_PREFS")) == 0) && n > 0 && A.P.padded >= (int64_t)prefs_min_len * n) {
         ORC_TRY(arena.alloc((size_t)n * kPrefs, &prefs));
         hipLaunchKernelGGL(agg_init_prefs_k, dim3(g), dim3(kBlock), 0, st, A, choice, act_a, act_b, prefs);
