@@ -85,12 +85,15 @@ __global__ void agg_init_k(MatView A, int *__restrict__ choice, unsigned char *_
 // ---- preference lists [r04] ------------------------------------------------------------------------------------------
 // A row's decision is "the most negative entry whose column no earlier row holds" — the FIRST free column in the row's order of preference
 // (value ascending, position ascending: the strict <, first-wins scan of linear_algebra.rs:37-52).  That order does not change while the pairing is
-// sought, so the pass that computes the starting state (the unconstrained arg-min = the first preference) keeps the row's EIGHT most preferred
-// columns: prefs[8 i .. 8 i + 7] (-1 = fewer; bit 30 of entry 7 = the row has more candidates than listed).  An evaluation then reads one 32-byte
-// line and probes <= 8 first takers instead of reading the row (2-4 lines) and probing every column (15 / 34 on the channel's coarse levels): the
-// look-ups are most of the scattered lines the set-ups take from the products beside them.  When every listed column is taken and the row has
-// more, the full scan decides (exact either way: an unlisted column ranks behind every listed one).
-constexpr int kPrefs = 8;
+// sought, so the pass that computes the starting state (the unconstrained arg-min = the first preference) keeps the row's kPrefs most preferred
+// columns: prefs[kPrefs i ..] (-1 = fewer; bit 30 of the last entry = the row has more candidates than listed).  An evaluation then reads a few
+// bytes and probes <= kPrefs first takers instead of reading the row (2-4 lines) and probing every column (7 / 15 / 34 on the channel's levels):
+// the look-ups are most of the scattered lines the set-ups take from the products beside them.  When every listed column is taken and the row
+// has more, the full scan decides (exact either way: an unlisted column ranks behind every listed one).
+// How many: 8 was the first choice; measured on one box each, interleaved, per SIMPLE iteration: 8 -> 4: 769.0 / 763.1 -> 758.7 / 760.1 ms;
+// 4 -> 2: 778.4 / 771.1 -> 769.9 / 763.8; 2 -> 3: 771.2 / 764.2 -> 784.2 / 768.6 (12-byte lists straddle lines).  The first two preferences decide
+// most evaluations, and every listed column is a look-up whether it is needed or not.
+constexpr int kPrefs = 2;
 constexpr int kPrefMore = 1 << 30;
 __global__ void agg_init_prefs_k(MatView A, int *__restrict__ choice, unsigned char *__restrict__ active, unsigned char *__restrict__ active_next,
                                  int *__restrict__ prefs) {
