@@ -779,7 +779,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8))) voi
             if (lane == 0) st_i(flag + i, 2);
             const int old = ld_i(choice + i);  // only the owner writes it
             // ---- evaluate (group_eval_row over the wavefront, against the versioned table)
-            // [r04] from the row's preference list where the level has one (agg_init_prefs_k): one 32-byte line and <= 8 look-ups instead of
+            // [r04] from the row's preference list where the level has one (agg_init_prefs_k): a few bytes and <= kPrefs look-ups instead of
             // the row and one look-up per entry; the full scan only when every listed column is taken and the row has more
             bool scan_row = prefs == nullptr;
             int pref_nv = -1;
