@@ -90,10 +90,12 @@ __global__ void agg_init_k(MatView A, int *__restrict__ choice, unsigned char *_
 // bytes and probes <= kPrefs first takers instead of reading the row (2-4 lines) and probing every column (7 / 15 / 34 on the channel's levels):
 // the look-ups are most of the scattered lines the set-ups take from the products beside them.  When every listed column is taken and the row
 // has more, the full scan decides (exact either way: an unlisted column ranks behind every listed one).
-// How many: 8 was the first choice; measured on one box each, interleaved, per SIMPLE iteration: 8 -> 4: 769.0 / 763.1 -> 758.7 / 760.1 ms;
-// 4 -> 2: 778.4 / 771.1 -> 769.9 / 763.8; 2 -> 3: 771.2 / 764.2 -> 784.2 / 768.6 (12-byte lists straddle lines).  The first two preferences decide
-// most evaluations, and every listed column is a look-up whether it is needed or not.
-constexpr int kPrefs = 2;
+// How many: 8 was the first choice.  One hierarchy alone (profiles/r04_setup.csv): 8 columns: sweeps 10.6 GB, cascades 31.3 GB; 2 columns: sweeps
+// 7.2 GB, cascades 38.4 GB (a displaced row's first two preferences are often taken: the full scan runs more often).  Whole iterations on one box
+// drift upwards by 3-5 ms from run to run (found late: with the order of the two builds reversed the "winner" changed), so 8 -> 4 (769.0 / 763.1 ->
+// 758.7 / 760.1 ms, new build first) and 4 -> 2 (778.4 / 771.1 -> 769.9 / 763.8 new first; 764.7 / 768.9 / 778.1 against 769.6 / 776.0 / 782.6 old
+// first) say no more than "about equal"; 3 is worse either way (12-byte lists straddle lines).  Four it is.
+constexpr int kPrefs = 4;
 constexpr int kPrefMore = 1 << 30;
 __global__ void agg_init_prefs_k(MatView A, int *__restrict__ choice, unsigned char *__restrict__ active, unsigned char *__restrict__ active_next,
                                  int *__restrict__ prefs) {
