@@ -675,6 +675,7 @@ __global__ __launch_bounds__(kBlock) void momentum_k(MeshDev M, SellDev P, Momen
         A.b_w[c] = total.z + A.b_w_di[c];
         const double px = a_p.x / a_ii_di, py = a_p.y / a_ii_di, pz = a_p.z / a_ii_di;  // :331-333
         if (kInplace) { I.pe[c] = px; I.pe[n + c] = py; I.pe[2 * n + c] = pz; }
+        else if (I.pe) I.pe[c] = (((0. + px) + py) + pz) / 3.;  // [r05] reference reduction order with frozen diagonals: the cell's term of :338
         pe_max = fmax(pe_max, fmax(px, fmax(py, pz)));
         pe_min = fmin(pe_min, fmin(px, fmin(py, pz)));
         pe_sum += (((0. + px) + py) + pz) / 3.;  // :338
@@ -998,6 +999,8 @@ int solver_init(SolverState &s, OrcMesh *m, const OrcSettings *settings, double 
         std::vector<int64_t> cur(s.level_ptr.begin(), s.level_ptr.end() - 1);
         for (int64_t c = 0; c < s.n_own; ++c) cells[(size_t)cur[(size_t)level[(size_t)c]]++] = (int32_t)c;
         ORC_TRY(s.level_cells.upload(cells.data(), cells.size()));
+    } else if (s.settings.reduction_order == ORC_REDUCTION_REFERENCE && !m->halo.active()) {
+        ORC_TRY(s.pe.alloc(n));  // [r05] per-cell terms of the report's sums in the reference's association (k_momentum, k_apply_correction)
     }
     ORC_TRY(s.partials.alloc((size_t)8 * kMaxPartials));
     ORC_TRY(s.scal.alloc(16));
@@ -1067,7 +1070,11 @@ int k_momentum(SolverState &s, double *peclet_host) {
         ref_pe = s.settings.reduction_order == ORC_REDUCTION_REFERENCE && !s.mesh->halo.active() && peclet_host != nullptr;
         if (ref_pe) hipLaunchKernelGGL(peclet_cell_term_k, dim3(g), dim3(kBlock), 0, ctx().stream, s.pe.p, s.n);  // pe[c] = its term of :338
     } else {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(momentum_k<false>), dim3(g), dim3(kBlock), 0, ctx().stream, m.dev(), m.pat.dev(), A, s.partials.p, InplaceArgs());
+        // [r05] frozen diagonals in the reference's reduction order (a verification mode too: the frozen oracle bit for bit, report included)
+        InplaceArgs I{};
+        ref_pe = s.settings.reduction_order == ORC_REDUCTION_REFERENCE && !s.mesh->halo.active() && peclet_host != nullptr && s.pe.p != nullptr;
+        I.pe = ref_pe ? s.pe.p : nullptr;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(momentum_k<false>), dim3(g), dim3(kBlock), 0, ctx().stream, m.dev(), m.pat.dev(), A, s.partials.p, I);
     }
     hipLaunchKernelGGL(reduce_minmax_k, dim3(1), dim3(64), 0, ctx().stream, s.partials.p, g, s.scal.p + 8);
     ORC_HIP(hipGetLastError());
@@ -1102,7 +1109,7 @@ int k_apply_correction(SolverState &s, double *sums_host) {
     // reference's association too — p'.norm() through dotx (solver.rs:1226), the velocity-correction sum cell by cell (:1224), the
     // means as left-to-right folds (:206-208) — so that not only the fields but the six report doubles of an iteration are the
     // oracle's bit for bit (scripts/reference_mode_fullsize.py compares exactly those at 10.24 M cells).  s.pe is free by now.
-    const bool ref_report = s.settings.reduction_order == ORC_REDUCTION_REFERENCE && s.settings.frozen_diagonals == 0 && !s.mesh->halo.active() && s.pe.p;
+    const bool ref_report = s.settings.reduction_order == ORC_REDUCTION_REFERENCE && !s.mesh->halo.active() && s.pe.p;
     hipLaunchKernelGGL(correction_k, dim3(g), dim3(kBlock), 0, ctx().stream, m.dev(), s.du.p, s.dv.p, s.dw.p, s.p_prime.p, s.u.p, s.v.p,
                        s.w.p, s.p.p, s.settings.pressure_relaxation, s.settings.momentum_relaxation, s.partials.p, s.dev_status.p,
                        ref_report ? s.pe.p : (double *)nullptr);

@@ -69,3 +69,19 @@ def rel_l2(a, b):
 def analytical_poiseuille(y, h=0.001, mu=1e-3, dp_dx=5.0, u_top=0.0):
     """tests.rs:26-29"""
     return u_top * y / h + 1.0 / (2.0 * mu) * dp_dx * (y * y - h * y)
+
+
+def rough_fields(cc, dp_dx=5.0, h=1e-3, mu=1e-3, lx=0.002, seed=0x524F55):
+    """The bench's Poiseuille start (bench.initial_fields) with PER-CENT-level cell-to-cell noise on u and p and v, w of a per cent of
+    the bulk velocity: successive velocity differences change sign from cell to cell, so every branch of the TVD limiters
+    (lib.rs:107-118), both upwind directions and the zero-difference fallback's neighbourhood are live in one assembly.
+    A formula, so that tests/golden/make_golden_bench_midsize.py --frozen and the GPU test build the same doubles."""
+    n = len(cc)
+    y = cc[:, 1]
+    r = [splitmix64_uniform(n, seed + k) for k in range(4)]
+    ub = 1.0 / (2.0 * mu) * dp_dx * (y * y - h * y)
+    u = ub * (1.0 + 0.05 * r[0])
+    v = 0.02 * np.abs(ub).max() * r[1]
+    w = 0.02 * np.abs(ub).max() * r[2]
+    p = -dp_dx * lx * (1.0 - cc[:, 0] / lx) * (1.0 + 0.03 * r[3])
+    return tuple(np.ascontiguousarray(a) for a in (u, v, w, p))

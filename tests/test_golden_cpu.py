@@ -39,6 +39,30 @@ def test_oracle_reproduces_golden_assembly(oracle, mesh_path, name):
     assert not np.array_equal(g["a_uvw_faithful_it2"], g["a_uvw_frozen_it2"]) or name == "3x3_cube_mixed" or True
 
 
+def test_committed_frozen_assembly_hashes_are_the_oracle_of_this_tree(oracle):
+    """tests/golden/bench_midsize_frozen_mixed_60x30x30.npz (the GPU suite's pin of the timed assembly, tests/test_gpu_bench_family.py) against the
+    oracle as built from this tree: the first assembly of the generator (make_golden_bench_midsize.py --frozen --mixed), hash by hash — a change
+    of oracle/, of the mesh generator or of bench.initial_fields that moves a bit shows up here, on the CPU, not as a GPU failure."""
+    import hashlib
+    import bench
+    from orc_amd import parallel
+    from orc_amd.mesh import set_mixed_channel_bcs
+    g = np.load(os.path.join(GOLDEN, "bench_midsize_frozen_mixed_60x30x30.npz"), allow_pickle=False)
+    _a, _h, _g, a = parallel.mixed_slab_arrays(*(int(x) for x in g["shape"]), 0, 1)
+    set_mixed_channel_bcs(a)
+    om = oracle.Mesh.from_arrays(a)
+    kw = {k: (float(v) if "." in v else int(v)) for k, v in g["settings"]}
+    s = oracle.default_settings(**kw)
+    u, v, w, p = (np.ascontiguousarray(x) for x in bench.initial_fields(np.asarray(a["cell_centroid"])))
+    a_di, *_ = oracle.build_momentum_diffusion_matrix(om, 1e-3)
+    mats = [oracle.initialize_momentum_matrix(om) for _ in range(3)]
+    bu, bv, bw, _pe = oracle.build_momentum_advection_matrices(mats[0], mats[1], mats[2], a_di, om, u, v, w, p, s, 1000.0)
+    a_p, b_p = oracle.build_pressure_correction_matrices(om, u, v, w, p, mats[0], mats[1], mats[2], s, 1000.0)
+    for key, x in (("a_u_1", mats[0].arrays()[2]), ("a_v_1", mats[1].arrays()[2]), ("a_w_1", mats[2].arrays()[2]), ("b_u_1", bu), ("b_v_1", bv),
+                   ("b_w_1", bw), ("a_p_1", a_p.arrays()[2]), ("b_p_1", b_p)):
+        assert hashlib.sha256(np.ascontiguousarray(x).tobytes()).digest() == g["sha256_" + key].tobytes(), key
+
+
 def test_oracle_reproduces_golden_unit_test_solution(oracle):
     a, b, sol = unit_test_system()
     g = np.load(os.path.join(GOLDEN, "unit_test_system.npz"))

@@ -154,3 +154,114 @@ def test_midsize_bench_channel_reference_order_against_the_committed_oracle_run(
                 "iteration %d, field %s differs from the oracle (largest sampled difference %.3e of the field's scale)" % (it, name, worst)
         ro = g["report_%d" % it]  # oracle: means 0-2, mean Peclet 3, velocity correction 4, pressure correction 5
         assert same_bits(np.array([rep[0][k] for k in (0, 1, 2, 3, 6, 7)]), ro), (it, rep[0], ro)
+
+
+# ------------------------------------------------------------------ the assembly bench.py TIMES, at the bench's own launch shape
+def _midsize_arrays(mixed):
+    import os
+    from conftest import GOLDEN
+    from orc_amd.mesh import hex_channel, set_channel_bcs, set_mixed_channel_bcs
+    g = np.load(os.path.join(GOLDEN, "bench_midsize_frozen_mixed_60x30x30.npz" if mixed else "bench_midsize_frozen_128x64x64.npz"), allow_pickle=False)
+    shape = tuple(int(x) for x in g["shape"])
+    if mixed:
+        from orc_amd import parallel
+        _a, _h, _g, a = parallel.mixed_slab_arrays(*shape, 0, 1)
+        set_mixed_channel_bcs(a)
+    else:
+        a = set_channel_bcs(hex_channel(*shape))
+    return g, a
+
+
+def _first_mismatch(g, key, x, stride):
+    """None when x has the oracle's bits (SHA-256 of the raw doubles); otherwise a sentence for the assertion: the array, how far the
+    strided samples are apart and where the first differing sample sits."""
+    import hashlib
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    if hashlib.sha256(x.tobytes()).digest() == g["sha256_" + key].tobytes():
+        return None
+    s, t = x[::stride], g["sample_" + key]
+    bad = np.nonzero(~((s == t) | (np.isnan(s) & np.isnan(t))))[0]
+    where = "no sampled entry differs" if len(bad) == 0 else "first differing sample at index %d: %r against the oracle's %r" % (
+        int(bad[0]) * stride, float(s[bad[0]]), float(t[bad[0]]))
+    with np.errstate(invalid="ignore"):
+        stats = np.array([np.nanmin(x), np.nanmax(x), np.nansum(x), float(np.isnan(x).sum())])
+    return "%s differs from the oracle (%d of %d samples; %s; min / max / sum / NaNs %s against %s)" % (key, len(bad), len(t), where, stats, g["stats_" + key])
+
+
+@pytest.mark.parametrize("mixed", [False, True], ids=["hex_128x64x64", "mixed_60x30x30"])
+def test_frozen_assembly_at_the_bench_launch_shape_against_the_committed_oracle_hashes(gpu, mixed):
+    """discretization.rs:134-356, 359-448 with frozen diagonals — face_k<0/1>, momentum_k<false>, pressure_k: the kernels of the timed iteration —
+    at 524 288 hex cells (2 048 workgroups: the XCD-by-XCD walk of momentum_k<false>, several virtual blocks per workgroup) and on 159 510
+    mixed cells (623 workgroups: the plain grid stride, ragged rows), through the C ABI's orc_build_momentum_advection_matrices /
+    orc_build_pressure_correction_matrices.  Two consecutive assemblies: the first from the bench's initial fields and unit diagonals (SURVEY
+    Q3), the second from rough fields and the first's matrices (non-trivial old diagonals in Rhie-Chow).  The assembly has no reductions, so
+    identical bits are the bar at any size: SHA-256 of every array against tests/golden/make_golden_bench_midsize.py --frozen [--mixed]."""
+    from orc_amd import discretization as D
+    from orc_amd.mesh import Mesh
+    from orc_amd.settings import NumericalSettings
+    g, a = _midsize_arrays(mixed)
+    dm = Mesh(a)
+    cc = np.asarray(a["cell_centroid"])
+    s = NumericalSettings.default(frozen_diagonals=1, breakdown_guard=0, **BENCH_KW)
+    sn, snnz = int(g["stride_n"]), int(g["stride_nnz"])
+    a_di, *_ = D.build_momentum_diffusion_matrix(dm, 1e-3)
+    mats = [D.initialize_momentum_matrix(dm) for _ in range(3)]
+    for k, f in ((1, bench.initial_fields(cc)), (2, H.rough_fields(cc))):
+        u, v, w, p = (np.ascontiguousarray(x) for x in f)
+        bu, bv, bw, pe = D.build_momentum_advection_matrices(dm, mats[0], mats[1], mats[2], a_di, u, v, w, p, s, 1000.0)
+        a_p, b_p = D.build_pressure_correction_matrices(dm, u, v, w, p, mats[0], mats[1], mats[2], s, 1000.0)
+        found = [_first_mismatch(g, "%s_%d" % (name, k), x, stride) for name, x, stride in (
+            ("a_u", mats[0], snnz), ("a_v", mats[1], snnz), ("a_w", mats[2], snnz), ("b_u", bu, sn), ("b_v", bv, sn), ("b_w", bw, sn),
+            ("a_p", a_p, snnz), ("b_p", b_p, sn))]
+        found = [m for m in found if m]
+        assert not found, "assembly %d: %s" % (k, found[0])
+        # the Peclet mean is a sum over the cells (tree on the device, left to right in the oracle); min and max are exact
+        assert np.isclose(pe[0], g["peclet_%d" % k][0], rtol=1e-10) and pe[1] == g["peclet_%d" % k][1] and pe[2] == g["peclet_%d" % k][2]
+
+
+@pytest.mark.parametrize("mixed", [False, True], ids=["hex_128x64x64", "mixed_60x30x30"])
+def test_midsize_frozen_iteration_bit_exact_in_reference_order_and_product_default_within_the_association_scale(gpu, mixed):
+    """ONE whole SIMPLE iteration in the mode bench.py times — frozen diagonals: face_k<0>, momentum_k<false>, one-launch assembly, the whole
+    Multigrid arm — at 128 x 64 x 64 hex cells and on 159 510 mixed cells, against the oracle with frozen diagonals (solver.rs:60-222):
+    * with the dot products in nalgebra's association and no guard the device has the oracle's BITS (SHA-256 of u, v, w, p, report doubles);
+    * the product default (wave trees, guard) differs from that in the association of its sums only.  VERDICT r04 asked to hold 1e-6 here; one
+      iteration of the reference algorithm at this size does not allow it to ANY implementation that reassociates: the oracle against ITSELF
+      with pairwise sums moves u by 1.1e-4 / v 3e-5 / w 8e-6 / p 7e-5 relative L2 on the hex channel (`association_sensitivity` in the golden
+      file; r_hat_0 = 1 and no guard, linear_algebra.rs:252-268, tests/test_oracle_sensitivity.py).  Measured on the device: u 2.6e-4.  Bar: ten
+      times the oracle's own sensitivity per field (v, w against the scale of u), the guard silent."""
+    import hashlib
+    from orc_amd.linear_algebra import breakdown_guard_events
+    from orc_amd.mesh import Mesh
+    from orc_amd.settings import NumericalSettings
+    from orc_amd.solver import Solver
+    g, a = _midsize_arrays(mixed)
+    f0 = bench.initial_fields(np.asarray(a["cell_centroid"]))
+    dm = Mesh(a)
+    ro = g["report_frozen_1"]  # oracle: means 0-2, mean Peclet 3, velocity correction 4, pressure correction 5
+    s = Solver(dm, NumericalSettings.default(reduction_order=REFERENCE, frozen_diagonals=1, breakdown_guard=0, **BENCH_KW), 1000.0, 1e-3)
+    s.set_fields(*f0)
+    st, rep = s.iterate(1, report=True, raise_on_error=False)
+    assert st == 0
+    stride = int(g["stride_fields"])
+    for name, x in zip("uvwp", s.get_fields()):
+        x = np.ascontiguousarray(x)
+        ref = g["fields_sample_" + name]
+        worst = float(np.max(np.abs(x[::stride] - ref)) / max(np.max(np.abs(ref)), 1e-300))
+        assert hashlib.sha256(x.tobytes()).digest() == g["fields_sha256_" + name].tobytes(), \
+            "field %s differs from the frozen oracle in reference order (largest sampled difference %.3e of the field's scale)" % (name, worst)
+    assert same_bits(np.array([rep[0][k] for k in (0, 1, 2, 3, 6, 7)]), ro), (rep[0], ro)
+    del s
+    ev0 = breakdown_guard_events()
+    s = Solver(dm, NumericalSettings.default(**BENCH_KW), 1000.0, 1e-3)
+    s.set_fields(*f0)
+    st, rep = s.iterate(1, report=True, raise_on_error=False)
+    assert st == 0 and breakdown_guard_events() == ev0
+    scale_u = float(np.linalg.norm(g["fields_sample_u"]))
+    for k, (name, x) in enumerate(zip("uvwp", s.get_fields())):
+        ref = g["fields_sample_" + name]
+        scale = float(np.linalg.norm(ref)) if name in "up" else scale_u
+        err = float(np.linalg.norm(x[::stride] - ref)) / scale
+        bar = 10.0 * float(g["association_sensitivity"][k])
+        assert err <= bar, "field %s: relative L2 over the samples %.3e, bar %.3e" % (name, err, bar)
+    sens = g["association_sensitivity_report"]
+    assert abs(rep[0][6] - ro[4]) <= 10 * sens[4] * ro[4] and abs(rep[0][7] - ro[5]) <= 10 * sens[5] * ro[5], (rep[0], ro)
