@@ -30,7 +30,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s mea
 REF_CELLS = 400 * 160 * 160
 
 
-def initial_fields(cc, dp_dx=5.0, h=1e-3, mu=1e-3, lx=0.002, seed=0x4F5243, x0=0.0, lx_total=None):
+def initial_fields(cc, dp_dx=5.0, h=1e-3, mu=1e-3, lx=0.002, seed=0x4F5243, x0=0.0, lx_total=None, ids=None):
     """Analytical Poiseuille profile (tests.rs:26-29) with a 1e-6 relative splitmix64 perturbation (nothing is
     exactly zero or exactly equal between neighbours) and the matching linear pressure drop.  A rougher start
     (percent-level cell-to-cell noise = large mass imbalance per cell) makes the reference algorithm itself
@@ -39,10 +39,11 @@ def initial_fields(cc, dp_dx=5.0, h=1e-3, mu=1e-3, lx=0.002, seed=0x4F5243, x0=0
     n = len(cc)
     y = cc[:, 1]
     lx_total = lx_total or lx
-    u = 1.0 / (2.0 * mu) * dp_dx * (y * y - h * y) * (1.0 + 1e-6 * splitmix64_uniform(n, seed))
-    v = 1e-12 * splitmix64_uniform(n, seed + 1)
-    w = 1e-12 * splitmix64_uniform(n, seed + 2)
-    p = -dp_dx * lx_total * (1.0 - (cc[:, 0] + x0) / lx_total) * (1.0 + 1e-6 * splitmix64_uniform(n, seed + 3))
+    # ids (global cell ids of a rank's cells): the perturbation of the WHOLE mesh's cell, so that a strong-scaling run starts from the N = 1 field
+    u = 1.0 / (2.0 * mu) * dp_dx * (y * y - h * y) * (1.0 + 1e-6 * splitmix64_uniform(n, seed, ids))
+    v = 1e-12 * splitmix64_uniform(n, seed + 1, ids)
+    w = 1e-12 * splitmix64_uniform(n, seed + 2, ids)
+    p = -dp_dx * lx_total * (1.0 - (cc[:, 0] + x0) / lx_total) * (1.0 + 1e-6 * splitmix64_uniform(n, seed + 3, ids))
     return u, v, w, p
 
 
@@ -114,19 +115,47 @@ def spawn_ranks(n):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
     env.setdefault("OMP_NUM_THREADS", "1")
-    if env.get("ORC_BENCH_HOST_TRANSPORT") == "1":
-        # the rehearsal with several ranks on ONE GPU: two processes with four hardware queues each and the lock-step schedule's
-        # main -> three lanes -> main event chain stalled the GPU's queue scheduler (r04: reproducible with 4 and 8 queues per process,
-        # never with 2, never with one process per GPU): keep the rehearsal to two hardware queues per process
-        env.setdefault("GPU_MAX_HW_QUEUES", "2")
-    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True, bufsize=1)
-    line = None
-    for out in proc.stdout:  # rank 0 prints exactly one JSON line; anything else a rank writes to stdout goes to our stderr
-        if out.startswith('{"metric"'):
-            line = out
+    # a rank that makes no progress for this many seconds prints its stacks and the library's stream states and EXITS non-zero (Watchdog
+    # below): a first multi-GPU run that stalls must not end as a silent time-out of whoever started it
+    env.setdefault("ORC_BENCH_WATCHDOG", str(WATCHDOG_DEFAULT_S))
+    # (r04 set GPU_MAX_HW_QUEUES=2 here for ranks sharing one card; the library now keeps such ranks' streams in one priority class —
+    # runtime.cpp, stream_create — which is the cause that setting worked around: DESIGN.md §7)
+    import signal
+    # the ranks get a session (= process group) of their own: whatever ends this launcher — a time-out's SIGTERM, Ctrl-C, an exception —
+    # takes torch.distributed.run AND the ranks with it; nothing is left holding the GPU
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True, bufsize=1, start_new_session=True)
+
+    def end_group(sig):
+        try:
+            os.killpg(proc.pid, sig)
+        except (ProcessLookupError, PermissionError):
+            pass
+
+    def forward(signum, _frame):
+        end_group(signal.SIGTERM)
+        raise SystemExit(128 + signum)
+
+    old = {sg: signal.signal(sg, forward) for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP)}
+    line, rc = None, 1
+    try:
+        for out in proc.stdout:  # rank 0 prints exactly one JSON line; anything else a rank writes to stdout goes to our stderr
+            if out.startswith('{"metric"'):
+                line = out
+            else:
+                sys.stderr.write(out)
+        rc = proc.wait()
+    finally:
+        if proc.poll() is None:  # we are leaving early: end the whole group, politely, then for good
+            end_group(signal.SIGTERM)
+            try:
+                proc.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                end_group(signal.SIGKILL)
+                proc.wait()
         else:
-            sys.stderr.write(out)
-    rc = proc.wait()
+            end_group(signal.SIGKILL)  # the launcher is gone; a rank that outlived it (it should not) goes too
+        for sg, h in old.items():
+            signal.signal(sg, h)
     if line is not None:
         sys.stdout.write(line)
         sys.stdout.flush()
@@ -134,6 +163,79 @@ def spawn_ranks(n):
         sys.stderr.write("bench.py: the ranks ended without a result line\n")
         rc = 1
     return rc
+
+
+WATCHDOG_DEFAULT_S = 240  # N > 1: seconds without progress (mesh set-up, a spin-up iteration, a step) after which a rank reports and exits
+
+
+class Watchdog:
+    """A timer thread that is re-armed at every sign of progress (`kick`).  When it fires the rank writes to stderr: the Python stack of every
+    thread (the main one sits in a ctypes call of the library), how many hardware queues the process holds (KFD sysfs, when readable), and which
+    of the library's streams still hold work (orc_debug_stream_report: hipStreamQuery, never blocks) — then EXITS with code 3.  No restart, no
+    re-exec: a process that has touched the GPU ends, its launcher sees a failed rank and ends the others."""
+
+    def __init__(self, seconds, rank):
+        self.seconds, self.rank, self.timer, self.where = seconds, rank, None, "start"
+
+    def kick(self, where):
+        import threading
+        self.where = where
+        if self.timer is not None:
+            self.timer.cancel()
+        if self.seconds > 0:
+            self.timer = threading.Timer(self.seconds, self.bark)
+            self.timer.daemon = True
+            self.timer.start()
+
+    def stop(self):
+        if self.timer is not None:
+            self.timer.cancel()
+            self.timer = None
+
+    def bark(self):
+        import faulthandler
+        err = sys.stderr
+        err.write("[bench watchdog r%d] no progress for %d s after '%s'\n" % (self.rank, self.seconds, self.where))
+        faulthandler.dump_traceback(file=err, all_threads=True)
+        err.write("[bench watchdog r%d] %s\n" % (self.rank, hardware_queue_note()))
+        # the stream report calls into the HIP runtime, which may itself wait for a lock the stuck call holds (seen: hipStreamQuery beside a
+        # hipStreamSynchronize that never returns): ask from a helper thread and give it five seconds — the exit below does not depend on it
+        import threading
+
+        def report():
+            try:
+                import ctypes
+                lib = sys.modules["orc_amd._lib"].lib()
+                buf = ctypes.create_string_buffer(8192)
+                busy = lib.orc_debug_stream_report(buf, len(buf))
+                err.write("[bench watchdog r%d] library streams (%d busy):\n%s" % (self.rank, busy, buf.value.decode()))
+            except Exception as e:  # the library may not be loaded yet
+                err.write("[bench watchdog r%d] no stream report (%r)\n" % (self.rank, e))
+
+        th = threading.Thread(target=report, daemon=True)
+        th.start()
+        th.join(5.0)
+        if th.is_alive():
+            err.write("[bench watchdog r%d] the stream report itself did not return within 5 s (the HIP runtime is waiting too)\n" % self.rank)
+        err.flush()
+        os._exit(3)
+
+
+def hardware_queue_note():
+    """user-mode queues of this process as the kernel driver lists them (compute + SDMA), for the watchdog and the N > 1 result line"""
+    d = "/sys/class/kfd/kfd/proc/%d/queues" % os.getpid()
+    try:
+        qs = os.listdir(d)
+        kinds = {}
+        for q in qs:
+            try:
+                t = open(os.path.join(d, q, "type")).read().strip()
+            except OSError:
+                t = "?"
+            kinds[t] = kinds.get(t, 0) + 1
+        return "KFD queues of pid %d: %d %s (GPU_MAX_HW_QUEUES=%s)" % (os.getpid(), len(qs), kinds, os.environ.get("GPU_MAX_HW_QUEUES", "unset: 4 per priority class"))
+    except OSError as e:
+        return "KFD queue list not readable (%s)" % e.__class__.__name__
 
 
 def main():
@@ -152,6 +254,9 @@ def main():
     ap.add_argument("--inner", type=int, default=50, help="matrix_solver.iterations (lib.rs:80)")
     ap.add_argument("--momentum-relaxation", type=float, default=0.1)
     ap.add_argument("--pressure-relaxation", type=float, default=0.001)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="N > 1: weak (default, what the driver's scaling run times) = every rank owns "
+                    "an nx x ny x nz slab of an N times deeper channel; strong = the SAME nx x ny x nz mesh cut into N z-slabs (BASELINE configs[3]'s "
+                    "'1 and 2x MI355X' on one ~10 M-cell mesh)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--spmv-reps", type=int, default=50)
     ap.add_argument("--levels-csv", default=None, help="write the per-level product table (profiles/rNN_levels.csv)")
@@ -173,9 +278,9 @@ def main():
         raise SystemExit(spawn_ranks(args.gpus))
     if world != args.gpus:
         raise SystemExit("bench.py --gpus %d inside a torch.distributed.run of %d ranks: the two must agree" % (args.gpus, world))
-    if os.environ.get("ORC_BENCH_WATCHDOG"):  # debugging aid: after N seconds a rank prints its Python stacks and exits (a stuck collective shows itself)
-        import faulthandler
-        faulthandler.dump_traceback_later(int(os.environ["ORC_BENCH_WATCHDOG"]), exit=True)
+    # N > 1: on by default (a launcher that is not ours — the driver's torch.distributed.run — gets it too); ORC_BENCH_WATCHDOG=0 switches it off
+    wd = Watchdog(int(os.environ.get("ORC_BENCH_WATCHDOG", WATCHDOG_DEFAULT_S if world > 1 else 0)), rank)
+    wd.kick("start")
 
     dist = None
     if world > 1:
@@ -183,6 +288,7 @@ def main():
         import torch.distributed as dist
         dist.init_process_group(backend="gloo")  # control plane only; the data path uses RCCL inside liborc_amd
     if args.dry_run:
+        time.sleep(float(os.environ.get("ORC_BENCH_DRY_RUN_SLEEP", "0")))  # (tests: a rank that hangs — for the watchdog and for the launcher's clean-up)
         seen = world
         if dist is not None:
             t = torch.tensor([1.0], dtype=torch.float64)
@@ -223,6 +329,13 @@ def main():
     settings = NumericalSettings.default(**settings_kw)
 
     nx, ny, nz = args.nx, args.ny, args.nz
+    strong = args.scaling == "strong" and world > 1
+    if strong:
+        # the same nx x ny x nz mesh on every N: rank r owns layers [r nz / N, (r + 1) nz / N) (+ ghost layers); the generators need whole (config 5:
+        # even) layer counts per rank
+        if nz % world or (args.workload == "config5" and (nz // world) % 2):
+            raise SystemExit("bench.py --scaling strong: nz = %d does not cut into %d %sslabs" % (nz, world, "even " if args.workload == "config5" else ""))
+        nz = nz // world
     t_setup = time.perf_counter()
     mixed_facts = None
     if args.workload == "config5":
@@ -238,9 +351,9 @@ def main():
         nnz = mesh.nnz
     else:
         from orc_amd import parallel
-        solver, mesh, n_cells_total, nnz = parallel.make_slab_solver(nx, ny, nz, rank, world, settings, initial_fields)
-    del_a = None
+        solver, mesh, n_cells_total, nnz = parallel.make_slab_solver(nx, ny, nz, rank, world, settings, initial_fields, global_noise=strong)
     t_setup = time.perf_counter() - t_setup
+    wd.kick("mesh and solver set-up")
 
     def barrier_sync():
         orc_amd._lib.check(orc_amd._lib.lib().orc_synchronize())
@@ -266,6 +379,7 @@ def main():
         if st_ != 0:
             raise SystemExit("bench.py: spin-up iteration failed with status %d" % st_)
         trajectory.append([float(rep_[0][k]) for k in (0, 1, 2, 6, 7)])
+        wd.kick("spin-up iteration %d" % (_ + 1))
     solver.snapshot()
     from orc_amd.linear_algebra import breakdown_guard_events
     guard_before = breakdown_guard_events()
@@ -280,6 +394,7 @@ def main():
             last = rep_[0]
             if record:
                 step_ms.append((time.perf_counter() - ts) * 1e3)  # iterate() ends with a host sync
+            wd.kick("%s step %d" % ("timed" if record else "warm-up", _ + 1))
             if st_ != 0:
                 status = st_
                 break
@@ -287,9 +402,15 @@ def main():
 
     if args.warmup > 0:
         run(args.warmup, False)
+    coll_before = 0
+    if dist is not None:
+        import ctypes
+        orc_amd._lib.lib().orc_debug_collectives.restype = ctypes.c_longlong
+        coll_before = int(orc_amd._lib.lib().orc_debug_collectives(0))
     barrier_sync()
     t0 = time.perf_counter()
     st, last_rep = run(args.steps, True)
+    dt_local = time.perf_counter() - t0  # this rank's own view (the line's ms_per_step is the slowest rank's, barriers included)
     barrier_sync()
     dt = time.perf_counter() - t0
     rep = np.array([last_rep]) if last_rep is not None else None
@@ -299,6 +420,34 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    wd.kick("timed region")
+    multi = None
+    if dist is not None:
+        # what a first multi-GPU run must be able to say about itself (VERDICT r04 #6b): did N ranks run on N cards, how evenly, through how many
+        # collectives, with how large a halo — gathered over the control plane, reported by rank 0
+        import ctypes
+        L = orc_amd._lib.lib()
+        L.orc_debug_collectives.restype = ctypes.c_longlong
+        buf = ctypes.create_string_buffer(256)
+        dev_info = buf.value.decode() if L.orc_device_info(buf, len(buf)) == 0 else "?"
+        fb, tb = ctypes.c_int64(0), ctypes.c_int64(0)
+        orc_amd._lib.check(L.orc_device_memory(ctypes.byref(fb), ctypes.byref(tb)))
+        halo = getattr(mesh, "halo", None) or {}
+        sp_ = [int(x) for x in halo.get("send_ptr", [0])]
+        mine = {"rank": rank, "device": dev_info, "hbm_used_gb": round((tb.value - fb.value) / 1e9, 1), "ms_per_step": round(dt_local / args.steps * 1e3, 2),
+                "owned_cells": int(getattr(mesh, "n_owned", mesh.n_cells)), "ghost_cells": int(mesh.n_cells - getattr(mesh, "n_owned", mesh.n_cells)),
+                "peers": [int(q) for q in halo.get("peers", [])],
+                "halo_bytes_per_field_and_exchange": [8 * (b - a_) for a_, b in zip(sp_[:-1], sp_[1:])],
+                "collectives_in_timed_region": int(L.orc_debug_collectives(0)) - coll_before, "hardware_queues": hardware_queue_note()}
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+        ms_all = [r_["ms_per_step"] for r_ in allr]
+        multi = {"ranks": allr, "distinct_devices": len({r_["device"] for r_ in allr}),
+                 "ms_per_step_min_max_over_ranks": [min(ms_all), max(ms_all)],
+                 "collectives_per_iteration": allr[0]["collectives_in_timed_region"] / float(max(args.steps, 1)),
+                 "collectives_definition": "halo exchanges + all-reduces (status agreements included) the library issued per SIMPLE iteration on rank 0 "
+                                           "(orc_debug_collectives), timed steps only",
+                 "watchdog_s": wd.seconds}
     guard_events_timed = breakdown_guard_events() - guard_before  # solves of the warm-up + timed steps the breakdown guard froze
     # device memory in use by the timed run (before the measurement legs below build a hierarchy of their own)
     import ctypes
@@ -360,6 +509,7 @@ def main():
         gs.update({"kernel": "gs_color_sorted_k (level 0: the smoother's general sweep; gsx_sweep0_k belongs to the bicgstab_gs solver)",
                    "avg_sweep_ms": gs_ms, "avg_launch_ms": gs_ms / max(gs_colors, 1), "algorithmic_bytes_per_sweep": gs_bytes,
                    "achieved": gs_bytes / (gs_ms * 1e-3) / 1e9, "frac": gs_bytes / (gs_ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
+    nz_total = args.nz if strong else nz * world  # layers of the whole mesh
     key = (args.nx, args.ny, args.nz, args.momentum, args.solver)
     workload_name = ("BASELINE configs[3]" if key == (400, 160, 160, "umist", "multigrid")
                      else "BASELINE configs[3] as its text reads (AMG V-cycle with a GS smoother: an extension, ORC's smoother is BiCGSTAB)" if key == (400, 160, 160, "umist", "multigrid_gs")
@@ -367,6 +517,8 @@ def main():
     mixed = args.workload == "config5"
     if mixed:
         workload_name = "BASELINE configs[4]" if (key[:3] == (252, 100, 72) and args.solver == "multigrid") else "custom (BASELINE configs[4] family)"
+    if strong:
+        workload_name += " on %dx MI355X (strong scaling: ONE %dx%dx%d mesh cut into %d z-slabs)" % (world, nx, ny, nz_total, world)
     bicg_bytes = 2.0 * spmv_bytes + 104.0 * n_local
     # Memory-side traffic per launch from the PMC counters (TCC_EA0_RDREQ by request size + TCC_EA0_WRREQ, separate rocprofv3
     # --pmc passes: scripts/gpu_pmc_r02.sh; equal to FETCH_SIZE x 2 + WRITE_SIZE of MI355X_MICROARCH.md §HBM for this
@@ -388,9 +540,10 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         units = n_cells_total / float(REF_CELLS)  # 10.24M-cell SIMPLE iterations per step (N at weak scaling)
         if mixed:
-            units = float(world)  # one slab of nz block layers per rank: slab-iterations per step
+            units = 1.0 if strong else float(world)  # one slab of nz block layers per rank: slab-iterations per step (strong: the one mesh)
         out = {
             "metric": ("SIMPLE iterations/s (10.24M-cell hex channel equivalents; = iterations/s at N=1)" if not mixed else
+                       ("SIMPLE iterations/s of ONE %dx%dx%d-block mixed tet/hex/poly mesh cut into N slabs" % (nx, ny, nz_total)) if strong else
                        "SIMPLE iterations/s (mixed tet/hex/poly slab equivalents: N x iterations/s, one %dx%dx%d-block slab per GPU)" % (nx, ny, nz)),
             "value": units * args.steps / dt,
             "unit": "iterations/s",
@@ -399,8 +552,11 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
-            "scaling_definition": ("weak: every rank owns a %dx%dx%d slab of a %dx%dx(%d*N) channel cut along z; value = N x (10.24M-cell SIMPLE "
+            "scaling": "strong" if strong else "weak",
+            "scaling_definition": ("strong: the same %dx%dx%d mesh on every N, cut along z into N slabs of %d layers (one ghost layer per inner side%s); value = "
+                                   "SIMPLE iterations per second of that one mesh%s" % (nx, ny, nz_total, nz, ", two for the mixed mesh" if mixed else "",
+                                                                                        " in 10.24M-cell equivalents" if not mixed else "")) if strong else
+                                  ("weak: every rank owns a %dx%dx%d slab of a %dx%dx(%d*N) channel cut along z; value = N x (10.24M-cell SIMPLE "
                                    "iterations per second), i.e. cells processed per second / 10.24M" % (nx, ny, nz, nx, ny, nz)) if not mixed else
                                   ("weak: every rank generates and owns %d block layers of a %dx%dx(%d*N)-block mixed channel cut along z (cells by centroid; "
                                    "two generated ghost layers per inner side, no process holds the whole mesh); value = N x SIMPLE iterations per second"
@@ -463,6 +619,7 @@ def main():
                 "gauss_seidel_sweep": gs,
             },
             "amg_levels": levels,
+            "multi_gpu": multi,
             "report_last": [float(x) for x in rep[-1]] if rep is not None and len(rep) else None,
             "report_trajectory": {"columns": ["u_mean", "v_mean", "w_mean", "velocity_correction_norm", "pressure_correction_norm"],
                                   "spin_up": trajectory,
@@ -472,6 +629,7 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(settings_kw, iters=3 if mixed else 6, mixed_ref_cells=(n_cells_total // world) if mixed else None)
         print(json.dumps(out), flush=True)
+    wd.stop()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -35,6 +35,9 @@ int orc_synchronize(void);                     /* hipStreamSynchronize on the li
 const char *orc_status_string(int status);     /* the reference's panic text for the code */
 const char *orc_last_error(void);              /* detail of the last ORC_ERR_HIP / BAD_ARGUMENT */
 int orc_device_memory(int64_t *free_bytes, int64_t *total_bytes); /* hipMemGetInfo of the library's device */
+/* "<device name> | pci <domain:bus:device.function> | ordinal <n> | <CUs> CUs" of the library's device: a multi-GPU run reports it per rank,
+ * so that "did N ranks run on N different cards" is answered by the result itself.  Returns ORC_ERR_BAD_ARGUMENT when cap is too small. */
+int orc_device_info(char *buf, int cap);
 void orc_settings_default(OrcSettings *s);     /* NumericalSettings::default() + MatrixSolverSettings::default(), lib.rs:58-86 */
 
 /* ---------- mesh::Mesh (mesh.rs:140-187) ---------- */
@@ -307,6 +310,9 @@ int orc_debug_set_spmv_variant(int variant);
 /* Test hook: how many level-0 products of partitioned operators this thread has run in the overlapped form (interior rows
  * on a second stream beside the halo exchange, rows along the cuts after it) since orc_init. */
 long long orc_debug_halo_overlaps(void);
+/* Which of the library's streams still hold work — hipStreamQuery, never blocks; meant for a watchdog thread while the calling thread of a
+ * solve waits: one line per stream, "<name>[<lane>] priority <p> busy|idle".  Returns the number of busy streams (-1: buffer too short). */
+int orc_debug_stream_report(char *buf, int cap);
 /* test hook: products launched on a length-sorted image of a coarse level (XSortDev) since the process started */
 long long orc_debug_xsort_products(void);
 /* [r04] test hooks.  orc_debug_clamp_partials_grid: the ONE function through which every launcher sizes a grid whose workgroups

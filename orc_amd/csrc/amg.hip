@@ -2066,6 +2066,122 @@ __global__ void agg_verify_k(MatView A, const int *__restrict__ choice, const in
     if (bad) atomicAdd(&C->changed, bad);  // rare: a verified pairing has none
 }
 
+// ------------------------------------------------------------------ the pairing by deferred acceptance [r05]
+// The reference's loop (linear_algebra.rs:30-60) is a SERIAL DICTATORSHIP: row i takes the column it prefers most — value ascending, position
+// ascending: the strict <, first-wins scan, with the diagonal, NaNs and Float::MAX left out — among the columns no EARLIER row holds.  Give every
+// column the same priority order over the rows (the lower index wins) and that allocation is the unique stable matching, which row-proposing
+// deferred acceptance reaches from ANY order of proposals: a row proposes down its list; a column keeps the lowest row that ever proposed to it;
+// a row that loses a column (rejected at once, or displaced later by a lower row) goes on to ITS next preference and never back up — a column,
+// once held, is held by ever lower rows.  The whole mutable state is holder[j] = the lowest row that has proposed to column j, and one
+// returning atomicMin IS a proposal: it returns a lower row -> rejected; a higher one -> accepted, and that row is displaced and becomes the
+// lane's next proposer; nobody -> the chain ends.  A displaced row's next column needs no per-row state: it is the preference after the column
+// just lost.  One lane per row starts a chain; the chains of the channel (a triangle of displaced rows at the end of every grid line: DESIGN §6)
+// are followed by the lanes that run into them, thousands at a time, each step two dependent accesses (the atomic, the next row's preference
+// list) instead of r02-r04's versioned first-taker repairs (three returning atomics + two store completions per step, 38 GB of look-ups per
+// hierarchy).  No fences: holder is touched by device-scope atomics only, everything else is read-only while the kernel runs.
+// r02-r04's machinery (slice sweeps, lock-step rounds, cascades) stays as the fallback for a pairing the verification pass rejects or a
+// chain that exceeds the step budget — neither has been seen (scripts/analysis/deferred_acceptance.py: the argument, checked on the CPU).
+struct DaCounters {
+    int overflow;  // chains cut off by the step budget (the fallback then runs)
+    int scans;     // proposals that had to scan their row (the preference list was exhausted): statistics
+    int steps;     // proposals in all: statistics
+    int changed;   // (AggCounters layout for the verification pass is separate; this one is the kernel's own)
+};
+
+// A look at the holder table before proposing: holder[j] only ever DECREASES, so a value below r — however stale the copy a plain load returns
+// — means the proposal would be rejected, and the row passes the column by without an atomic.  (A stale copy errs towards "free": the atomic
+// that follows is the authority.)  Relaxed agent-scope loads: past the vector L1, which would never show another CU's atomics.
+__device__ __forceinline__ int da_peek(const int *holder, int j) { return __hip_atomic_load(holder + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// The first column in row r's order of preference BEHIND column `after` (value, then position; after < 0: from the top) that no lower row is
+// seen to hold — by a scan of the row: the list (kPrefs entries) did not reach that far.  One pass per call, every taken column passed by.
+__device__ __noinline__ int da_scan_next(const MatView &A, int64_t r, int after, const int *holder) {
+    const int len = A.P.row_len[r];
+    const RowWalk W(A, r);
+    int k_c = -1;
+    double v_c = 0.;
+    if (after >= 0) {
+        for (int k = 0; k < len; ++k)
+            if (W.column(k) == after) { k_c = k; break; }
+        if (k_c < 0) return -1;  // (cannot happen: `after` came from this row)
+        v_c = W.value(A, r, k_c);
+    }
+    double best = 1.7976931348623157e308;  // Float::MAX: an entry that is not below it is never chosen (nor a NaN)
+    int bj = -1;
+    for (int k = 0; k < len; ++k) {
+        const int j = W.column(k);
+        if (j == r || j >= A.P.n) continue;
+        const double a = W.value(A, r, k);
+        if (k_c >= 0 && !(a > v_c || (a == v_c && k > k_c))) continue;  // at or before `after` in the order of preference
+        if (!(a < best)) continue;                                        // strict <: the earlier position wins among equals
+        if (da_peek(holder, j) < (int)r) continue;                        // held by a lower row: passed by
+        best = a; bj = j;
+    }
+    return bj;
+}
+
+// the next column row r proposes to: the first listed preference behind `after` that is not seen to be held by a lower row, else the scan
+__device__ __forceinline__ int da_next_pref(const MatView &A, const int4 pl, int64_t r, int after, const int *holder, int &scans) {
+    static_assert(kPrefs == 4, "da_next_pref reads the four listed preferences as one int4");
+    const int p[4] = {pl.x, pl.y, pl.z, pl.w >= 0 ? (pl.w & ~kPrefMore) : -1};
+    const bool more = pl.w >= 0 && (pl.w & kPrefMore) != 0;
+    int first = 0;  // index of the first listed preference behind `after`
+    if (after >= 0) {
+        first = 4;
+#pragma unroll
+        for (int q = 3; q >= 0; --q)
+            if (p[q] == after) first = q + 1;
+        if (first == 4 && after != p[3]) { ++scans; return da_scan_next(A, r, after, holder); }  // `after` lies beyond the list already
+    }
+    int h[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) h[q] = (q >= first && p[q] >= 0) ? da_peek(holder, p[q]) : 0x7fffffff;  // (independent loads: they travel together)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (q < first) continue;
+        if (p[q] < 0) return -1;          // the list held every candidate and ends here
+        if (h[q] >= (int)r) return p[q];
+    }
+    if (!more) return -1;
+    ++scans;
+    return da_scan_next(A, r, p[3], holder);
+}
+
+__global__ __launch_bounds__(kBlock) void da_propose_k(MatView A, const int *__restrict__ prefs, int *holder, DaCounters *C, int max_steps) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A.P.n) return;
+    const int4 *pl4 = reinterpret_cast<const int4 *>(prefs);
+    int64_t r = i;
+    int4 pl = pl4[r];
+    int steps = 0, scans = 0;
+    bool cut = false;
+    int cand = da_next_pref(A, pl, r, -1, holder, scans);
+    while (cand >= 0) {
+        const int old = atomicMin(&holder[cand], (int)r);  // the proposal
+        ++steps;
+        int after = cand;
+        if (old > (int)r) {
+            if (old == 0x7fffffff) break;  // the column was free: the chain ends here
+            r = old;                       // accepted; `old` is displaced and proposes next, from the column it has just lost on
+            pl = pl4[r];
+        }
+        if (steps >= max_steps) { cut = true; break; }
+        cand = da_next_pref(A, pl, r, after, holder, scans);
+    }
+    if (cut) atomicAdd(&C->overflow, 1);
+    if (scans) atomicAdd(&C->scans, scans);
+    if (steps > 1) atomicAdd(&C->steps, steps - 1);  // (statistics: proposals beyond a chain's first)
+}
+
+// holder -> the pairing: chooser[j] = the row that holds column j (-1: nobody), choice[that row] = j (choice preset to -1)
+__global__ void da_finish_k(const int *__restrict__ holder, int *__restrict__ choice, int *__restrict__ chooser, int64_t n) {
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
+        const int h = holder[j];
+        chooser[j] = h == 0x7fffffff ? -1 : h;
+        if (h != 0x7fffffff) choice[h] = (int)j;  // a row holds one column at most
+    }
+}
+
 SiblingPairing::~SiblingPairing() {
     for (auto &e : ready)
         if (e) (void)hipEventDestroy(e);
@@ -2236,14 +2352,45 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
     // saves no look-up, only the row's own lines, and still pays: 767.0 / 768.5 / 757.5 -> 758.9 / 761.5 / 759.1 ms against lists from 12 on).  Per call.
     int *prefs = nullptr;
     const int prefs_min_len = getenv("ORC_AMG_PREFS_MIN_LEN") ? atoi(getenv("ORC_AMG_PREFS_MIN_LEN")) : 5;
-    if (!(getenv("ORC_AMG_PREFS") && atoi(getenv("ORC_AMG_PREFS")) == 0) && n > 0 && A.P.padded >= (int64_t)prefs_min_len * n) {
+    const bool da_on = !(getenv("ORC_AMG_DA") && atoi(getenv("ORC_AMG_DA")) == 0) && !warm && n > 0;  // (deferred acceptance proposes from the lists: always built then)
+    if (da_on || (!(getenv("ORC_AMG_PREFS") && atoi(getenv("ORC_AMG_PREFS")) == 0) && n > 0 && A.P.padded >= (int64_t)prefs_min_len * n)) {
         ORC_TRY(arena.alloc((size_t)n * kPrefs, &prefs));
         hipLaunchKernelGGL(agg_init_prefs_k, dim3(g), dim3(kBlock), 0, st, A, choice, act_a, act_b, prefs);
     } else
     hipLaunchKernelGGL(agg_init_k, dim3(g), dim3(kBlock), 0, st, A, choice, act_a, act_b);  // also resets the slice flags
+    static const bool trace_t = getenv("ORC_AMG_TRACE") != nullptr;
+    // [r05] the pairing by deferred acceptance (above): one launch of proposals, the pairing read off the holder table, ONE verification pass and
+    // ONE host read.  ORC_AMG_DA=0 (read per call: the tests compare the forms): r04's sweeps + lock-step rounds + cascades.
+    if (prefs && da_on) {
+        DaCounters *D;
+        ORC_TRY(arena.alloc((size_t)1, &D));
+        ORC_HIP(hipMemsetAsync(D, 0, sizeof(DaCounters), st));
+        hipLaunchKernelGGL(agg_reset_k, dim3(g), dim3(kBlock), 0, st, taken_by, n);  // holder = taken_by: nobody
+        const int da_steps = getenv("ORC_AMG_DA_STEPS") ? std::max(1, atoi(getenv("ORC_AMG_DA_STEPS"))) : (1 << 20);  // (a test cuts the chains short: the fallback must finish the job)
+        hipLaunchKernelGGL(da_propose_k, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, A, (const int *)prefs, taken_by, D, da_steps);
+        ORC_HIP(hipMemsetAsync(choice, 0xff, sizeof(int) * (size_t)n, st));
+        hipLaunchKernelGGL(da_finish_k, dim3(g), dim3(kBlock), 0, st, (const int *)taken_by, choice, chooser, n);
+        // is it the fixed point?  every row against the exact first-taker table (= holder): the sequential pairing is the only state that passes
+        hipLaunchKernelGGL(agg_verify_k, dim3(g), dim3(kBlock), 0, st, A, (const int *)choice, (const int *)taken_by, C);
+        ORC_HIP(hipGetLastError());
+        AggCounters hc;
+        DaCounters hd;
+        ORC_HIP(hipMemcpyAsync(&hc, C, sizeof(hc), hipMemcpyDeviceToHost, st));
+        ORC_HIP(hipMemcpyAsync(&hd, D, sizeof(hd), hipMemcpyDeviceToHost, st));
+        ORC_HIP(hipStreamSynchronize(st));
+        if (trace_t) fprintf(stderr, "[amg da n=%lld] proposals beyond the first %d, row scans %d, chains cut %d, rows that would change %d\n", (long long)n, hd.steps, hd.scans, hd.overflow, hc.changed);
+        if (hd.overflow == 0 && hc.changed == 0) {
+            g_cert_aggregations.fetch_add(1, std::memory_order_relaxed);  // certified by one pass that changed nothing
+            g_cert_rounds.fetch_add(1, std::memory_order_relaxed);
+            if (rounds_out) *rounds_out = 1;
+            return ORC_OK;
+        }
+        // not the fixed point (a cut chain; never seen otherwise): r04's machinery from the arg-min state
+        ORC_HIP(hipMemsetAsync(C, 0, sizeof(AggCounters), st));
+        hipLaunchKernelGGL(agg_init_prefs_k, dim3(g), dim3(kBlock), 0, st, A, choice, act_a, act_b, prefs);
+    }
     if (warm) ORC_HIP(hipMemcpyAsync(choice, warm, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, st));
     int rounds = 0;
-    static const bool trace_t = getenv("ORC_AMG_TRACE") != nullptr;
     double t_mark = 0.;
     auto lap = [&](const char *what) {  // trace only: wall time of the phase that just ended (drains the stream)
         if (!trace_t) return;
@@ -2388,6 +2535,7 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
                 const double avg_len = n > 0 ? (double)stored / (double)n : 0.;
                 group = avg_len <= 14. ? 16 : (avg_len <= 28. ? 32 : 64);
             }
+            group = group <= 16 ? 16 : (group <= 32 ? 32 : 64);  // the instantiated widths: the kernel and chase_carry_k must agree on the groups per launch
             int launches = 0, first_list = -1, list0 = -1;
             if (trace) {  // the list the first lock-step round left
                 TailCounters h0;

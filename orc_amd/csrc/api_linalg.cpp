@@ -101,7 +101,7 @@ int orc_iterative_solve3(int64_t n, const int64_t *row_ptr, const int64_t *col_i
         SiblingPairing sibling;
         hipStream_t streams[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         for (int k = 0; k < 6 && st == ORC_OK; ++k)
-            if (hipStreamCreateWithFlags(&streams[k], hipStreamNonBlocking) != hipSuccess) st = set_error(ORC_ERR_HIP, "hipStreamCreate failed");
+            st = stream_create(&streams[k], kPlainStream, k, "solve3");
         for (int k = 0; k < 3; ++k) {
             lanes[k].setup_stream = streams[2 * k]; lanes[k].solve_stream = streams[2 * k + 1];
             lanes[k].hier_arena = &hier[k]; lanes[k].vec_arena = &vec[k]; lanes[k].scratch_arena = &scratch[k];
@@ -113,7 +113,7 @@ int orc_iterative_solve3(int64_t n, const int64_t *row_ptr, const int64_t *col_i
             st = multigrid_arm3_dev(A3, bb, xx, iteration_count, relaxation_factor, convergence_threshold, preconditioner, arena, lanes, &sibling, st3);
         (void)hipDeviceSynchronize();
         for (int k = 0; k < 6; ++k)
-            if (streams[k]) (void)hipStreamDestroy(streams[k]);
+            if (streams[k]) stream_destroy(streams[k]);
     }
     for (int k = 0; k < 3; ++k) {
         const int st2 = dx[k].download(solution_vectors[k], (size_t)n);

@@ -1130,43 +1130,12 @@ int k_apply_correction(SolverState &s, double *sums_host) {
     return ORC_OK;
 }
 
-// Streams of the concurrent solves: set-up streams (dependent rounds of tiny kernels, each waited for by the host) get the
-// highest priority the device offers so that their kernels do not queue behind the other streams' products; the
-// streams that carry the bandwidth-bound solves get the lowest.  ORC_STREAM_PRIORITIES: 0 = none, 1 = one class per
-// lane (measured: about the same), 2 = this scheme (default).  1.34 -> 1.24 s per iteration.
-enum { kSetupStream = 0, kSolveStream = 100 };
+// Streams of the concurrent solves: set-up streams (dependent rounds of tiny kernels, each waited for by the host) and solve streams (the
+// bandwidth-bound products) get different priority classes — stream_create (runtime.cpp) decides, and knows when it must not.
+// [r04] measurement: ORC_SETUP_CU_MASK (a 32-bit hex pattern repeated over the device's CU mask words) confined the set-up streams to a share
+// of the CUs: all settings within +-1 %; removed in r05 with the other measured-and-dropped switches.
 static int create_stream(hipStream_t *out, int role, int lane) {
-    // 3 (default): solve streams above set-up streams — since the round-2 set-up rework the solves are the critical path of
-    // the momentum phase (measured: 0.863-0.879 s per iteration against 0.903-0.909 s with 2, the round-1 setting that
-    // favoured the then latency-bound set-up, and 0.926-0.957 s without priorities); 1: by lane; 0: none
-    static const int prio_mode = getenv("ORC_STREAM_PRIORITIES") ? atoi(getenv("ORC_STREAM_PRIORITIES")) : 3;
-    // [r04] measurement: confine the SET-UP streams to a share of the CUs (ORC_SETUP_CU_MASK = a 32-bit hex pattern repeated over the
-    // device's CU mask words, e.g. 55555555 = every other CU of every XCD), so that the bandwidth-bound products beside them keep at
-    // least the rest of the chip to themselves; the solve streams stay unmasked.  (A masked stream has no priority class.)
-    static const char *mask_env = getenv("ORC_SETUP_CU_MASK");
-    if (mask_env && role == kSetupStream) {
-        const uint32_t pat = (uint32_t)strtoul(mask_env, nullptr, 16);
-        if (pat != 0u) {
-            uint32_t words[16];
-            for (int i = 0; i < 16; ++i) words[i] = pat;
-            hipDeviceProp_t prop;
-            int dev = 0;
-            int n_cu = 256;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
-            ORC_HIP(hipExtStreamCreateWithCUMask(out, (uint32_t)std::min(16, (n_cu + 31) / 32), words));
-            return ORC_OK;
-        }
-    }
-    int least = 0, greatest = 0;
-    if (prio_mode != 0 && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) {
-        int klass = prio_mode == 1 ? lane : (role == kSolveStream ? 2 : 0);
-        if (prio_mode == 3) klass = role == kSolveStream ? 0 : 2;  // the other way round: products first
-        const int prio = klass == 0 ? greatest : (klass == 2 ? least : (least + greatest) / 2);
-        ORC_HIP(hipStreamCreateWithPriority(out, hipStreamNonBlocking, prio));
-        return ORC_OK;
-    }
-    ORC_HIP(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
-    return ORC_OK;
+    return stream_create(out, role, lane, role == kSolveStream ? "solve" : "set-up");
 }
 
 static int solve_field_on(SolverState &s, DevBuf<double> &a, DevBuf<double> &b, DevBuf<double> &x, int eq, Arena &arena, SolveStats &stats,
@@ -1191,7 +1160,10 @@ static int solve_field_on(SolverState &s, DevBuf<double> &a, DevBuf<double> &b, 
     stats.hierarchy = prepared ? prepared : ((eq == 3 && s.p_hierarchy.n_levels > 0) ? &s.p_hierarchy : nullptr);
     if (side && s.two_stream_multigrid && t.solver_type == ORC_SOLVER_MULTIGRID) {
         if (!side->stream) {
-            ORC_TRY(create_stream(&side->stream, kSolveStream, eq < 3 ? eq : 1));
+            // the side stream and the stream of this solve wait for each other's events level by level (side_wait_setup / setup_wait_side): they
+            // share a class — "a stream only waits for its own class or a higher one" (runtime.cpp, stream_create)
+            const int role = stream_role(ctx().stream) == kSetupStream ? kSetupStream : kSolveStream;
+            ORC_TRY(create_stream(&side->stream, role, eq < 3 ? eq : 1));
             ORC_HIP(hipEventCreateWithFlags(&side->ev_setup, hipEventDisableTiming));
             ORC_HIP(hipEventCreateWithFlags(&side->ev_solve, hipEventDisableTiming));
             side->arena = side_arena;
@@ -1207,7 +1179,7 @@ static int solve_field(SolverState &s, DevBuf<double> &a, DevBuf<double> &b, Dev
 }
 
 static void destroy_side(SolveSide &d) {
-    if (d.stream) (void)hipStreamDestroy(d.stream);
+    if (d.stream) stream_destroy(d.stream);
     if (d.ev_setup) (void)hipEventDestroy(d.ev_setup);
     if (d.ev_solve) (void)hipEventDestroy(d.ev_solve);
     d = SolveSide();
@@ -1215,12 +1187,12 @@ static void destroy_side(SolveSide &d) {
 
 SolverState::~SolverState() {
     for (auto &l : lanes) {
-        if (l.stream) (void)hipStreamDestroy(l.stream);
+        if (l.stream) stream_destroy(l.stream);
         if (l.level0_done) (void)hipEventDestroy(l.level0_done);
         destroy_side(l.side);
     }
     destroy_side(side);
-    if (prep_stream) (void)hipStreamDestroy(prep_stream);
+    if (prep_stream) stream_destroy(prep_stream);
 }
 
 // Runs in a host thread of its own beside the momentum solves: the p' matrix from the fresh momentum diagonals (the
@@ -1637,9 +1609,12 @@ int solver_iterate(SolverState &s, uint64_t iterations, double *report) {
         const bool lanes_partitioned = s.concurrent_momentum && H.active() && !dbg && !ctx().profile && method == ORC_SOLVER_MULTIGRID;
         // [r04] the lock-step schedule also on a partitioned mesh (tree reductions there by construction): N > 1 runs the schedule of the
         // N = 1 headline, with a third of the momentum phase's halo exchanges and all-reduces (ORC_TRIPLE_MOMENTUM=0: one system per solve)
-        const bool triple_part = s.concurrent_momentum && H.active() && !dbg && !ctx().profile && s.triple_momentum && triple_supported() &&
+        // (the schedule — hence the SEQUENCE OF COLLECTIVES of a rank — is decided from this solver's settings and the mesh alone, never from
+        // the thread context's reduction order, which is whatever the last solve left there: ADVICE r04.  A partitioned mesh reduces as
+        // trees whatever the settings say; solve_momentum_triple puts that into the context itself.)
+        const bool triple_part = s.concurrent_momentum && H.active() && !dbg && !ctx().profile && s.triple_momentum &&
                                  (method == ORC_SOLVER_MULTIGRID || method == ORC_SOLVER_BICGSTAB);
-        const bool triple_ok = (lanes_ok && s.triple_momentum && triple_supported() && s.settings.reduction_order != ORC_REDUCTION_REFERENCE &&
+        const bool triple_ok = (lanes_ok && s.triple_momentum && s.settings.reduction_order != ORC_REDUCTION_REFERENCE &&
                                 (method == ORC_SOLVER_MULTIGRID || method == ORC_SOLVER_BICGSTAB ||
                                  (method == ORC_SOLVER_BICGSTAB_GS_PRECOND && gs_slot_space_enabled()))) || triple_part;
         // The p' hierarchy is needed after the momentum solves.  Beside the per-system lanes it is built from the start; in the

@@ -85,11 +85,13 @@ __global__ void halo_pack_k(const double *__restrict__ x, const int32_t *__restr
 
 // C1: neighbour halo exchange of k fields.
 bool comm_host_transport_active() { return g_host_ex != nullptr; }
+// The host-staged transport exists for one thing: several ranks of a job on ONE card (RCCL refuses duplicate devices).
+bool device_shared_between_ranks() { return g_host_ex != nullptr; }
 
 HaloPlan::~HaloPlan() {
     if (ev_ready) (void)hipEventDestroy((hipEvent_t)ev_ready);
     if (ev_done) (void)hipEventDestroy((hipEvent_t)ev_done);
-    if (aux_stream) (void)hipStreamDestroy((hipStream_t)aux_stream);
+    if (aux_stream) stream_destroy((hipStream_t)aux_stream);
 }
 
 int HaloPlan::exchange(double *const *xs, int k) {

@@ -78,6 +78,17 @@ int set_error(int code, const char *fmt, ...);
 
 int ensure_init();
 
+// Every stream the library creates goes through these two (runtime.cpp) — one place decides the priority class, and a registry knows what
+// exists: orc_debug_stream_report tells a watchdog which streams still hold work (a stall must name its stream).
+// role: the set-up streams carry dependent rounds of small kernels, the solve streams the bandwidth-bound products (classes: DESIGN §6).
+enum StreamRole { kSetupStream = 0, kSolveStream = 100, kPlainStream = 200 };
+int stream_create(hipStream_t *out, int role, int lane, const char *name);
+void stream_destroy(hipStream_t st);
+int stream_role(hipStream_t st);  // the role a stream was created with (kPlainStream for a stream the library did not create)
+// true when several ranks of this job share ONE device (the host-staged rehearsal transport: comm.cpp): every stream then lives in one
+// priority class, see stream_create
+bool device_shared_between_ranks();
+
 // Device buffer with explicit lifetime (no hipMalloc inside timed loops: see Arena).
 template <class T>
 struct DevBuf {

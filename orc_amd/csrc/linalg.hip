@@ -436,7 +436,7 @@ static int launch_spmv(const MatView &A_in, const double *x, const Epi &epi, dou
         if (!H->aux_stream) {
             hipStream_t st2;
             hipEvent_t e1, e2;
-            ORC_HIP(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
+            ORC_TRY(stream_create(&st2, kSolveStream, 0, "halo-overlap"));
             ORC_HIP(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
             ORC_HIP(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
             H->aux_stream = st2; H->ev_ready = e1; H->ev_done = e2;
@@ -1022,7 +1022,7 @@ static int launch_spmv3(const MatView3 &A_in, const double *x3, const Epi3 &epi,
         if (!H->aux_stream) {
             hipStream_t st2;
             hipEvent_t e1, e2;
-            ORC_HIP(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
+            ORC_TRY(stream_create(&st2, kSolveStream, 0, "halo-overlap"));
             ORC_HIP(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
             ORC_HIP(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
             H->aux_stream = st2; H->ev_ready = e1; H->ev_done = e2;

@@ -1,6 +1,7 @@
 // runtime.cpp — process-wide context (device, stream, error text), arena allocator.
 #include <algorithm>
 #include <cstdarg>
+#include <mutex>
 
 #include "common.hpp"
 
@@ -28,6 +29,71 @@ int set_error(int code, const char *fmt, ...) {
     va_end(ap);
     ctx().last_error = buf;
     return code;
+}
+
+// ------------------------------------------------------------------ streams
+// Priority classes, and the one rule about them [r05].  HIP keeps one pool of hardware queues PER PRIORITY CLASS (GPU_MAX_HW_QUEUES = 4 each);
+// a stream that waits for another stream's event is a barrier packet PARKED at the head of its hardware queue.  r04 put the solve streams in the
+// highest class, the set-up streams in the lowest and left the library stream — which carries the level-0 / level-1 solves and records the
+// events the solve lanes wait for — in the default class BETWEEN them: the lock-step schedule (multigrid_arm3_dev) parks three top-class
+// queues on an event that sits behind some hundred kernels of a LOWER class.  One process per card got away with it; two processes on one
+// card (the host-transport rehearsal) stalled for good: eight parked top-class queues and the command processor never came round to the
+// default-class queue that would release them.  Established by experiment (scripts/gpu_r05_b.sh, gpu_r05_c.sh; 40x26x16 slabs, two ranks):
+//   classes as in r04, 4 queues per class: stalls (3 of 3 runs; also with the p' set-up moved) — 3 or 2 queues per class: runs;
+//   set-up class ABOVE the solve class, or classes by lane: runs;  ONE class with 4, 8, 16 queues per process: runs.
+// So it is neither the number of queues nor of streams, it is the DIRECTION of the wait: a higher class parked on a lower one — priority
+// inversion, with the hardware scheduler as the party that never yields.  The rule: a stream only ever waits (hipStreamWaitEvent) for streams
+// of its own class or a higher one.  The library stream and the halo-overlap stream therefore live in the SOLVE class (they are solve
+// streams); the set-up streams, which are joined by their host threads and wait for nobody, stay below.  And ranks that share one card get
+// ONE class altogether: the rehearsal gains nothing from classes.
+struct StreamEntry { hipStream_t st; std::string name; int priority; int role; };
+static std::mutex g_streams_mu;
+static std::vector<StreamEntry> g_streams;
+
+static void stream_register(hipStream_t st, const char *name, int priority, int role) {
+    std::lock_guard<std::mutex> lk(g_streams_mu);
+    g_streams.push_back(StreamEntry{st, name ? name : "?", priority, role});
+}
+
+int stream_role(hipStream_t st) {
+    std::lock_guard<std::mutex> lk(g_streams_mu);
+    for (const auto &e : g_streams)
+        if (e.st == st) return e.role;
+    return kPlainStream;
+}
+
+int stream_create(hipStream_t *out, int role, int lane, const char *name) {
+    // ORC_STREAM_PRIORITIES: 3 (default) = solve streams above set-up streams — since the round-2 set-up rework the solves are the critical
+    // path of the momentum phase (0.863-0.879 s per iteration against 0.903-0.909 s with 2 = set-up above solve and 0.926-0.957 s with 0 =
+    // no classes, r02); 1 = one class per lane
+    static const int prio_env = getenv("ORC_STREAM_PRIORITIES") ? atoi(getenv("ORC_STREAM_PRIORITIES")) : 3;
+    // ORC_DEBUG_KEEP_PRIORITY_CLASSES=1 (scripts/gpu_r05_b.sh only): the r04 behaviour — classes even when ranks share the card — to reproduce the stall
+    static const bool keep_classes = getenv("ORC_DEBUG_KEEP_PRIORITY_CLASSES") && atoi(getenv("ORC_DEBUG_KEEP_PRIORITY_CLASSES")) != 0;
+    const int prio_mode = (role == kPlainStream || (device_shared_between_ranks() && !keep_classes)) ? 0 : prio_env;
+    int least = 0, greatest = 0, prio = 0;
+    bool with_prio = false;
+    if (prio_mode != 0 && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) {
+        int klass = prio_mode == 1 ? lane : (role == kSolveStream ? 2 : 0);
+        if (prio_mode == 3) klass = role == kSolveStream ? 0 : 2;  // products first
+        prio = klass == 0 ? greatest : (klass == 2 ? least : (least + greatest) / 2);
+        with_prio = true;
+    }
+    if (with_prio) ORC_HIP(hipStreamCreateWithPriority(out, hipStreamNonBlocking, prio));
+    else ORC_HIP(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
+    char full[96];
+    snprintf(full, sizeof(full), "%s[%d]", name ? name : "stream", lane);
+    stream_register(*out, full, with_prio ? prio : 0, role);
+    return ORC_OK;
+}
+
+void stream_destroy(hipStream_t st) {
+    if (!st) return;
+    {
+        std::lock_guard<std::mutex> lk(g_streams_mu);
+        for (size_t i = 0; i < g_streams.size(); ++i)
+            if (g_streams[i].st == st) { g_streams.erase(g_streams.begin() + (long)i); break; }
+    }
+    (void)hipStreamDestroy(st);
 }
 
 int ensure_init() {
@@ -123,8 +189,8 @@ int orc_init(int device_ordinal) {
     if (device_ordinal < 0) device_ordinal = 0;
     if (device_ordinal >= n) return orc::set_error(ORC_ERR_BAD_ARGUMENT, "device %d out of range (%d visible)", device_ordinal, n);
     ORC_HIP(hipSetDevice(device_ordinal));
-    if (c.stream) { (void)hipStreamDestroy(c.stream); c.stream = nullptr; }
-    ORC_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    if (c.stream) { orc::stream_destroy(c.stream); c.stream = nullptr; }
+    ORC_TRY(orc::stream_create(&c.stream, orc::kSolveStream, 0, "library"));  // a solve stream: stream_create, "the one rule"
     c.device = device_ordinal;
     if (c.guard_events) { (void)hipFree(c.guard_events); c.guard_events = nullptr; }
     ORC_HIP(hipMalloc((void **)&c.guard_events, sizeof(int)));
@@ -147,6 +213,19 @@ int orc_device_memory(int64_t *free_bytes, int64_t *total_bytes) {
     ORC_HIP(hipMemGetInfo(&f, &t));
     if (free_bytes) *free_bytes = (int64_t)f;
     if (total_bytes) *total_bytes = (int64_t)t;
+    return ORC_OK;
+}
+
+int orc_device_info(char *buf, int cap) {
+    ORC_TRY(orc::ensure_init());
+    if (!buf || cap <= 0) return orc::set_error(ORC_ERR_BAD_ARGUMENT, "null argument");
+    hipDeviceProp_t prop;
+    char bus[64] = "?";
+    const int dev = orc::ctx().device;
+    ORC_HIP(hipGetDeviceProperties(&prop, dev));
+    (void)hipDeviceGetPCIBusId(bus, (int)sizeof(bus), dev);
+    const int w = snprintf(buf, (size_t)cap, "%s | pci %s | ordinal %d | %d CUs", prop.name, bus, dev, prop.multiProcessorCount);
+    if (w < 0 || w >= cap) return orc::set_error(ORC_ERR_BAD_ARGUMENT, "orc_device_info: buffer of %d bytes is too small", cap);
     return ORC_OK;
 }
 
@@ -235,6 +314,27 @@ int orc_debug_xwin_counters(long long out[3], int reset) {
     if (!out) return orc::set_error(ORC_ERR_BAD_ARGUMENT, "null argument");
     ORC_TRY(orc::ensure_init());
     return orc::debug_xwin_counters(out, reset != 0);
+}
+
+// Which of the library's streams still hold work (hipStreamQuery: never blocks), one line each: "<name> priority <p> busy|idle".  Meant for a
+// watchdog thread while the calling thread of a solve hangs in a synchronisation; returns the number of busy streams, -1 on a short buffer.
+int orc_debug_stream_report(char *buf, int cap) {
+    if (!buf || cap <= 0) return -1;
+    std::vector<orc::StreamEntry> copy;
+    {
+        std::lock_guard<std::mutex> lk(orc::g_streams_mu);
+        copy = orc::g_streams;
+    }
+    int busy = 0, off = 0;
+    for (const auto &e : copy) {
+        const hipError_t q = hipStreamQuery(e.st);
+        const char *state = q == hipSuccess ? "idle" : (q == hipErrorNotReady ? "busy" : hipGetErrorString(q));
+        if (q == hipErrorNotReady) ++busy;
+        const int w = snprintf(buf + off, (size_t)(cap - off), "%s priority %d %s\n", e.name.c_str(), e.priority, state);
+        if (w < 0 || w >= cap - off) return -1;
+        off += w;
+    }
+    return busy;
 }
 
 int orc_profile_enable(int on) {

@@ -53,9 +53,10 @@ class MeshArrays(dict):
         self["zone_vector"][k] = vector
 
 
-def splitmix64_uniform(n, seed=0x4F5243):
-    """uniform[-1,1) f64 from splitmix64, seed "ORC" (SURVEY §8d synthetic inputs); vectorised, stateless."""
-    idx = np.arange(1, n + 1, dtype=np.uint64)
+def splitmix64_uniform(n, seed=0x4F5243, ids=None):
+    """uniform[-1,1) f64 from splitmix64, seed "ORC" (SURVEY §8d synthetic inputs); vectorised, stateless.
+    ids: the stream positions (0-based) to evaluate instead of 0 .. n-1 — a rank's cells by their GLOBAL ids get the whole mesh's numbers."""
+    idx = np.arange(1, n + 1, dtype=np.uint64) if ids is None else np.asarray(ids, dtype=np.uint64) + np.uint64(1)
     with np.errstate(over="ignore"):
         z = np.uint64(seed) + idx * np.uint64(0x9E3779B97F4A7C15)
         z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)

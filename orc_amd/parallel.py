@@ -307,16 +307,48 @@ def finalize():
 
 
 # ------------------------------------------------------------------ bench helper
-def make_slab_solver(nx, ny, nz, rank, world, settings, initial_fields):
-    """Weak scaling: every rank owns an nx x ny x nz slab of the (nx, ny, nz*world) channel."""
+def make_slab_solver(nx, ny, nz, rank, world, settings, initial_fields, global_noise=False):
+    """Every rank owns an nx x ny x nz slab of the (nx, ny, nz*world) channel (weak scaling: nz fixed; strong: nz = the mesh's layers / world).
+    global_noise: the initial fields' perturbation is taken by GLOBAL cell id — the run starts from exactly the one-rank field of that channel."""
     from .solver import Solver
     a, halo, gids = slab_arrays(nx, ny, nz, rank, world)
     set_channel_bcs(a)
     mesh = PartitionedMesh(a, halo)
-    u, v, w, p = initial_fields(np.asarray(a["cell_centroid"]))
+    u, v, w, p = initial_fields(np.asarray(a["cell_centroid"]), ids=gids) if global_noise else initial_fields(np.asarray(a["cell_centroid"]))
     solver = Solver(mesh, settings, 1000.0, 1e-3)
     solver.set_fields(u, v, w, p)
     return solver, mesh, halo["n_global"], mesh.nnz
+
+
+def verify_ghost_geometry(a, halo, dist, rank, tol):
+    """One exchange of geometry over the control plane: every rank sends centroid x, y, z and volume of the cells on its send lists and
+    compares what arrives with ITS OWN copy of those cells (its ghost blocks).  The rank-local generators (mixed_slab_arrays) rely on
+    neighbouring ranks numbering the cells they share in the same relative order, which orc_mesh_partition_owner cannot check (ADVICE r04);
+    a ghost block in another order would still exchange the right NUMBER of values — and couple the wrong cells.  Raises on a mismatch."""
+    peers = [int(q) for q in halo["peers"]]
+    if not peers:
+        return 0.0
+    sp, si, rp = (np.asarray(halo[k], dtype=np.int64) for k in ("send_ptr", "send_idx", "recv_ptr"))
+    n_own = int(halo["n_owned"])
+    cc, vol = np.asarray(a["cell_centroid"]), np.asarray(a["cell_volume"])
+    worst, failure = 0.0, None
+    for comp in range(4):  # (every rank goes through all four exchanges whatever it finds: a rank that left early would strand its peers)
+        f = np.ascontiguousarray(cc[:, comp] if comp < 3 else vol, dtype=np.float64)
+        send = f[si]
+        recv = np.empty(int(rp[-1]))
+        exchange_over_dist(dist, rank, peers, send, [int(x) for x in sp[:-1]], [int(x) for x in np.diff(sp)], recv, [int(x) for x in rp[:-1]],
+                           [int(x) for x in np.diff(rp)])
+        mine = f[n_own:n_own + len(recv)]
+        scale = max(float(np.max(np.abs(mine))) if len(mine) else 0.0, 1e-300)
+        err = float(np.max(np.abs(recv - mine))) / scale if len(mine) else 0.0
+        worst = max(worst, err)
+        if err > tol and failure is None:
+            bad = int(np.argmax(np.abs(recv - mine)))
+            failure = ("rank %d: ghost cell %d (local %d) is not the cell its owner sends: %s %r here, %r there (relative %.3e > %.1e) — the "
+                       "ranks number their shared cells differently" % (rank, bad, n_own + bad, "xyzV"[comp], float(mine[bad]), float(recv[bad]), err, tol))
+    if failure:
+        raise RuntimeError(failure)
+    return worst
 
 
 def make_mixed_slab_solver(nx, ny, nz, rank, world, settings, initial_fields, dist=None, polyhedra=True):
@@ -337,11 +369,12 @@ def make_mixed_slab_solver(nx, ny, nz, rank, world, settings, initial_fields, di
         dist.all_reduce(t)
         n_global = int(t.item())
     halo["n_global"] = n_global
+    ghost_check = verify_ghost_geometry(a, halo, dist, rank, 1e-9) if world > 1 else None  # (slabs are generated in shifted boxes: equal to rounding, not to the bit)
     nfc = np.diff(np.asarray(a["cell_face_ptr"])[:halo["n_owned"] + 1])
     host_bytes = sum(np.asarray(v).nbytes for v in sub.values() if isinstance(v, np.ndarray)) + sum(np.asarray(v).nbytes for v in a.values() if isinstance(v, np.ndarray))
     facts = dict(generated_cells=int(sub.n_cells), owned_cells=int(halo["n_owned"]), ghost_cells=int(len(a["cell_volume"]) - halo["n_owned"]),
                  faces_per_cell={int(k): int(v) for k, v in zip(*np.unique(nfc, return_counts=True))}, generation_s=round(t_gen, 2),
-                 host_arrays_gb=round(host_bytes / 1e9, 2))
+                 host_arrays_gb=round(host_bytes / 1e9, 2), ghost_geometry_check=ghost_check)
     del sub
     if world > 1:
         mesh = PartitionedMesh(a, halo)

@@ -153,6 +153,17 @@ def mixed_slab_checks(rank, world, nx=20, ny=4, nzl=2):
     parallel.exchange_over_dist(dist, rank, peers, send, list(sp[:-1]), list(np.diff(sp)), recv, list(rp[:-1]), list(np.diff(rp)))
     x[n_own:] = recv
     assert np.array_equal(x, truth[gids]), "ghost values differ from the owners'"
+    # the runtime check bench.py's config-5 entry makes (parallel.verify_ghost_geometry: geometry of the send lists against the ghost blocks,
+    # one exchange over the control plane) passes — and catches a ghost block in another order
+    assert parallel.verify_ghost_geometry(a, halo, dist, rank, 1e-9) < 1e-9
+    assert len(gids) - n_own >= 2
+    twisted = MeshArrays({k: (np.array(v, copy=True) if isinstance(v, np.ndarray) else v) for k, v in a.items()})
+    twisted["cell_centroid"][[n_own, n_own + 1]] = twisted["cell_centroid"][[n_own + 1, n_own]]
+    try:
+        parallel.verify_ghost_geometry(twisted, halo, dist, rank, 1e-9)
+        raise AssertionError("two swapped ghost cells went unnoticed")
+    except RuntimeError as e:
+        assert "number their shared cells differently" in str(e)
     # distributed product on the local pattern (ghost columns included) == global product
     m = c1g >= 0
     A_glob = sps.csr_matrix((1.0 + 0.001 * np.arange(2 * m.sum()), (np.r_[c0g[m], c1g[m]], np.r_[c1g[m], c0g[m]])), shape=(ng, ng)).tocsr()
@@ -368,6 +379,7 @@ def gpu_mixed_slab_checks(rank, world):
     dist.all_reduce(t)
     halo["n_global"] = int(t.item())
     assert halo["n_global"] == ag.n_cells
+    assert parallel.verify_ghost_geometry(a, halo, dist, rank, 1e-9) < 1e-9
     dd, gids = cKDTree(np.asarray(ag["cell_centroid"])).query(np.asarray(a["cell_centroid"]))
     assert dd.max() < 1e-12
     ug = global_fields(ag)

@@ -50,14 +50,16 @@ def test_aggregation_and_galerkin_bit_exact(gpu, oracle, shape):
     assert rounds >= 1
 
 
-@pytest.mark.parametrize("env", [{"ORC_AMG_CHASE": "0"}, {"ORC_AMG_CHASE_STEPS": "2", "ORC_AMG_CHASE_LAUNCHES": "2"},
-                                 {"ORC_AMG_CHASE_GROUP": "16"}, {"ORC_AMG_CHASE_GROUP": "64", "ORC_AMG_CHASE_GRID": "8"},
-                                 {"ORC_AMG_CHASE_STEPS": "1", "ORC_AMG_CHASE_GRID": "8", "ORC_AMG_CHASE_LAUNCHES": "100000"},
+@pytest.mark.parametrize("env", [{"ORC_AMG_DA": "0"}, {"ORC_AMG_DA_STEPS": "3"}, {"ORC_AMG_DA": "0", "ORC_AMG_CHASE": "0"}, {"ORC_AMG_DA": "0", "ORC_AMG_CHASE_STEPS": "2", "ORC_AMG_CHASE_LAUNCHES": "2"},
+                                 {"ORC_AMG_DA": "0", "ORC_AMG_CHASE_GROUP": "64", "ORC_AMG_CHASE_GRID": "8"},
+                                 {"ORC_AMG_DA": "0", "ORC_AMG_CHASE_STEPS": "1", "ORC_AMG_CHASE_GRID": "8", "ORC_AMG_CHASE_LAUNCHES": "100000"},
                                  {"ORC_GALERKIN_SORT": "1"}, {"ORC_GALERKIN_GROUPS": "64,64,64,64"}, {"ORC_GALERKIN_GROUPS": "16,16,16,32"},
-                                 {"ORC_AMG_EVAL_GROUP": "16", "ORC_AMG_SWEEP_GROUP": "32"}, {"ORC_AMG_EVAL_GROUP": "8", "ORC_AMG_SWEEP_GROUP": "0"},
-                                 {"ORC_AMG_CHASE_GROUP": "-1", "ORC_AMG_SWEEP_GROUP": "4"}])
+                                 {"ORC_AMG_DA": "0", "ORC_AMG_EVAL_GROUP": "16", "ORC_AMG_SWEEP_GROUP": "32"}, {"ORC_AMG_DA": "0", "ORC_AMG_EVAL_GROUP": "8", "ORC_AMG_SWEEP_GROUP": "0"},
+                                 {"ORC_AMG_DA": "0", "ORC_AMG_CHASE_GROUP": "-1", "ORC_AMG_SWEEP_GROUP": "4"}])
 def test_set_up_forms_agree(gpu, monkeypatch, env):
-    """Every form of the set-up lands on the same pairing and the same coarse operator, bit for bit: lock-step rounds only;
+    """Every form of the set-up lands on the same pairing and the same coarse operator, bit for bit.  The default [r05] is the pairing by
+    deferred acceptance (da_propose_k: one launch of proposals); ORC_AMG_DA=0 is r04's machinery, which stays as the fallback — reached here by
+    cutting every chain of proposals after three steps (ORC_AMG_DA_STEPS=3).  r04's forms, behind ORC_AMG_DA=0: lock-step rounds only;
     a cascade phase cut off after two steps and two launches (the lock-step rounds finish the job); cascades followed by
     16- and by 64-lane groups on a tiny grid; one step per wavefront and launch on a tiny grid (every launch carries
     unclaimed rows and continuations over to the next); the Galerkin product by sorting and by merging with every group size;
@@ -100,7 +102,7 @@ def test_aggregation_dependency_chain(gpu, oracle):
     Rd = sp.coo_matrix((np.ones(len(rows)), (rows, cols)), shape=((n + 1) // 2, n)).tocsr()
     Rd.sum_duplicates()
     assert abs(Rd - R).max() == 0
-    assert rounds >= 2  # chains resolve inside a 64-row slice; one sweep per slice crossed
+    assert rounds >= 1  # (deferred acceptance: one lane follows the whole chain; r04's sweeps needed one round per slice crossed)
 
 
 def test_aggregation_asymmetric_pattern(gpu, oracle):

@@ -22,9 +22,8 @@ def launch(nproc, mode, timeout=600):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % nproc, "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.join(ROOT, "tests", "mp_worker.py"), mode]
     env = dict(os.environ, OMP_NUM_THREADS="1")
-    # the GPU modes put several ranks on ONE card (host-staged transport): two hardware queues per process, or the queue scheduler can stall
-    # on the lock-step schedule's cross-stream event chains (never seen with one process per GPU)
-    env.setdefault("GPU_MAX_HW_QUEUES", "2")
+    # (the GPU modes put several ranks on ONE card through the host-staged transport; r04 capped their hardware queues here — the library now
+    # keeps such ranks' streams in one priority class by itself: runtime.cpp stream_create)
     return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
 
 
