@@ -372,6 +372,10 @@ int orc_mixed_channel_write_msh(const char *path, int64_t nx, int64_t ny, int64_
  * per-line node count of face_type 0 / 5 sections), no two cells sharing more than one face (discretization.rs:312-322). */
 int orc_poly_channel_write_msh(const char *path, int64_t nx, int64_t ny, int64_t nz, double lx, double ly, double lz,
                                int64_t *n_cells, int64_t *n_faces);
+/* [r05] The same mesh (polyhedra = 0: orc_mixed_channel_write_msh's, != 0: orc_poly_channel_write_msh's) built IN MEMORY: a handle as from
+ * orc_read_mesh whose every array equals, bit for bit, what reading the written file gives (same numbering, zones, geometry code) — without
+ * the 580 MB temporary file per rank that BASELINE configs[4] cost in r04.  NULL + *status on failure. */
+OrcMeshData *orc_mixed_channel_generate(int64_t nx, int64_t ny, int64_t nz, double lx, double ly, double lz, int polyhedra, int *status);
 
 /* ---------- multi-GPU (one process per GPU, RCCL over xGMI) ---------- */
 #define ORC_COMM_ID_BYTES 128

@@ -2083,94 +2083,117 @@ __global__ void agg_verify_k(MatView A, const int *__restrict__ choice, const in
 // chain that exceeds the step budget — neither has been seen (scripts/analysis/deferred_acceptance.py: the argument, checked on the CPU).
 struct DaCounters {
     int overflow;  // chains cut off by the step budget (the fallback then runs)
-    int scans;     // proposals that had to scan their row (the preference list was exhausted): statistics
-    int steps;     // proposals in all: statistics
-    int changed;   // (AggCounters layout for the verification pass is separate; this one is the kernel's own)
+    int steps;     // proposals made by da_chase_k: statistics
+    int list;      // rows the first pass left to the chains
+    int pad;
 };
 
-// A look at the holder table before proposing: holder[j] only ever DECREASES, so a value below r — however stale the copy a plain load returns
-// — means the proposal would be rejected, and the row passes the column by without an atomic.  (A stale copy errs towards "free": the atomic
+// A look at the holder table before proposing: holder[j] only ever DECREASES, so a value below r — however stale the copy a load returns —
+// means the proposal would be rejected, and the row passes the column by without an atomic.  (A stale copy errs towards "free": the atomic
 // that follows is the authority.)  Relaxed agent-scope loads: past the vector L1, which would never show another CU's atomics.
 __device__ __forceinline__ int da_peek(const int *holder, int j) { return __hip_atomic_load(holder + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// The first column in row r's order of preference BEHIND column `after` (value, then position; after < 0: from the top) that no lower row is
-// seen to hold — by a scan of the row: the list (kPrefs entries) did not reach that far.  One pass per call, every taken column passed by.
-__device__ __noinline__ int da_scan_next(const MatView &A, int64_t r, int after, const int *holder) {
+// First pass: one thread per row, the SELL image (lane = row: coalesced).  The row's most preferred column that no lower row is seen to hold
+// (agg_eval_row's scan with the holder table as the first-taker table) gets the row's proposal.  Whoever loses — the row itself, when a lower
+// row got in between the look and the atomic; or the higher row it displaces — goes on the list of the chains: (row, the column it lost on).
+__global__ __launch_bounds__(kBlock) void da_first_k(MatView A, int *holder, int2 *__restrict__ list, DaCounters *C) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int loser = -1, lost_on = -1;
+    if (i < A.P.n) {
+        const int len = A.P.row_len[i];
+        const int64_t base = A.P.slice_ptr[i >> 6] + (i & 63);
+        double best = 1.7976931348623157e308;  // Float::MAX
+        int bj = -1;
+        for (int k = 0; k < len; ++k) {
+            const int64_t pos = base + (int64_t)k * 64;
+            const int j = A.P.col[pos];
+            if (j == i || j >= A.P.n) continue;  // ghost columns (partitioned level 0) are never partners
+            const double a = view_value(A, i, pos);
+            if (!(a < best)) continue;
+            if (da_peek(holder, j) < (int)i) continue;
+            best = a; bj = j;
+        }
+        if (bj >= 0) {
+            const int old = atomicMin(&holder[bj], (int)i);
+            if (old < (int)i) { loser = (int)i; lost_on = bj; }
+            else if (old != 0x7fffffff) { loser = old; lost_on = bj; }
+        }
+    }
+    const int slot = wave_append_slot(&C->list, loser >= 0);
+    if (loser >= 0) list[slot] = make_int2(loser, lost_on);
+}
+
+// Row r's most preferred column BEHIND `after` in its order of preference (value, then position) that no lower row is seen to hold: G lanes
+// read the row G entries at a time (the row-contiguous mirror where the matrix has one) and reduce by (value, position) — the strict <,
+// first-wins scan of linear_algebra.rs:37-52 restricted to what the row has not been refused yet.  Every lane returns the column (-1: none).
+template <int G>
+__device__ __forceinline__ int da_group_next(const MatView &A, const int *holder, int64_t r, int after, int gl) {
     const int len = A.P.row_len[r];
     const RowWalk W(A, r);
+    // where `after` stands in the order
     int k_c = -1;
     double v_c = 0.;
-    if (after >= 0) {
-        for (int k = 0; k < len; ++k)
-            if (W.column(k) == after) { k_c = k; break; }
-        if (k_c < 0) return -1;  // (cannot happen: `after` came from this row)
-        v_c = W.value(A, r, k_c);
+    for (int k = gl; k < len; k += G)
+        if (W.column(k) == after) { k_c = k; v_c = W.value(A, r, k); }
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) {
+        const int ok = __shfl_xor(k_c, off, G);
+        const double ov = __shfl_xor(v_c, off, G);
+        if (ok > k_c) { k_c = ok; v_c = ov; }
     }
-    double best = 1.7976931348623157e308;  // Float::MAX: an entry that is not below it is never chosen (nor a NaN)
-    int bj = -1;
-    for (int k = 0; k < len; ++k) {
+    double best = 1.7976931348623157e308;  // Float::MAX
+    int bk = 0x7fffffff, bj = -1;
+    for (int k = gl; k < len; k += G) {
         const int j = W.column(k);
         if (j == r || j >= A.P.n) continue;
         const double a = W.value(A, r, k);
-        if (k_c >= 0 && !(a > v_c || (a == v_c && k > k_c))) continue;  // at or before `after` in the order of preference
-        if (!(a < best)) continue;                                        // strict <: the earlier position wins among equals
+        if (k_c >= 0 && !(a > v_c || (a == v_c && k > k_c))) continue;  // at or before `after`: refused already
+        if (!(a < best)) continue;                                        // (a lane's k ascend: strict < keeps the earlier position)
         if (da_peek(holder, j) < (int)r) continue;                        // held by a lower row: passed by
-        best = a; bj = j;
+        best = a; bk = k; bj = j;
+    }
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) {
+        const double ob = __shfl_xor(best, off, G);
+        const int ok = __shfl_xor(bk, off, G);
+        const int oj = __shfl_xor(bj, off, G);
+        if (ob < best || (ob == best && ok < bk)) { best = ob; bk = ok; bj = oj; }
     }
     return bj;
 }
 
-// the next column row r proposes to: the first listed preference behind `after` that is not seen to be held by a lower row, else the scan
-__device__ __forceinline__ int da_next_pref(const MatView &A, const int4 pl, int64_t r, int after, const int *holder, int &scans) {
-    static_assert(kPrefs == 4, "da_next_pref reads the four listed preferences as one int4");
-    const int p[4] = {pl.x, pl.y, pl.z, pl.w >= 0 ? (pl.w & ~kPrefMore) : -1};
-    const bool more = pl.w >= 0 && (pl.w & kPrefMore) != 0;
-    int first = 0;  // index of the first listed preference behind `after`
-    if (after >= 0) {
-        first = 4;
-#pragma unroll
-        for (int q = 3; q >= 0; --q)
-            if (p[q] == after) first = q + 1;
-        if (first == 4 && after != p[3]) { ++scans; return da_scan_next(A, r, after, holder); }  // `after` lies beyond the list already
-    }
-    int h[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) h[q] = (q >= first && p[q] >= 0) ? da_peek(holder, p[q]) : 0x7fffffff;  // (independent loads: they travel together)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        if (q < first) continue;
-        if (p[q] < 0) return -1;          // the list held every candidate and ends here
-        if (h[q] >= (int)r) return p[q];
-    }
-    if (!more) return -1;
-    ++scans;
-    return da_scan_next(A, r, p[3], holder);
-}
-
-__global__ __launch_bounds__(kBlock) void da_propose_k(MatView A, const int *__restrict__ prefs, int *holder, DaCounters *C, int max_steps) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= A.P.n) return;
-    const int4 *pl4 = reinterpret_cast<const int4 *>(prefs);
-    int64_t r = i;
-    int4 pl = pl4[r];
-    int steps = 0, scans = 0;
+// The chains: a group of G lanes takes a listed row and follows what its proposals set off — propose; if a higher row is displaced, go on as
+// that row — until a proposal meets a free column or a row runs out of candidates.  No state but the holder table; no group waits for another.
+template <int G>
+__global__ __launch_bounds__(kBlock) void da_chase_k(MatView A, int *holder, const int2 *__restrict__ list, DaCounters *C, int max_steps) {
+    const int gl = threadIdx.x & (G - 1);
+    const int64_t groups = ((int64_t)gridDim.x * blockDim.x) / G;
+    const int count = C->list;
+    int steps = 0;
     bool cut = false;
-    int cand = da_next_pref(A, pl, r, -1, holder, scans);
-    while (cand >= 0) {
-        const int old = atomicMin(&holder[cand], (int)r);  // the proposal
-        ++steps;
-        int after = cand;
-        if (old > (int)r) {
-            if (old == 0x7fffffff) break;  // the column was free: the chain ends here
-            r = old;                       // accepted; `old` is displaced and proposes next, from the column it has just lost on
-            pl = pl4[r];
+    for (int64_t e = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G; e < count; e += groups) {
+        const int2 it = list[e];
+        int64_t r = it.x;
+        int after = it.y;
+        for (int s = 0;; ++s) {
+            if (s >= max_steps) { cut = true; break; }
+            const int cand = da_group_next<G>(A, holder, r, after, gl);
+            if (cand < 0) break;  // the row has no candidate left: unmatched
+            int old = 0;
+            if (gl == 0) old = atomicMin(&holder[cand], (int)r);
+            old = __shfl(old, 0, G);
+            ++steps;
+            after = cand;
+            if (old > (int)r) {
+                if (old == 0x7fffffff) break;  // a free column: the chain ends
+                r = old;                       // accepted; `old` is displaced and goes on from the column it lost
+            }
         }
-        if (steps >= max_steps) { cut = true; break; }
-        cand = da_next_pref(A, pl, r, after, holder, scans);
     }
-    if (cut) atomicAdd(&C->overflow, 1);
-    if (scans) atomicAdd(&C->scans, scans);
-    if (steps > 1) atomicAdd(&C->steps, steps - 1);  // (statistics: proposals beyond a chain's first)
+    if (gl == 0) {
+        if (cut) atomicAdd(&C->overflow, 1);
+        if (steps) atomicAdd(&C->steps, steps);
+    }
 }
 
 // holder -> the pairing: chooser[j] = the row that holds column j (-1: nobody), choice[that row] = j (choice preset to -1)
@@ -2347,27 +2370,25 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
         ORC_HIP(hipMemsetAsync(C, 0, sizeof(AggCounters), st));
         warm = nullptr;  // not this matrix's pairing: from scratch
     }
-    // preference lists for the sweep's, the lock-step rounds' and the cascades' evaluations.  ORC_AMG_PREFS=0: every evaluation scans its row (r03);
-    // ORC_AMG_PREFS_MIN_LEN: stored entries per row from which on (5: every level of the channel — with the mesh pattern's 7 entries per row a list
-    // saves no look-up, only the row's own lines, and still pays: 767.0 / 768.5 / 757.5 -> 758.9 / 761.5 / 759.1 ms against lists from 12 on).  Per call.
-    int *prefs = nullptr;
-    const int prefs_min_len = getenv("ORC_AMG_PREFS_MIN_LEN") ? atoi(getenv("ORC_AMG_PREFS_MIN_LEN")) : 5;
-    const bool da_on = !(getenv("ORC_AMG_DA") && atoi(getenv("ORC_AMG_DA")) == 0) && !warm && n > 0;  // (deferred acceptance proposes from the lists: always built then)
-    if (da_on || (!(getenv("ORC_AMG_PREFS") && atoi(getenv("ORC_AMG_PREFS")) == 0) && n > 0 && A.P.padded >= (int64_t)prefs_min_len * n)) {
-        ORC_TRY(arena.alloc((size_t)n * kPrefs, &prefs));
-        hipLaunchKernelGGL(agg_init_prefs_k, dim3(g), dim3(kBlock), 0, st, A, choice, act_a, act_b, prefs);
-    } else
-    hipLaunchKernelGGL(agg_init_k, dim3(g), dim3(kBlock), 0, st, A, choice, act_a, act_b);  // also resets the slice flags
     static const bool trace_t = getenv("ORC_AMG_TRACE") != nullptr;
-    // [r05] the pairing by deferred acceptance (above): one launch of proposals, the pairing read off the holder table, ONE verification pass and
-    // ONE host read.  ORC_AMG_DA=0 (read per call: the tests compare the forms): r04's sweeps + lock-step rounds + cascades.
-    if (prefs && da_on) {
+    // [r05] the pairing by deferred acceptance (above): a coalesced first pass, the chains, the pairing read off the holder table, ONE
+    // verification pass and ONE host read.  ORC_AMG_DA=0 (read per call: the tests compare the forms): r04's sweeps + lock-step rounds + cascades.
+    const bool da_on = !(getenv("ORC_AMG_DA") && atoi(getenv("ORC_AMG_DA")) == 0) && !warm && n > 0;
+    if (da_on) {
+        ArenaScope da_scope(arena);  // the list is dead when the pairing is known
         DaCounters *D;
+        int2 *list;
         ORC_TRY(arena.alloc((size_t)1, &D));
+        ORC_TRY(arena.alloc((size_t)n, &list));
         ORC_HIP(hipMemsetAsync(D, 0, sizeof(DaCounters), st));
         hipLaunchKernelGGL(agg_reset_k, dim3(g), dim3(kBlock), 0, st, taken_by, n);  // holder = taken_by: nobody
-        const int da_steps = getenv("ORC_AMG_DA_STEPS") ? std::max(1, atoi(getenv("ORC_AMG_DA_STEPS"))) : (1 << 20);  // (a test cuts the chains short: the fallback must finish the job)
-        hipLaunchKernelGGL(da_propose_k, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, A, (const int *)prefs, taken_by, D, da_steps);
+        const int da_steps = getenv("ORC_AMG_DA_STEPS") ? std::max(1, atoi(getenv("ORC_AMG_DA_STEPS"))) : (1 << 22);  // (a test cuts the chains short: the fallback must finish the job)
+        hipLaunchKernelGGL(da_first_k, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, A, taken_by, list, D);
+        const int da_group = getenv("ORC_AMG_DA_GROUP") ? atoi(getenv("ORC_AMG_DA_GROUP")) : 16;
+        if (da_group == 4) hipLaunchKernelGGL(da_chase_k<4>, dim3(kMaxGrid), dim3(kBlock), 0, st, A, taken_by, (const int2 *)list, D, da_steps);
+        else if (da_group == 8) hipLaunchKernelGGL(da_chase_k<8>, dim3(kMaxGrid), dim3(kBlock), 0, st, A, taken_by, (const int2 *)list, D, da_steps);
+        else if (da_group == 32) hipLaunchKernelGGL(da_chase_k<32>, dim3(kMaxGrid), dim3(kBlock), 0, st, A, taken_by, (const int2 *)list, D, da_steps);
+        else hipLaunchKernelGGL(da_chase_k<16>, dim3(kMaxGrid), dim3(kBlock), 0, st, A, taken_by, (const int2 *)list, D, da_steps);
         ORC_HIP(hipMemsetAsync(choice, 0xff, sizeof(int) * (size_t)n, st));
         hipLaunchKernelGGL(da_finish_k, dim3(g), dim3(kBlock), 0, st, (const int *)taken_by, choice, chooser, n);
         // is it the fixed point?  every row against the exact first-taker table (= holder): the sequential pairing is the only state that passes
@@ -2378,17 +2399,25 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
         ORC_HIP(hipMemcpyAsync(&hc, C, sizeof(hc), hipMemcpyDeviceToHost, st));
         ORC_HIP(hipMemcpyAsync(&hd, D, sizeof(hd), hipMemcpyDeviceToHost, st));
         ORC_HIP(hipStreamSynchronize(st));
-        if (trace_t) fprintf(stderr, "[amg da n=%lld] proposals beyond the first %d, row scans %d, chains cut %d, rows that would change %d\n", (long long)n, hd.steps, hd.scans, hd.overflow, hc.changed);
+        if (trace_t) fprintf(stderr, "[amg da n=%lld] rows left to the chains %d, their proposals %d, chains cut %d, rows that would change %d\n", (long long)n, hd.list, hd.steps, hd.overflow, hc.changed);
         if (hd.overflow == 0 && hc.changed == 0) {
             g_cert_aggregations.fetch_add(1, std::memory_order_relaxed);  // certified by one pass that changed nothing
             g_cert_rounds.fetch_add(1, std::memory_order_relaxed);
             if (rounds_out) *rounds_out = 1;
             return ORC_OK;
         }
-        // not the fixed point (a cut chain; never seen otherwise): r04's machinery from the arg-min state
-        ORC_HIP(hipMemsetAsync(C, 0, sizeof(AggCounters), st));
-        hipLaunchKernelGGL(agg_init_prefs_k, dim3(g), dim3(kBlock), 0, st, A, choice, act_a, act_b, prefs);
+        ORC_HIP(hipMemsetAsync(C, 0, sizeof(AggCounters), st));  // not the fixed point (a cut chain; never seen otherwise): r04's machinery, from scratch
     }
+    // preference lists for the sweep's, the lock-step rounds' and the cascades' evaluations.  ORC_AMG_PREFS=0: every evaluation scans its row (r03);
+    // ORC_AMG_PREFS_MIN_LEN: stored entries per row from which on (5: every level of the channel — with the mesh pattern's 7 entries per row a list
+    // saves no look-up, only the row's own lines, and still pays: 767.0 / 768.5 / 757.5 -> 758.9 / 761.5 / 759.1 ms against lists from 12 on).  Per call.
+    int *prefs = nullptr;
+    const int prefs_min_len = getenv("ORC_AMG_PREFS_MIN_LEN") ? atoi(getenv("ORC_AMG_PREFS_MIN_LEN")) : 5;
+    if (!(getenv("ORC_AMG_PREFS") && atoi(getenv("ORC_AMG_PREFS")) == 0) && n > 0 && A.P.padded >= (int64_t)prefs_min_len * n) {
+        ORC_TRY(arena.alloc((size_t)n * kPrefs, &prefs));
+        hipLaunchKernelGGL(agg_init_prefs_k, dim3(g), dim3(kBlock), 0, st, A, choice, act_a, act_b, prefs);
+    } else
+    hipLaunchKernelGGL(agg_init_k, dim3(g), dim3(kBlock), 0, st, A, choice, act_a, act_b);  // also resets the slice flags
     if (warm) ORC_HIP(hipMemcpyAsync(choice, warm, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, st));
     int rounds = 0;
     double t_mark = 0.;

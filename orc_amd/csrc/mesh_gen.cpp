@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../../include/orc_amd.h"
+#include "mesh_raw.hpp"
 
 namespace {
 
@@ -295,9 +296,21 @@ enum BlockKind { kHexBlock, kPrismBlock, kTetBlock, kTransitionBlock, kPolyBlock
 // triangular faces, so that no two cells ever share more than one face (one matrix entry per interior face,
 // discretization.rs:312-322).
 int write_mixed_channel(const char *path, int64_t nx, int64_t ny, int64_t nz, double lx, double ly, double lz, int polyhedra,
-                        int64_t *n_cells_out, int64_t *n_faces_out);
+                        int64_t *n_cells_out, int64_t *n_faces_out, OrcMeshData *into = nullptr);
 
 }  // namespace
+
+// [r05] The same mesh WITHOUT the file: the generator's nodes and faces go straight into the reader's raw form (mesh_raw.hpp) and through the
+// reader's own geometry step — every array equals, bit for bit, what orc_read_mesh returns for the file orc_mixed_channel_write_msh /
+// orc_poly_channel_write_msh would have written (node coordinates are written with 17 significant digits; tests/test_io_cpu.py compares).
+// BASELINE configs[4]: a rank's 5.4 M-cell box cost 11.4 s through a 580 MB temporary file (r04).  Handle as from orc_read_mesh.
+extern "C" OrcMeshData *orc_mixed_channel_generate(int64_t nx, int64_t ny, int64_t nz, double lx, double ly, double lz, int polyhedra, int *status) {
+    OrcMeshData *d = new OrcMeshData();
+    const int st = write_mixed_channel(nullptr, nx, ny, nz, lx, ly, lz, polyhedra, nullptr, nullptr, d);
+    if (status) *status = st;
+    if (st != ORC_OK) { delete d; return nullptr; }
+    return d;
+}
 
 extern "C" int orc_mixed_channel_write_msh(const char *path, int64_t nx, int64_t ny, int64_t nz, double lx, double ly, double lz,
                                            int64_t *n_cells_out, int64_t *n_faces_out) {
@@ -312,8 +325,8 @@ extern "C" int orc_poly_channel_write_msh(const char *path, int64_t nx, int64_t 
 namespace {
 
 int write_mixed_channel(const char *path, int64_t nx, int64_t ny, int64_t nz, double lx, double ly, double lz, int polyhedra,
-                        int64_t *n_cells_out, int64_t *n_faces_out) {
-    if (!path || nx < 20 || ny < 1 || nz < 1) return ORC_ERR_BAD_ARGUMENT;
+                        int64_t *n_cells_out, int64_t *n_faces_out, OrcMeshData *into) {
+    if ((!path && !into) || nx < 20 || ny < 1 || nz < 1) return ORC_ERR_BAD_ARGUMENT;
     MixedBuilder B;
     B.nx = nx; B.ny = ny; B.nz = nz; B.lx = lx; B.ly = ly; B.lz = lz;
     B.grid_nodes = (nx + 1) * (ny + 1) * (nz + 1);
@@ -497,6 +510,37 @@ int write_mixed_channel(const char *path, int64_t nx, int64_t ny, int64_t nz, do
     }
     int64_t n_faces = 0;
     for (auto &z : zones) n_faces += (int64_t)z.size();
+    if (into) {  // what the reader would hold after reading the file written below: same numbering, same zones, same node lists
+        orc::RawMesh R;
+        R.dims = 3;
+        R.n_vert = (int64_t)B.coords.size();
+        R.vert.reserve(B.coords.size());
+        for (const V3 &p : B.coords) R.vert.push_back({p.x, p.y, p.z});
+        R.vert_present.assign(B.coords.size(), 1);
+        R.faces.reserve((size_t)n_faces);
+        R.node_pool.reserve((size_t)n_faces * 4);
+        into->cell_zones.emplace_back((uint64_t)2, (uint64_t)1);  // "(12 (2 1 n 1 0))"
+        int zone_id = 3;
+        for (int z = 0; z < 12; ++z) {
+            if (zones[z].empty()) continue;
+            const int zi = (int)into->zones.size();
+            into->zones.push_back({(uint64_t)zone_id++, z < 2 ? 2 : 3, 0., {0., 0., 0.}, zone_names[z]});
+            for (const OutFace &o : zones[z]) {
+                orc::RawFace rf;
+                rf.node_begin = (int64_t)R.node_pool.size();
+                rf.n_nodes = o.nn;
+                rf.zone = zi;
+                for (int q = 0; q < o.nn; ++q) R.node_pool.push_back(o.n[q]);
+                rf.c[0] = o.c0;
+                rf.c[1] = o.c1;
+                R.faces.push_back(rf);
+            }
+        }
+        R.n_face = (int64_t)R.faces.size();
+        if (n_cells_out) *n_cells_out = B.n_cells;
+        if (n_faces_out) *n_faces_out = n_faces;
+        return orc::mesh_finalize_geometry("<generated mixed channel>", 0, R, *into);
+    }
     FILE *fp = std::fopen(path, "w");
     if (!fp) return ORC_ERR_IO;
     const int64_t nv = (int64_t)B.coords.size();

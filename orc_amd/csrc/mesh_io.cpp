@@ -16,31 +16,13 @@
 #include "common.hpp"
 #include "orc_amd.h"
 
-struct OrcMeshData {
-    int32_t dimensions = 0;
-    int64_t n_vertices = 0, n_faces = 0, n_cells = 0;
-    std::vector<double> vertex;  // [3V]
-    std::vector<int64_t> face_c0, face_c1, face_node_ptr, face_nodes, cell_face_ptr, cell_faces;
-    std::vector<int32_t> face_zone;
-    std::vector<double> face_area, face_normal, face_centroid, cell_centroid, cell_volume;
-    struct Zone {
-        uint64_t id;
-        int32_t type;
-        double scalar;
-        double vec[3];
-        std::string name;
-    };
-    std::vector<Zone> zones;                               // FaceZone, in order of first appearance in the file
-    std::vector<std::pair<uint64_t, uint64_t>> cell_zones;  // (zone id, zone type), io.rs:180-193
-};
+#include "mesh_raw.hpp"
 
 namespace {
 
 using orc::set_error;
 
-struct V3 {
-    double x, y, z;
-};
+using V3 = orc::MeshV3;
 // numerical_types::Vector operators (lib.rs:240-273, 356-447, 529-538), one rounding per written operation
 inline V3 sub(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 inline V3 add(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
@@ -138,12 +120,7 @@ bool valid_bc(uint64_t t) {  // FaceConditionTypes::try_from (mesh.rs:51-66)
     }
 }
 
-struct RawFace {
-    int64_t node_begin = -1;  // into the node pool
-    int32_t n_nodes = 0;
-    int32_t zone = -1;
-    int64_t c[2] = {-1, -1};
-};
+using orc::RawFace;
 
 int fail(const char *path, int64_t line_no, const char *what) {
     return set_error(ORC_ERR_MESH_FORMAT, "%s:%lld: %s", path, (long long)line_no, what);
@@ -159,13 +136,14 @@ int parse_msh(const char *path, const std::string &text, OrcMeshData &d) {
     };
     std::vector<std::string_view> blk;
     std::vector<uint64_t> items;
-    std::vector<V3> vert;
-    std::vector<char> vert_present;
-    std::vector<RawFace> faces;
-    std::vector<int64_t> node_pool;
-    int64_t n_vert = 0, n_face = 0;
+    orc::RawMesh R;
+    std::vector<V3> &vert = R.vert;
+    std::vector<char> &vert_present = R.vert_present;
+    std::vector<RawFace> &faces = R.faces;
+    std::vector<int64_t> &node_pool = R.node_pool;
+    int64_t &n_vert = R.n_vert, &n_face = R.n_face;
     std::string zone_name;
-    int dims = 0;
+    int &dims = R.dims;
 
     std::string_view header;
     if (!next(header)) return fail(path, 0, "mesh is at least one line long");  // io.rs:75-77
@@ -282,8 +260,19 @@ int parse_msh(const char *path, const std::string &text, OrcMeshData &d) {
         if (!next(header)) break;
     }
     if (dims == 0) return fail(path, line_no, "no dimension section before the geometry");
+    return orc::mesh_finalize_geometry(path, line_no, R, d);
+}
 
-    // ---- io.rs:289-415: faces in ascending number
+}  // namespace
+
+// ---- io.rs:289-438: faces in ascending number, then the cells (shared with the generators' in-memory form, mesh_raw.hpp)
+int orc::mesh_finalize_geometry(const char *path, int64_t line_no, orc::RawMesh &R, OrcMeshData &d) {
+    const std::vector<V3> &vert = R.vert;
+    const std::vector<char> &vert_present = R.vert_present;
+    const std::vector<RawFace> &faces = R.faces;
+    const std::vector<int64_t> &node_pool = R.node_pool;
+    const int64_t n_vert = R.n_vert, n_face = R.n_face;
+    const int dims = R.dims;
     d.dimensions = dims;
     d.n_vertices = n_vert;
     d.n_faces = n_face;
@@ -379,6 +368,8 @@ int parse_msh(const char *path, const std::string &text, OrcMeshData &d) {
     }
     return ORC_OK;
 }
+
+namespace {
 
 bool slurp(const char *path, std::string &out) {
     FILE *fp = fopen(path, "rb");

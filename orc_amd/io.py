@@ -19,13 +19,14 @@ def _p(a, t=_F64):
 class MeshData:
     """Host image of mesh::Mesh as read_mesh builds it (OrcMeshData*)."""
 
-    def __init__(self, mesh_path):
+    def __init__(self, mesh_path, _handle=None):
         L = lib()
-        L.orc_read_mesh.restype = C.c_void_p
-        st = C.c_int(0)
-        ptr = L.orc_read_mesh(str(mesh_path).encode(), C.byref(st))
-        check(st.value)
-        self.ptr = C.c_void_p(ptr)
+        if _handle is None:
+            L.orc_read_mesh.restype = C.c_void_p
+            st = C.c_int(0)
+            _handle = L.orc_read_mesh(str(mesh_path).encode(), C.byref(st))
+            check(st.value)
+        self.ptr = C.c_void_p(_handle)
         dims, nv, nc, nf, ncf, nfn, nz = C.c_int32(), C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64(), C.c_int32()
         check(L.orc_mesh_data_sizes(self.ptr, C.byref(dims), C.byref(nv), C.byref(nc), C.byref(nf), C.byref(ncf), C.byref(nfn), C.byref(nz)))
         self.dimensions, self.n_vertices, self.n_cells, self.n_faces = dims.value, nv.value, nc.value, nf.value
@@ -35,6 +36,17 @@ class MeshData:
         if getattr(self, "ptr", None):
             lib().orc_mesh_data_destroy(self.ptr)
             self.ptr = None
+
+    @classmethod
+    def mixed_channel(cls, nx, ny, nz, lx=0.002, ly=0.001, lz=None, polyhedra=False):
+        """orc_mixed_channel_generate: the mesh of mesh.write_mixed_channel_msh(...) built in memory — bit for bit what reading that file gives."""
+        L = lib()
+        L.orc_mixed_channel_generate.restype = C.c_void_p
+        st = C.c_int(0)
+        h = L.orc_mixed_channel_generate(C.c_int64(nx), C.c_int64(ny), C.c_int64(nz), C.c_double(lx), C.c_double(ly),
+                                         C.c_double(1e-4 * nz if lz is None else lz), C.c_int(1 if polyhedra else 0), C.byref(st))
+        check(st.value)
+        return cls(None, _handle=h)
 
     def zones(self):
         """[(zone id, FaceConditionTypes code, scalar_value, vector_value, name)] in file order."""

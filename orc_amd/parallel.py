@@ -179,13 +179,18 @@ def mixed_slab_arrays(nx, ny, nz_local, rank, world, lx=0.002, ly=0.001, dz=1e-4
     g_hi = 2 if rank < world - 1 else 0
     nzt = nz_local + g_lo + g_hi
     k0 = rank * nz_local - g_lo  # global index of the sub-box's first block layer (even)
-    path = os.path.join(tmpdir or tempfile.gettempdir(), "orc_mixed_slab_%d_%d.msh" % (os.getpid(), rank))
-    try:
-        write_mixed_channel_msh(path, nx, ny, nzt, lx=lx, ly=ly, lz=dz * nzt, polyhedra=polyhedra)
-        d = orc_io.read_mesh(path)
-    finally:
-        if os.path.exists(path):
-            os.remove(path)
+    # [r05] built in memory (orc_mixed_channel_generate: the reader's own geometry code on the generator's nodes and faces) — r04 wrote a
+    # 580 MB TGRID file per rank and read it back: 11.4 of a rank's 12.5 s of set-up.  ORC_MIXED_SLAB_VIA_FILE=1: the old way (same arrays).
+    if os.environ.get("ORC_MIXED_SLAB_VIA_FILE") == "1":
+        path = os.path.join(tmpdir or tempfile.gettempdir(), "orc_mixed_slab_%d_%d.msh" % (os.getpid(), rank))
+        try:
+            write_mixed_channel_msh(path, nx, ny, nzt, lx=lx, ly=ly, lz=dz * nzt, polyhedra=polyhedra)
+            d = orc_io.read_mesh(path)
+        finally:
+            if os.path.exists(path):
+                os.remove(path)
+    else:
+        d = orc_io.MeshData.mixed_channel(nx, ny, nzt, lx=lx, ly=ly, lz=dz * nzt, polyhedra=polyhedra)
     a = MeshArrays(d.arrays())
     layer = np.floor(np.asarray(a["cell_centroid"])[:, 2] / dz + 1e-6).astype(np.int64) + k0  # global block layer of every cell
     owner = (layer // nz_local).astype(np.int32)

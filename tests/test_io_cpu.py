@@ -387,3 +387,25 @@ def test_poly_channel_generator_agglomerated_polyhedra(oracle, tmp_path):
     for zi, name in enumerate(a["zone_names"]):
         sel = nn[fz == zi]
         assert len(sel) == 0 or set(np.unique(sel).tolist()) == ({3} if name.endswith("_TRI") else {4}), name
+
+
+@pytest.mark.parametrize("polyhedra", [False, True])
+def test_mixed_channel_generated_in_memory_equals_the_written_and_read_file(tmp_path, polyhedra):
+    """[r05] orc_mixed_channel_generate (what bench.py --workload config5 uses per rank): the generator's nodes and faces handed to the reader's
+    own geometry step, no file — every array of the handle (adjacency, zones, areas, normals, centroids, volumes, cell face lists) has the bits
+    of orc_read_mesh on the file orc_mixed_channel_write_msh / orc_poly_channel_write_msh writes for the same arguments."""
+    from orc_amd import io as orc_io
+    from orc_amd.mesh import write_mixed_channel_msh
+    nx, ny, nz = 60, 12, 10
+    path = str(tmp_path / "mixed.msh")
+    write_mixed_channel_msh(path, nx, ny, nz, polyhedra=polyhedra)
+    a = orc_io.read_mesh(path).arrays()
+    d = orc_io.MeshData.mixed_channel(nx, ny, nz, polyhedra=polyhedra)
+    b = d.arrays()
+    assert set(a) == set(b)
+    for k in a:
+        if isinstance(a[k], np.ndarray):
+            assert a[k].dtype == b[k].dtype and np.array_equal(a[k], b[k]), k
+        else:
+            assert a[k] == b[k], k
+    assert d.n_vertices > (nx + 1) * (ny + 1) * (nz + 1)  # (block-centre nodes of the pyramid blocks)
