@@ -2085,7 +2085,8 @@ struct DaCounters {
     int overflow;  // chains cut off by the step budget (the fallback then runs)
     int steps;     // proposals made by da_chase_k: statistics
     int list;      // rows the first pass left to the chains
-    int pad;
+    int scans;     // (statistics: proposals found by a scan of the row, the list having run out)
+    int longest;   // (statistics: proposals of the longest chain)
 };
 
 // A look at the holder table before proposing: holder[j] only ever DECREASES, so a value below r — however stale the copy a load returns —
@@ -2096,103 +2097,259 @@ __device__ __forceinline__ int da_peek(const int *holder, int j) { return __hip_
 // First pass: one thread per row, the SELL image (lane = row: coalesced).  The row's most preferred column that no lower row is seen to hold
 // (agg_eval_row's scan with the holder table as the first-taker table) gets the row's proposal.  Whoever loses — the row itself, when a lower
 // row got in between the look and the atomic; or the higher row it displaces — goes on the list of the chains: (row, the column it lost on).
-__global__ __launch_bounds__(kBlock) void da_first_k(MatView A, int *holder, int2 *__restrict__ list, DaCounters *C) {
+// The scan also leaves the row's kPrefs most preferred columns behind (agg_init_prefs_k's lists: value ascending, position ascending; bit 30 of the
+// last entry: the row has more candidates): a chain that displaces the row finds its next proposal in ONE 16-byte line at a known address.
+__global__ __launch_bounds__(kBlock) void da_first_k(MatView A, int *holder, int2 *__restrict__ list, DaCounters *C, int *__restrict__ prefs) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int loser = -1, lost_on = -1;
     if (i < A.P.n) {
         const int len = A.P.row_len[i];
         const int64_t base = A.P.slice_ptr[i >> 6] + (i & 63);
+        double bv[kPrefs];
+        int bj[kPrefs];
+#pragma unroll
+        for (int q = 0; q < kPrefs; ++q) { bv[q] = 1.7976931348623157e308; bj[q] = -1; }
         double best = 1.7976931348623157e308;  // Float::MAX
-        int bj = -1;
+        int fj = -1, cand = 0;
         for (int k = 0; k < len; ++k) {
             const int64_t pos = base + (int64_t)k * 64;
             const int j = A.P.col[pos];
             if (j == i || j >= A.P.n) continue;  // ghost columns (partitioned level 0) are never partners
             const double a = view_value(A, i, pos);
+            if (!(a < 1.7976931348623157e308)) continue;  // never chosen (nor a NaN)
+            ++cand;
+            int pos_q = kPrefs;  // its place in the list: in front of the first listed entry it is STRICTLY smaller than
+#pragma unroll
+            for (int q = kPrefs - 1; q >= 0; --q)
+                if (a < bv[q]) pos_q = q;
+#pragma unroll
+            for (int q = kPrefs - 1; q >= 1; --q)
+                if (q > pos_q) { bv[q] = bv[q - 1]; bj[q] = bj[q - 1]; }
+#pragma unroll
+            for (int q = 0; q < kPrefs; ++q)
+                if (q == pos_q) { bv[q] = a; bj[q] = j; }
             if (!(a < best)) continue;
             if (da_peek(holder, j) < (int)i) continue;
-            best = a; bj = j;
+            best = a; fj = j;
         }
-        if (bj >= 0) {
-            const int old = atomicMin(&holder[bj], (int)i);
-            if (old < (int)i) { loser = (int)i; lost_on = bj; }
-            else if (old != 0x7fffffff) { loser = old; lost_on = bj; }
+        int4 pl;
+        pl.x = bj[0]; pl.y = bj[1]; pl.z = bj[2];
+        pl.w = (cand > kPrefs && bj[3] >= 0) ? (bj[3] | kPrefMore) : bj[3];
+        reinterpret_cast<int4 *>(prefs)[i] = pl;
+        if (fj >= 0) {
+            const int old = atomicMin(&holder[fj], (int)i);
+            if (old < (int)i) { loser = (int)i; lost_on = fj; }
+            else if (old != 0x7fffffff) { loser = old; lost_on = fj; }
         }
     }
     const int slot = wave_append_slot(&C->list, loser >= 0);
     if (loser >= 0) list[slot] = make_int2(loser, lost_on);
 }
 
-// Row r's most preferred column BEHIND `after` in its order of preference (value, then position) that no lower row is seen to hold: G lanes
-// read the row G entries at a time (the row-contiguous mirror where the matrix has one) and reduce by (value, position) — the strict <,
-// first-wins scan of linear_algebra.rs:37-52 restricted to what the row has not been refused yet.  Every lane returns the column (-1: none).
-template <int G>
-__device__ __forceinline__ int da_group_next(const MatView &A, const int *holder, int64_t r, int after, int gl) {
-    const int len = A.P.row_len[r];
-    const RowWalk W(A, r);
-    // where `after` stands in the order
-    int k_c = -1;
-    double v_c = 0.;
-    for (int k = gl; k < len; k += G)
-        if (W.column(k) == after) { k_c = k; v_c = W.value(A, r, k); }
-#pragma unroll
-    for (int off = G / 2; off > 0; off >>= 1) {
-        const int ok = __shfl_xor(k_c, off, G);
-        const double ov = __shfl_xor(v_c, off, G);
-        if (ok > k_c) { k_c = ok; v_c = ov; }
-    }
-    double best = 1.7976931348623157e308;  // Float::MAX
-    int bk = 0x7fffffff, bj = -1;
-    for (int k = gl; k < len; k += G) {
-        const int j = W.column(k);
-        if (j == r || j >= A.P.n) continue;
-        const double a = W.value(A, r, k);
-        if (k_c >= 0 && !(a > v_c || (a == v_c && k > k_c))) continue;  // at or before `after`: refused already
-        if (!(a < best)) continue;                                        // (a lane's k ascend: strict < keeps the earlier position)
-        if (da_peek(holder, j) < (int)r) continue;                        // held by a lower row: passed by
-        best = a; bk = k; bj = j;
-    }
-#pragma unroll
-    for (int off = G / 2; off > 0; off >>= 1) {
-        const double ob = __shfl_xor(best, off, G);
-        const int ok = __shfl_xor(bk, off, G);
-        const int oj = __shfl_xor(bj, off, G);
-        if (ob < best || (ob == best && ok < bk)) { best = ob; bk = ok; bj = oj; }
-    }
-    return bj;
-}
-
 // The chains: a group of G lanes takes a listed row and follows what its proposals set off — propose; if a higher row is displaced, go on as
-// that row — until a proposal meets a free column or a row runs out of candidates.  No state but the holder table; no group waits for another.
+// that row — until a proposal meets a free column or a row runs out of candidates; then it takes the next listed row.  No state but the holder
+// table; no group waits for another.
+//
+// ONE flat loop per wavefront, the same straight-line code for its 64 / G groups in every pass: a group that is through with its chain takes
+// its next row in the same pass in which the others make their next step (nested "for every listed row { follow the chain }" leaves a group
+// whose chain has ended masked off until the longest chain of its wavefront ends).  Loads are unconditional at clamped addresses (a
+// conditional load is a branch with a wait of its own behind it), the results masked.  A pass:
+//   1. the row's LIST (da_first_k: its kPrefs most preferred columns): lanes 0-3 look at the holders of the listed columns behind `after`;
+//   2. only if some group of the wavefront found them all taken and its row has more candidates: the SCAN of the row — descriptor, then
+//      columns and values (<= kDaRegs entries per lane in registers, only the slots the wavefront's longest scanned row needs; longer rows:
+//      two sweeps), then every candidate's holder, two reductions;
+//   3. the proposal (one returning atomicMin per group) — beside it, already on its way, the list of the row it will most likely displace
+//      (the holder just seen).
+// Two dependent round trips per step where the list reaches (the channel's fine level: 25 600 chains of ~160 steps, 1.4 ms), five where the
+// row is scanned.  What bounds the coarse levels is the LONGEST chain times those trips, not the number of proposals (measured: more groups
+// per wavefront, fewer looks per scan — in order of preference, lane by lane — and fewer memory instructions per pass all leave 5-8 ms).
+constexpr int kDaRegs = 8;
 template <int G>
-__global__ __launch_bounds__(kBlock) void da_chase_k(MatView A, int *holder, const int2 *__restrict__ list, DaCounters *C, int max_steps) {
+__global__ __launch_bounds__(kBlock) void da_chase_k(MatView A, int *holder, const int2 *__restrict__ list, DaCounters *C, int max_steps, const int *__restrict__ prefs) {
     const int gl = threadIdx.x & (G - 1);
+    const int shift = (threadIdx.x & 63) & ~(G - 1);
+    const unsigned long long gmask = G == 64 ? ~0ull : (((1ull << G) - 1ull) << shift);
     const int64_t groups = ((int64_t)gridDim.x * blockDim.x) / G;
     const int count = C->list;
-    int steps = 0;
-    bool cut = false;
-    for (int64_t e = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G; e < count; e += groups) {
+    const int4 *pl4 = reinterpret_cast<const int4 *>(prefs);
+    const int n = (int)A.P.n;
+    const bool mirror = A.rows.col != nullptr;
+    const int32_t *colp = mirror ? A.rows.col : A.P.col;
+    const double *valp = mirror ? A.rows.val : A.val;
+    const int64_t stride = mirror ? 1 : 64;
+    int64_t e = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    bool have = e < count;
+    int r = 0, after = -1;
+    int4 pl = make_int4(-1, -1, -1, -1);
+    if (have) {
         const int2 it = list[e];
-        int64_t r = it.x;
-        int after = it.y;
-        for (int s = 0;; ++s) {
-            if (s >= max_steps) { cut = true; break; }
-            const int cand = da_group_next<G>(A, holder, r, after, gl);
-            if (cand < 0) break;  // the row has no candidate left: unmatched
-            int old = 0;
-            if (gl == 0) old = atomicMin(&holder[cand], (int)r);
-            old = __shfl(old, 0, G);
+        r = it.x; after = it.y;
+        pl = pl4[r];
+    }
+    int steps = 0, scans = 0, chain_steps = 0, longest = 0;
+    bool cut = false;
+    while (__ballot(have) != 0ull) {
+        // ---- 1. the list
+        const int p3 = pl.w >= 0 ? (pl.w & ~kPrefMore) : -1;
+        const bool more = pl.w >= 0 && (pl.w & kPrefMore) != 0;
+        const int pq = gl == 0 ? pl.x : (gl == 1 ? pl.y : (gl == 2 ? pl.z : (gl == 3 ? p3 : -1)));
+        const int first = after == pl.x ? 1 : (after == pl.y ? 2 : (after == pl.z ? 3 : 4));  // the first listed preference behind `after`
+        const bool beyond = first == 4 && after != p3;                                         // `after` lies behind the whole list already
+        const bool look = have && !beyond && gl < kPrefs && gl >= first && pq >= 0;
+        int h = da_peek(holder, look ? pq : 0);
+        h = look ? h : -1;
+        const unsigned long long free_all = __ballot(look && h >= r);
+        const unsigned free_mine = (unsigned)((free_all & gmask) >> shift);
+        int cand = -1, seen = 0x7fffffff;
+        if (free_mine) {
+            const int q = __ffs((int)free_mine) - 1;
+            cand = __shfl(pq, q, G);
+            seen = __shfl(h, q, G);
+        }
+        const bool need_scan = have && (beyond || (!free_mine && more));
+        const int scan_after = beyond ? after : p3;  // (a row's unlisted candidates all rank behind its last listed one)
+        // ---- 2. the scan, for the groups whose list ran out (wave-uniform branch; inside, every lane runs the same code)
+        if (__ballot(need_scan) != 0ull) {
+            const int rs = need_scan ? r : 0;
+            int len = A.P.row_len[rs];
+            const int64_t base = mirror ? (int64_t)A.rows.slice_base[rs >> 6] + A.rows.intra_off[rs] : A.P.slice_ptr[rs >> 6] + (rs & 63);
+            const double s1 = A.s1 ? A.s1[rs] : 1., s2 = A.s2 ? A.s2[rs] : 1.;
+            len = need_scan ? len : 0;
+            int k_c = -1;
+            double v_c = 0.;
+            double best = 1.7976931348623157e308;  // Float::MAX
+            int bk = 0x7fffffff, bj = -1, bh = 0x7fffffff;
+            int len_max = len;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) len_max = max(len_max, __shfl_xor(len_max, off, 64));
+            if (len_max <= G * kDaRegs) {
+                const int u_max = (len_max + G - 1) / G;  // wave-uniform
+                int cj[kDaRegs], hp[kDaRegs];
+                double cv[kDaRegs];
+#pragma unroll
+                for (int u = 0; u < kDaRegs; ++u) {
+                    cj[u] = -1;
+                    if (u < u_max) {
+                        const int k = gl + u * G;
+                        const int c = colp[base + (int64_t)(k < len ? k : 0) * stride];
+                        cj[u] = k < len ? c : -1;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < kDaRegs; ++u) {
+                    cv[u] = 0.;
+                    if (u < u_max) {
+                        const int k = gl + u * G;
+                        cv[u] = valp[base + (int64_t)(k < len ? k : 0) * stride];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < kDaRegs; ++u) {
+                    hp[u] = -1;
+                    if (u >= u_max) continue;
+                    const bool ok = cj[u] >= 0 && cj[u] != rs && cj[u] < n;
+                    const int hh = da_peek(holder, ok ? cj[u] : 0);
+                    hp[u] = ok ? hh : -1;  // (-1: not a candidate)
+                    double t = cv[u];
+                    if (A.s1) t = s1 * t;  // RowWalk::value's order
+                    if (A.s2) t = s2 * t;
+                    cv[u] = t;
+                    if (cj[u] == scan_after && cj[u] >= 0) { k_c = gl + u * G; v_c = t; }
+                }
+#pragma unroll
+                for (int off = G / 2; off > 0; off >>= 1) {
+                    const int ok = __shfl_xor(k_c, off, G);
+                    const double ov = __shfl_xor(v_c, off, G);
+                    if (ok > k_c) { k_c = ok; v_c = ov; }
+                }
+#pragma unroll
+                for (int u = 0; u < kDaRegs; ++u) {  // (a lane's positions ascend with u: strict < keeps the earlier one)
+                    const int k = gl + u * G;
+                    const double a = cv[u];
+                    if (hp[u] < rs) continue;                                         // not a candidate, or held by a lower row
+                    if (k_c >= 0 && !(a > v_c || (a == v_c && k > k_c))) continue;    // at or before `scan_after`: refused already
+                    if (a < best) { best = a; bk = k; bj = cj[u]; bh = hp[u]; }
+                }
+            } else {  // rows beyond G * kDaRegs entries: the same in two sweeps over the row
+                const int sweeps = (len_max + G - 1) / G;
+                for (int u = 0; u < sweeps; ++u) {
+                    const int k = gl + u * G;
+                    const int64_t pos = base + (int64_t)(k < len ? k : 0) * stride;
+                    const int c = colp[pos];
+                    double t = valp[pos];
+                    if (A.s1) t = s1 * t;
+                    if (A.s2) t = s2 * t;
+                    if (k < len && c == scan_after) { k_c = k; v_c = t; }
+                }
+#pragma unroll
+                for (int off = G / 2; off > 0; off >>= 1) {
+                    const int ok = __shfl_xor(k_c, off, G);
+                    const double ov = __shfl_xor(v_c, off, G);
+                    if (ok > k_c) { k_c = ok; v_c = ov; }
+                }
+                for (int u = 0; u < sweeps; ++u) {
+                    const int k = gl + u * G;
+                    const int64_t pos = base + (int64_t)(k < len ? k : 0) * stride;
+                    const int c = colp[pos];
+                    double t = valp[pos];
+                    if (A.s1) t = s1 * t;
+                    if (A.s2) t = s2 * t;
+                    const bool ok = k < len && c != rs && c < n;
+                    const int hh = da_peek(holder, ok ? c : 0);
+                    if (!ok || hh < rs) continue;
+                    if (k_c >= 0 && !(t > v_c || (t == v_c && k > k_c))) continue;
+                    if (t < best) { best = t; bk = k; bj = c; bh = hh; }
+                }
+            }
+#pragma unroll
+            for (int off = G / 2; off > 0; off >>= 1) {
+                const double ob = __shfl_xor(best, off, G);
+                const int ok = __shfl_xor(bk, off, G);
+                const int oj = __shfl_xor(bj, off, G);
+                const int oh = __shfl_xor(bh, off, G);
+                if (ob < best || (ob == best && ok < bk)) { best = ob; bk = ok; bj = oj; bh = oh; }
+            }
+            if (need_scan) { cand = bj; seen = bh; ++scans; }
+        }
+        // ---- 3. the proposal; beside it the list of the row it will most likely displace
+        const bool propose = have && cand >= 0;
+        int old = 0;
+        if (gl == 0 && propose) old = atomicMin(&holder[cand], r);
+        const int guess = (propose && seen != 0x7fffffff && seen > r) ? seen : r;
+        const int4 pl_guess = pl4[guess];
+        old = __shfl(old, 0, G);
+        bool done = have && !propose;  // the row has no candidate left: unmatched, the chain ends
+        if (propose) {
             ++steps;
+            ++chain_steps;
             after = cand;
-            if (old > (int)r) {
-                if (old == 0x7fffffff) break;  // a free column: the chain ends
-                r = old;                       // accepted; `old` is displaced and goes on from the column it lost
+            if (old > r) {
+                if (old == 0x7fffffff) done = true;  // a free column: the chain ends
+                else {
+                    r = old;                         // accepted; `old` is displaced and goes on from the column it lost
+                    pl = old == guess ? pl_guess : pl4[old];
+                }
+            }
+            if (!done && chain_steps >= max_steps) { cut = true; done = true; }
+        }
+        // ---- the next listed row, in the same pass
+        if (done) {
+            longest = max(longest, chain_steps);
+            e += groups;
+            have = e < count;
+            chain_steps = 0;
+            if (have) {
+                const int2 it = list[e];
+                r = it.x; after = it.y;
+                pl = pl4[r];
             }
         }
     }
     if (gl == 0) {
         if (cut) atomicAdd(&C->overflow, 1);
         if (steps) atomicAdd(&C->steps, steps);
+        if (scans) atomicAdd(&C->scans, scans);
+        if (longest) atomicMax(&C->longest, longest);
     }
 }
 
@@ -2379,16 +2536,21 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
         DaCounters *D;
         int2 *list;
         ORC_TRY(arena.alloc((size_t)1, &D));
+        int *da_prefs;
         ORC_TRY(arena.alloc((size_t)n, &list));
+        ORC_TRY(arena.alloc((size_t)n * kPrefs, &da_prefs));
         ORC_HIP(hipMemsetAsync(D, 0, sizeof(DaCounters), st));
         hipLaunchKernelGGL(agg_reset_k, dim3(g), dim3(kBlock), 0, st, taken_by, n);  // holder = taken_by: nobody
         const int da_steps = getenv("ORC_AMG_DA_STEPS") ? std::max(1, atoi(getenv("ORC_AMG_DA_STEPS"))) : (1 << 22);  // (a test cuts the chains short: the fallback must finish the job)
-        hipLaunchKernelGGL(da_first_k, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, A, taken_by, list, D);
-        const int da_group = getenv("ORC_AMG_DA_GROUP") ? atoi(getenv("ORC_AMG_DA_GROUP")) : 16;
-        if (da_group == 4) hipLaunchKernelGGL(da_chase_k<4>, dim3(kMaxGrid), dim3(kBlock), 0, st, A, taken_by, (const int2 *)list, D, da_steps);
-        else if (da_group == 8) hipLaunchKernelGGL(da_chase_k<8>, dim3(kMaxGrid), dim3(kBlock), 0, st, A, taken_by, (const int2 *)list, D, da_steps);
-        else if (da_group == 32) hipLaunchKernelGGL(da_chase_k<32>, dim3(kMaxGrid), dim3(kBlock), 0, st, A, taken_by, (const int2 *)list, D, da_steps);
-        else hipLaunchKernelGGL(da_chase_k<16>, dim3(kMaxGrid), dim3(kBlock), 0, st, A, taken_by, (const int2 *)list, D, da_steps);
+        hipLaunchKernelGGL(da_first_k, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, A, taken_by, list, D, da_prefs);
+        // lanes per chain: the list needs four; a scan reads the row G entries at a time (kDaRegs slots per lane in registers).  Measured per level
+        // of the channel (one hierarchy, us): 7 entries per row: 4 / 8 / 16 lanes 1 620 / 1 454 / 1 475; 15: 4 767 / 6 303 / 8 274; 33: 9 048 / 8 047 / 8 596
+        const double da_avg = (double)A.P.padded / (double)n;
+        const int da_group = getenv("ORC_AMG_DA_GROUP") ? atoi(getenv("ORC_AMG_DA_GROUP")) : (da_avg <= 24. ? 4 : 8);
+        if (da_group == 4) hipLaunchKernelGGL(da_chase_k<4>, dim3(kMaxGrid), dim3(kBlock), 0, st, A, taken_by, (const int2 *)list, D, da_steps, (const int *)da_prefs);
+        else if (da_group == 8) hipLaunchKernelGGL(da_chase_k<8>, dim3(kMaxGrid), dim3(kBlock), 0, st, A, taken_by, (const int2 *)list, D, da_steps, (const int *)da_prefs);
+        else if (da_group == 32) hipLaunchKernelGGL(da_chase_k<32>, dim3(kMaxGrid), dim3(kBlock), 0, st, A, taken_by, (const int2 *)list, D, da_steps, (const int *)da_prefs);
+        else hipLaunchKernelGGL(da_chase_k<16>, dim3(kMaxGrid), dim3(kBlock), 0, st, A, taken_by, (const int2 *)list, D, da_steps, (const int *)da_prefs);
         ORC_HIP(hipMemsetAsync(choice, 0xff, sizeof(int) * (size_t)n, st));
         hipLaunchKernelGGL(da_finish_k, dim3(g), dim3(kBlock), 0, st, (const int *)taken_by, choice, chooser, n);
         // is it the fixed point?  every row against the exact first-taker table (= holder): the sequential pairing is the only state that passes
@@ -2399,7 +2561,7 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
         ORC_HIP(hipMemcpyAsync(&hc, C, sizeof(hc), hipMemcpyDeviceToHost, st));
         ORC_HIP(hipMemcpyAsync(&hd, D, sizeof(hd), hipMemcpyDeviceToHost, st));
         ORC_HIP(hipStreamSynchronize(st));
-        if (trace_t) fprintf(stderr, "[amg da n=%lld] rows left to the chains %d, their proposals %d, chains cut %d, rows that would change %d\n", (long long)n, hd.list, hd.steps, hd.overflow, hc.changed);
+        if (trace_t) fprintf(stderr, "[amg da n=%lld] rows left to the chains %d, their proposals %d (%d by a scan of the row), longest chain %d, chains cut %d, rows that would change %d\n", (long long)n, hd.list, hd.steps, hd.scans, hd.longest, hd.overflow, hc.changed);
         if (hd.overflow == 0 && hc.changed == 0) {
             g_cert_aggregations.fetch_add(1, std::memory_order_relaxed);  // certified by one pass that changed nothing
             g_cert_rounds.fetch_add(1, std::memory_order_relaxed);

@@ -1,17 +1,25 @@
 #!/usr/bin/env python3
-"""Folds the passes of scripts/gpu_pmc_r04.sh (gpurun_out/r04_pmc) into
-  profiles/r04_pmc_products.csv   one row per product kernel (and per level for spmv_xwin_k): time, memory-side bytes, cache and
+"""Folds the passes of scripts/gpu_pmc.sh (gpurun_out/<tag>) into
+  profiles/<prefix>_pmc_products.csv   one row per product kernel (and per level for spmv_xwin_k): time, memory-side bytes, cache and
                                   pipe counters per launch;
-  profiles/r04_spmv_pmc.json      the traffic of the kernel bench.py's roofline names — bench.py quotes it only if the kernel
+  profiles/<prefix>_spmv_pmc.json      the traffic of the kernel bench.py's roofline names — bench.py quotes it only if the kernel
                                   name and the matrix (n, nnz) are the ones it has just timed;
-  profiles/r04_products_kernel_stats.csv   the rocprofv3 --kernel-trace --stats summary of the same program.
+  profiles/<prefix>_products_kernel_stats.csv, <prefix>_setup.csv   the rocprofv3 --kernel-trace --stats summary of the same program.
 Memory-side bytes follow MI355X_MICROARCH.md (HBM): reads = FETCH_SIZE x 2 (gfx950 tallies 128-byte requests at 64 bytes),
 writes = WRITE_SIZE, both in KiB, each from its own --pmc pass; the request-size-resolved figure (128 x RDREQ_128B + 64 x
 RDREQ_64B + 32 x the rest) is listed beside it."""
-import collections, csv, glob, json, os, shutil, sys
+import argparse, collections, csv, glob, json, os, shutil, sys
+ap = argparse.ArgumentParser()
+ap.add_argument("--tag", default="r05_pmc", help="directory under gpurun_out/ that scripts/gpu_pmc.sh wrote")
+ap.add_argument("--prefix", default="r05", help="profiles/<prefix>_*.csv / .json")
+ap.add_argument("--n", type=int, default=10_240_000)
+ap.add_argument("--nnz", type=int, default=71_372_800)
+ap.add_argument("--workload", default="hex channel 400x160x160, a_u through two Jacobi scalings (scripts/profile_products.py)")
+args = ap.parse_args()
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-base = os.path.join(root, "gpurun_out", "r04_pmc")
-N, NNZ = 10_240_000, 71_372_800
+base = os.path.join(root, "gpurun_out", args.tag)
+N, NNZ = args.n, args.nnz
+PRE = args.prefix
 
 
 def short(name):
@@ -72,7 +80,7 @@ extra = ["TA_TA_BUSY_sum", "TA_FLAT_READ_WAVEFRONTS_sum", "TA_ADDR_STALLED_BY_TC
          "TCP_TCC_READ_REQ_sum", "TCP_PENDING_STALL_CYCLES_sum", "TCP_TCC_READ_REQ_LATENCY_sum", "TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum", "TCC_READ_sum",
          "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VMEM", "SQ_INSTS_VMEM_RD", "SQ_ACTIVE_INST_ANY",
          "SQ_INSTS_LDS", "SQ_ACTIVE_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_WAIT_INST_LDS", "SQ_LDS_ADDR_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_VALU", "SQ_INSTS_SALU"]
-with open(os.path.join(root, "profiles", "r04_pmc_products.csv"), "w") as fh:
+with open(os.path.join(root, "profiles", PRE + "_pmc_products.csv"), "w") as fh:
     fh.write("kernel,launches,avg_us,hbm_read_bytes(FETCH_SIZEx2),hbm_write_bytes(WRITE_SIZE),read_bytes_by_request_size,write_bytes_by_request_size,TB_per_s," + ",".join(extra) + "\n")
     for r in rows:
         fh.write('"%s",%d,%.1f,%.0f,%.0f,%.0f,%.0f,%.2f,' % (r["kernel"], r["launches"], r["avg_us"], r["hbm_read_bytes"], r["hbm_write_bytes"],
@@ -80,7 +88,7 @@ with open(os.path.join(root, "profiles", "r04_pmc_products.csv"), "w") as fh:
         fh.write(",".join("%.0f" % r["counters"].get(x, float("nan")) for x in extra) + "\n")
 ks = os.path.join(base, "kernel_stats.csv")
 if os.path.exists(ks):
-    shutil.copyfile(ks, os.path.join(root, "profiles", "r04_products_kernel_stats.csv"))
+    shutil.copyfile(ks, os.path.join(root, "profiles", PRE + "_products_kernel_stats.csv"))
 # the kernel bench.py's roofline names: the two in-loop launches of one system, averaged (one of each per BiCGSTAB iteration)
 # the in-loop launches of one system on level 0: spmv_uniform_k<EpiStoreSum | EpiTs, false, true, narrow, scaled>
 pair = [r for r in rows if r["kernel"].startswith(("spmv_uniform_k<EpiStoreSum, false, true", "spmv_uniform_k<EpiTs, false, true"))]
@@ -88,7 +96,7 @@ if len(pair) == 2:
     names = [r["kernel"] for r in sorted(pair, key=lambda r: "EpiTs" in r["kernel"])]
     kernel_name = names[0] + " / " + names[1].replace("spmv_uniform_k", "")
     avg = lambda key: sum(r[key] for r in pair) / 2.  # noqa: E731
-    doc = {"workload": "hex channel 400x160x160, a_u through two Jacobi scalings (scripts/profile_products.py)", "n": N, "nnz": NNZ,
+    doc = {"workload": args.workload, "n": N, "nnz": NNZ,
            "kernel": kernel_name, "avg_us": avg("avg_us"),
            "hbm_read_bytes_per_launch": avg("hbm_read_bytes"), "hbm_write_bytes_per_launch": avg("hbm_write_bytes"),
            "hbm_bytes_per_launch": avg("hbm_read_bytes") + avg("hbm_write_bytes"),
@@ -97,8 +105,8 @@ if len(pair) == 2:
            "bytes_the_launch_must_move_with_4_byte_columns": 12.0 * NNZ + 20.0 * N + 4.0 * N,  # EpiTs also re-reads s (8 n): 4 n on average
            "per_epilogue": {r["kernel"]: {"avg_us": r["avg_us"], "hbm_bytes": r["hbm_read_bytes"] + r["hbm_write_bytes"]} for r in pair},
            "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, KiB; reads doubled: gfx950 tallies 128-byte requests at 64 bytes, "
-                     "MI355X_MICROARCH.md HBM); scripts/gpu_pmc_r04.sh + scripts/pmc_summary_r04.py"}
-    json.dump(doc, open(os.path.join(root, "profiles", "r04_spmv_pmc.json"), "w"), indent=1)
+                     "MI355X_MICROARCH.md HBM); scripts/gpu_pmc.sh + scripts/pmc_summary.py"}
+    json.dump(doc, open(os.path.join(root, "profiles", PRE + "_spmv_pmc.json"), "w"), indent=1)
     print(json.dumps(doc, indent=1))
 for r in rows:
     c = r["counters"]
@@ -112,9 +120,10 @@ for r in rows:
 # ---- [r04] the set-up of ONE hierarchy (a_u: three aggregations + three Galerkin products, built by orc_bench_amg_levels inside the same program):
 # per phase the launches, the kernel time and the memory-side bytes (FETCH_SIZE x 2 + WRITE_SIZE per launch, summed) — VERDICT r03, weak #3:
 # "0.25 s of the 0.82 s iteration is hierarchy set-up with no byte model"
-PHASES = [("aggregation: slice sweeps", ("agg_init_k", "agg_reset_k", "agg_scatter_k", "agg_sweep_group_k", "agg_sweep_k", "agg_rotate_k", "agg_verify_k")),
-          ("aggregation: lock-step rounds", ("tail_eval_k", "tail_commit_k", "tail_update_k", "tail_rotate_k", "tail_seed_k", "tail_small_k")),
-          ("aggregation: cascades", ("tail_chase_k", "chase_carry_k", "chase_rotate_k", "chase_convert_k")),
+PHASES = [("aggregation [r05]: deferred acceptance (first pass, chains, pairing, verification)", ("da_first_k", "da_chase_k", "da_finish_k", "agg_reset_k", "agg_verify_k")),
+          ("aggregation [r04 fallback]: slice sweeps", ("agg_init_k", "agg_init_prefs_k", "agg_scatter_k", "agg_sweep_group_k", "agg_sweep_k", "agg_rotate_k")),
+          ("aggregation [r04 fallback]: lock-step rounds", ("tail_eval_k", "tail_commit_k", "tail_update_k", "tail_rotate_k", "tail_seed_k", "tail_small_k")),
+          ("aggregation [r04 fallback]: cascades", ("tail_chase_k", "chase_carry_k", "chase_rotate_k", "chase_convert_k")),
           ("aggregation: chooser table", ("chooser_k",)),
           ("Galerkin: bounds + scans", ("galerkin_bound_k", "scan_i64_k")),
           ("Galerkin: merge", ("galerkin_merge_k", "galerkin_wave_k")),
@@ -133,8 +142,8 @@ for phase, names in PHASES:
         rd += sum(v for _, v in per[k].get("FETCH_SIZE", [])) * 2. * 1024.
         wr += sum(v for _, v in per[k].get("WRITE_SIZE", [])) * 1024.
     setup_rows.append((phase, launches, us / 1e3, rd / 1e9, wr / 1e9, (rd + wr) / (us * 1e-6) / 1e12 if us else 0.))
-with open(os.path.join(root, "profiles", "r04_setup.csv"), "w") as fh:
-    fh.write("phase (one hierarchy of a_u at 10.24 M cells: levels 0->1, 1->2, 2->3; one stream; no sibling pairing),launches,kernel_ms,read_GB(FETCH_SIZEx2),written_GB(WRITE_SIZE),TB_per_s\n")
+with open(os.path.join(root, "profiles", PRE + "_setup.csv"), "w") as fh:
+    fh.write("phase (one hierarchy of a_u, %d rows: levels 0->1, 1->2, 2->3; one stream; no sibling pairing),launches" % N + ",kernel_ms,read_GB(FETCH_SIZEx2),written_GB(WRITE_SIZE),TB_per_s\n")
     for r in setup_rows:
         fh.write('"%s",%d,%.2f,%.2f,%.2f,%.2f\n' % r)
     tot = [sum(r[i] for r in setup_rows) for i in (1, 2, 3, 4)]

@@ -3,7 +3,8 @@
 then exactly the launches bench.py times — the level-0 products as the BiCGSTAB loop launches them (one system and three
 systems per launch: orc_bench_inloop_products), the plain product, and one product per level of a_u's Multigrid hierarchy
 (orc_bench_amg_levels: levels 0-1 spmv_uniform_k, levels 2-3 spmv_xwin_k) — `--reps` launches each after one warm launch.
-Run under `rocprofv3 --kernel-trace --stats` and, separately, one `--pmc` pass per counter group (scripts/gpu_pmc_r03.sh)."""
+Run under `rocprofv3 --kernel-trace --stats` and, separately, one `--pmc` pass per counter group (scripts/gpu_pmc.sh).
+`--workload config5`: the same for BASELINE configs[4]'s per-GPU slab (252 x 100 x 72 blocks of the mixed tet / hex / poly channel, 5.14 M cells)."""
 import argparse
 import os
 import sys
@@ -20,12 +21,20 @@ from orc_amd.solver import Solver  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--nx", type=int, default=400); ap.add_argument("--ny", type=int, default=160); ap.add_argument("--nz", type=int, default=160)
 ap.add_argument("--reps", type=int, default=6)
+ap.add_argument("--workload", default="hex", choices=["hex", "config5"])
 args = ap.parse_args()
 orc_amd.init(0)
-a = set_channel_bcs(hex_channel(args.nx, args.ny, args.nz))
-m = Mesh(a)
-s = Solver(m, NumericalSettings.default(momentum=5, momentum_relaxation=0.1, pressure_relaxation=0.001), 1000.0, 1e-3)
-s.set_fields(*initial_fields(np.asarray(a["cell_centroid"])))
+settings = NumericalSettings.default(momentum=5, momentum_relaxation=0.1, pressure_relaxation=0.001)
+if args.workload == "config5":
+    from orc_amd import parallel
+    dflt = (252, 100, 72)
+    nx, ny, nz = (v if v != d0 else d for v, d0, d in zip((args.nx, args.ny, args.nz), (400, 160, 160), dflt))
+    s, m, _n, _nnz, _facts = parallel.make_mixed_slab_solver(nx, ny, nz, 0, 1, settings, initial_fields)
+else:
+    a = set_channel_bcs(hex_channel(args.nx, args.ny, args.nz))
+    m = Mesh(a)
+    s = Solver(m, settings, 1000.0, 1e-3)
+    s.set_fields(*initial_fields(np.asarray(a["cell_centroid"])))
 s.assemble_momentum_only()
 inloop = s.bench_inloop_products(args.reps)
 plain, _ = s.bench_spmv(args.reps)
