@@ -34,6 +34,9 @@ int orc_device_count(void);                    /* 0 when no HIP device is visibl
 int orc_synchronize(void);                     /* hipStreamSynchronize on the library stream */
 const char *orc_status_string(int status);     /* the reference's panic text for the code */
 const char *orc_last_error(void);              /* detail of the last ORC_ERR_HIP / BAD_ARGUMENT */
+/* The library reads its environment switches (ORC_*: INTEGRATION.md lists them; none changes a result) ONCE, in the first orc_init; a caller
+ * that changes one afterwards — the tests do — says so here.  Never called by the library itself. */
+int orc_reload_environment(void);
 int orc_device_memory(int64_t *free_bytes, int64_t *total_bytes); /* hipMemGetInfo of the library's device */
 /* "<device name> | pci <domain:bus:device.function> | ordinal <n> | <CUs> CUs" of the library's device: a multi-GPU run reports it per rank,
  * so that "did N ranks run on N different cards" is answered by the result itself.  Returns ORC_ERR_BAD_ARGUMENT when cap is too small. */
@@ -303,18 +306,12 @@ int orc_bench_gs_sweep(OrcSolver *s, int reps, double *avg_ms, int *n_colors);
  * n_colors launches): avg_ms[0] one system (the p' solve), avg_ms[1] the u, v, w momentum systems per launch */
 int orc_bench_gs_sweep0(OrcSolver *s, int reps, double avg_ms[2], int *n_colors);
 int orc_bench_amg_levels(OrcSolver *s, int reps, int64_t *rows, int64_t *nnz, int64_t *padded, double *avg_ms, int *n_levels);
-/* Measurement only: force a product kernel variant for the next launches (0 = production choice, 1 = padded SELL-64,
- * 2 = padded with predicated padding, 3 = packed where a mirror exists, 4/5 = packed/padded WITHOUT the x gathers —
- * wrong results, times the matrix stream alone). */
-int orc_debug_set_spmv_variant(int variant);
 /* Test hook: how many level-0 products of partitioned operators this thread has run in the overlapped form (interior rows
  * on a second stream beside the halo exchange, rows along the cuts after it) since orc_init. */
 long long orc_debug_halo_overlaps(void);
 /* Which of the library's streams still hold work — hipStreamQuery, never blocks; meant for a watchdog thread while the calling thread of a
  * solve waits: one line per stream, "<name>[<lane>] priority <p> busy|idle".  Returns the number of busy streams (-1: buffer too short). */
 int orc_debug_stream_report(char *buf, int cap);
-/* test hook: products launched on a length-sorted image of a coarse level (XSortDev) since the process started */
-long long orc_debug_xsort_products(void);
 /* [r04] test hooks.  orc_debug_clamp_partials_grid: the ONE function through which every launcher sizes a grid whose workgroups
  * write per-workgroup partial sums (<= orc_debug_max_partials(), whatever the CU count or a measurement switch asks for); host only.
  * orc_debug_amg_certification: out[0] = aggregations whose asynchronous cascades were followed by the certifying lock-step

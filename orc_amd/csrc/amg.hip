@@ -75,72 +75,21 @@ __device__ __forceinline__ int agg_eval_row(const MatView &A, const int *__restr
     return bj;
 }
 
-__global__ void agg_init_k(MatView A, int *__restrict__ choice, unsigned char *__restrict__ active, unsigned char *__restrict__ active_next) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < A.P.n; i += (int64_t)gridDim.x * blockDim.x) {
-        choice[i] = agg_eval_row(A, nullptr, i, false);
-        if ((i & 63) == 0) { active[i >> 6] = 1; active_next[i >> 6] = 0; }
-    }
+__global__ void agg_init_k(MatView A, int *__restrict__ choice) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < A.P.n; i += (int64_t)gridDim.x * blockDim.x) choice[i] = agg_eval_row(A, nullptr, i, false);
 }
 
-// ---- preference lists [r04] ------------------------------------------------------------------------------------------
-// A row's decision is "the most negative entry whose column no earlier row holds" — the FIRST free column in the row's order of preference
-// (value ascending, position ascending: the strict <, first-wins scan of linear_algebra.rs:37-52).  That order does not change while the pairing is
-// sought, so the pass that computes the starting state (the unconstrained arg-min = the first preference) keeps the row's kPrefs most preferred
-// columns: prefs[kPrefs i ..] (-1 = fewer; bit 30 of the last entry = the row has more candidates than listed).  An evaluation then reads a few
-// bytes and probes <= kPrefs first takers instead of reading the row (2-4 lines) and probing every column (7 / 15 / 34 on the channel's levels):
-// the look-ups are most of the scattered lines the set-ups take from the products beside them.  When every listed column is taken and the row
-// has more, the full scan decides (exact either way: an unlisted column ranks behind every listed one).
-// How many: 8 was the first choice.  One hierarchy alone (profiles/r04_setup.csv): 8 columns: sweeps 10.6 GB, cascades 31.3 GB; 2 columns: sweeps
-// 7.2 GB, cascades 38.4 GB (a displaced row's first two preferences are often taken: the full scan runs more often).  Whole iterations on one box
-// drift upwards by 3-5 ms from run to run (found late: with the order of the two builds reversed the "winner" changed), so 8 -> 4 (769.0 / 763.1 ->
-// 758.7 / 760.1 ms, new build first) and 4 -> 2 (778.4 / 771.1 -> 769.9 / 763.8 new first; 764.7 / 768.9 / 778.1 against 769.6 / 776.0 / 782.6 old
-// first) say no more than "about equal"; 3 is worse either way (12-byte lists straddle lines).  Four it is.
+// Preference lists: a row's order of preference (value ascending, position ascending: the strict <, first-wins scan of linear_algebra.rs:37-52)
+// does not change while a pairing is sought; da_first_k keeps every row's kPrefs most preferred columns (-1 = fewer; bit 30 of the last entry =
+// the row has more candidates than listed).  Four: r04 measured 8 / 4 / 2 / 3 (lists of three straddle cache lines).
 constexpr int kPrefs = 4;
 constexpr int kPrefMore = 1 << 30;
-__global__ void agg_init_prefs_k(MatView A, int *__restrict__ choice, unsigned char *__restrict__ active, unsigned char *__restrict__ active_next,
-                                 int *__restrict__ prefs) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < A.P.n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int len = A.P.row_len[i];
-        const int64_t base = A.P.slice_ptr[i >> 6] + (i & 63);  // (the SELL image: lane = row, coalesced)
-        double bv[kPrefs];
-        int bj[kPrefs];
-#pragma unroll
-        for (int q = 0; q < kPrefs; ++q) { bv[q] = 1.7976931348623157e308; bj[q] = -1; }
-        int cand = 0;
-        for (int k = 0; k < len; ++k) {
-            const int64_t pos = base + (int64_t)k * 64;
-            const int j = A.P.col[pos];
-            if (j == i || j >= A.P.n) continue;
-            const double a = view_value(A, i, pos);
-            if (!(a < 1.7976931348623157e308)) continue;  // (the scan's "a < best" starts from Float::MAX: such an entry — or a NaN — is never chosen)
-            ++cand;
-            // its place: in front of the first listed entry it is strictly smaller than — an entry equal to a listed one stays behind it (it came
-            // later in the row) — and everything from there on moves one place back
-            int pos_q = kPrefs;
-#pragma unroll
-            for (int q = kPrefs - 1; q >= 0; --q)
-                if (a < bv[q]) pos_q = q;
-#pragma unroll
-            for (int q = kPrefs - 1; q >= 1; --q)
-                if (q > pos_q) { bv[q] = bv[q - 1]; bj[q] = bj[q - 1]; }
-#pragma unroll
-            for (int q = 0; q < kPrefs; ++q)
-                if (q == pos_q) { bv[q] = a; bj[q] = j; }
-        }
-        choice[i] = bj[0];
-#pragma unroll
-        for (int q = 0; q < kPrefs; ++q) prefs[i * kPrefs + q] = (q == kPrefs - 1 && cand > kPrefs && bj[q] >= 0) ? (bj[q] | kPrefMore) : bj[q];
-        if ((i & 63) == 0) { active[i >> 6] = 1; active_next[i >> 6] = 0; }
-    }
-}
 
-// one thread = one slice, rows in ascending order
-__global__ void agg_sweep_k(MatView A, int *__restrict__ choice, int *__restrict__ taken_by, const unsigned char *__restrict__ active,
-                            unsigned char *__restrict__ active_next, AggCounters *C, int all_active) {
+// one thread = one slice, rows in ascending order (the fallback of aggregate(): works on any pattern, symmetric or not)
+__global__ void agg_sweep_k(MatView A, int *__restrict__ choice, int *__restrict__ taken_by, AggCounters *C) {
     const int64_t n = A.P.n;
     int changed = 0;
     for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < A.P.n_slices; s += (int64_t)gridDim.x * blockDim.x) {
-        if (!all_active && !active[s]) continue;
         const int64_t lo = s * 64, hi = lo + 64 < n ? lo + 64 : n;
         for (int64_t i = lo; i < hi; ++i) {
             const int old = choice[i];
@@ -149,22 +98,8 @@ __global__ void agg_sweep_k(MatView A, int *__restrict__ choice, int *__restrict
             ++changed;
             choice[i] = nv;
             if (nv >= 0) atomicMin(&taken_by[nv], (int)i);
-            // `old` may still be taken by another row; leaving taken_by[old] <= i is only ever too
-            // pessimistic for rows > i and is repaired by the next round's rebuild, which cannot
-            // be skipped because this sweep counted a change.
-            // rows that can see the change: those holding old / nv in their pattern (symmetric: the
-            // columns of rows old / nv) and lying after i
-            const int js[2] = {old, nv};
-            for (int t = 0; t < 2; ++t) {
-                const int j = js[t];
-                if (j < 0) continue;
-                const int lj = A.P.row_len[j];
-                const int64_t bj = A.P.slice_ptr[j >> 6] + (j & 63);
-                for (int kk = 0; kk < lj; ++kk) {
-                    const int m = A.P.col[bj + (int64_t)kk * 64];
-                    if (m > i && m < n) active_next[m >> 6] = 1;
-                }
-            }
+            // `old` may still be taken by another row; leaving taken_by[old] <= i is only ever too pessimistic for rows > i and is repaired
+            // by the next sweep's rebuild, which cannot be skipped because this sweep counted a change.
         }
     }
     if (changed) atomicAdd(&C->changed, changed);
@@ -176,24 +111,6 @@ __global__ void agg_rotate_k(AggCounters *C, int *snapshot) {
         C->changed = 0;
         C->rounds += 1;
     }
-}
-
-// ---- tail phase: row-level Jacobi rounds with an incrementally exact taken_by ----------------
-// After the bulk sweeps what is left are long thin cascades (e.g. the last cell of every x-line
-// handing its partner on to the next line: ~ny dependent steps) that touch a handful of rows per
-// round, so a round must cost microseconds: evaluate the listed rows against the committed state,
-// commit, recompute taken_by for the two columns every change touches, activate later rows.
-struct TailCounters {
-    int cur, changed, next, rounds;
-    int parity;    // which of the two work lists is the current one (the other collects the next round's rows)
-    int first;     // first round: every row is evaluated, no list
-    int finished;  // a round without a change has been seen: the fixed point is certified
-    int fetch;     // cascades: next unclaimed entry of the current list (groups claim rows as they become free)
-    int moved;     // cascades, statistics: evaluations that changed their row's partner (all launches of an aggregation)
-};
-
-__global__ void tail_seed_k(TailCounters *T, int n) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) { T->cur = n; T->changed = 0; T->next = 0; T->rounds = 0; T->parity = 1; T->first = 1; T->finished = 0; T->fetch = 0; T->moved = 0; }
 }
 
 // One atomicAdd per wavefront instead of one per lane: the lanes that want a slot are counted with a ballot, the
@@ -209,673 +126,6 @@ __device__ __forceinline__ int wave_append_slot(int *counter, bool want) {
     if (lane == leader) base = atomicAdd(counter, __popcll(m));
     base = __shfl(base, leader, 64);
     return base + __popcll(m & ((1ull << lane) - 1ull));
-}
-
-// Row-level kernels use one 16-lane group per row: coarse-level rows hold 40-100 entries and a single thread
-// walking them is a chain of dependent gathers.  Lanes take entries k = lane, lane+16, ...; the group then
-// reduces (value, k) lexicographically, which is exactly the sequential "strict <, first wins" scan.
-constexpr int kG = 16;
-
-// entry k of row i: column and value through the view, from the row-contiguous mirror where the matrix has one
-struct RowWalk {
-    const int32_t *col;
-    const double *val;
-    int64_t base, stride;
-    __device__ __forceinline__ RowWalk(const MatView &A, int64_t i) {
-        if (A.rows.col) { col = A.rows.col; val = A.rows.val; base = A.rows.slice_base[i >> 6] + A.rows.intra_off[i]; stride = 1; }
-        else { col = A.P.col; val = A.val; base = A.P.slice_ptr[i >> 6] + (i & 63); stride = 64; }
-    }
-    __device__ __forceinline__ int column(int k) const { return col[base + (int64_t)k * stride]; }
-    __device__ __forceinline__ double value(const MatView &A, int64_t i, int k) const {
-        double v = val[base + (int64_t)k * stride];
-        if (A.s1) v = A.s1[i] * v;
-        if (A.s2) v = A.s2[i] * v;
-        return v;
-    }
-};
-
-__device__ __forceinline__ int group_eval_row(const MatView &A, const int *__restrict__ taken_by, int64_t i, int gl) {
-    const int len = A.P.row_len[i];
-    const RowWalk W(A, i);
-    double best = 1.7976931348623157e308;  // Float::MAX
-    int bk = 0x7fffffff, bj = -1;
-    for (int k = gl; k < len; k += kG) {
-        const int j = W.column(k);
-        if (j == i || j >= A.P.n) continue;
-        if (taken_by[j] < i) continue;
-        const double a = W.value(A, i, k);
-        if (a < best) { best = a; bk = k; bj = j; }
-    }
-#pragma unroll
-    for (int off = kG / 2; off > 0; off >>= 1) {
-        const double ob = __shfl_xor(best, off, kG);
-        const int ok = __shfl_xor(bk, off, kG);
-        const int oj = __shfl_xor(bj, off, kG);
-        if (ob < best || (ob == best && ok < bk)) { best = ob; bk = ok; bj = oj; }
-    }
-    return bj;
-}
-
-// ---- the slice sweep with a group of G lanes per slice [r03].  agg_sweep_k gives a slice to ONE thread, which walks its 64 rows
-// in order and every row entry by entry: fine for 7 entries per row (10.24 M rows: 4 ms), but the coarse levels have few
-// slices and long rows — 40 000 threads (2.4 wavefronts per CU) each chasing 64 x 34 dependent loads took 7 ms on level 2, more
-// than level 0.  Here the 64 rows of a slice are still visited in order (that is the point of the sweep: chains inside a slice
-// resolve in one pass), but the entries of a row are read G at a time (coalesced from the row-contiguous mirror where the level
-// has one) and reduced by (value, position), exactly the sequential "strict <, first wins" scan; lane 0 commits.  Like the
-// thread sweep this is a relaxation whose result only has to be a good starting state: the lock-step rounds certify the pairing.
-template <int G>
-__device__ __forceinline__ int group_eval_row_g(const MatView &A, const int *__restrict__ taken_by, int64_t i, int gl) {
-    const int len = A.P.row_len[i];
-    const RowWalk W(A, i);
-    double best = 1.7976931348623157e308;  // Float::MAX
-    int bk = 0x7fffffff, bj = -1;
-    for (int k = gl; k < len; k += G) {
-        const int j = W.column(k);
-        if (j == i || j >= A.P.n) continue;
-        if (taken_by[j] < i) continue;
-        const double a = W.value(A, i, k);
-        if (a < best) { best = a; bk = k; bj = j; }
-    }
-#pragma unroll
-    for (int off = G / 2; off > 0; off >>= 1) {
-        const double ob = __shfl_xor(best, off, G);
-        const int ok = __shfl_xor(bk, off, G);
-        const int oj = __shfl_xor(bj, off, G);
-        if (ob < best || (ob == best && ok < bk)) { best = ob; bk = ok; bj = oj; }
-    }
-    return bj;
-}
-
-// the group's answer from the preference list; lanes beyond the list idle.  scan_row: the list ran out and the row has more candidates
-template <int G>
-__device__ __forceinline__ int group_eval_pref(const int *__restrict__ prefs, const int *__restrict__ taken_by, int64_t i, int gl, bool &scan_row) {
-    scan_row = false;
-    const int shift = (threadIdx.x & 63) & ~(G - 1);
-    for (int q0 = 0; q0 < kPrefs; q0 += G) {
-        const int q = q0 + gl;
-        int j = -1;
-        bool more = false;
-        if (q < kPrefs) {
-            const int raw = prefs[i * kPrefs + q];
-            more = raw >= 0 && (raw & kPrefMore) != 0;
-            j = raw >= 0 ? (raw & ~kPrefMore) : -1;
-        }
-        const bool is_free = j >= 0 && taken_by[j] >= i;
-        const unsigned long long all = __ballot(is_free);
-        const unsigned long long mine = G == 64 ? all : ((all >> shift) & ((1ull << G) - 1ull));
-        if (mine) return __shfl(j, __ffsll((long long)mine) - 1, G);
-        const unsigned long long ended_all = __ballot(q < kPrefs && j < 0);  // the list ended inside this batch: every candidate is taken
-        const unsigned long long ended = G == 64 ? ended_all : ((ended_all >> shift) & ((1ull << G) - 1ull));
-        if (ended) return -1;
-        const unsigned long long more_all = __ballot(more);
-        const unsigned long long more_g = G == 64 ? more_all : ((more_all >> shift) & ((1ull << G) - 1ull));
-        if (q0 + G >= kPrefs) { scan_row = more_g != 0ull; return -1; }
-    }
-    return -1;
-}
-
-// [r04] What the sweep leaves to the cascades is NOT its seams: walking 3 ... 32 adjacent slices per group, and reading the first-taker table
-// past the vector L1, leave the same 2.7 M of 10.24 M rows away from the fixed point (ORC_AMG_TRACE "[amg distance]", scripts/gpu_r04_t.sh).  On
-// the channel the fixed point differs from the arg-min state in a triangle at the end of every grid line — the last row of line j has no
-// downstream neighbour and takes the one above, which displaces the last-but-one row of line j + 1, and so on (scripts/analysis/
-// pairing_structure.py) — chains of up to min(nx, ny) links that hop nx - 1 rows each: no slice-local order resolves them.
-template <int G>
-__global__ __launch_bounds__(kBlock) void agg_sweep_group_k(MatView A, int *__restrict__ choice, int *__restrict__ taken_by, const unsigned char *__restrict__ active,
-                                                            unsigned char *__restrict__ active_next, AggCounters *C, int all_active,
-                                                            const int *__restrict__ prefs /* preference lists (agg_init_prefs_k) or null */) {
-    const int64_t n = A.P.n;
-    const int gl = threadIdx.x & (G - 1);
-    const int64_t groups = ((int64_t)gridDim.x * blockDim.x) / G;
-    int changed = 0;
-    for (int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G; s < A.P.n_slices; s += groups) {
-        if (!all_active && !active[s]) continue;
-        const int64_t lo = s * 64, hi = lo + 64 < n ? lo + 64 : n;
-        for (int64_t i = lo; i < hi; ++i) {
-            int nv;
-            if (prefs) {
-                bool scan_row;
-                nv = group_eval_pref<G>(prefs, taken_by, i, gl, scan_row);
-                if (scan_row) nv = group_eval_row_g<G>(A, taken_by, i, gl);
-            } else {
-                nv = group_eval_row_g<G>(A, taken_by, i, gl);
-            }
-            const int old = choice[i];
-            if (nv == old) continue;
-            if (gl == 0) {
-                ++changed;
-                choice[i] = nv;
-                if (nv >= 0) atomicMin(&taken_by[nv], (int)i);
-            }
-            // rows that can see the change: those holding old / nv in their pattern (symmetric: the columns of rows old / nv), after i
-            const int js[2] = {old, nv};
-            for (int t = 0; t < 2; ++t) {
-                const int j = js[t];
-                if (j < 0) continue;
-                const int lj = A.P.row_len[j];
-                const RowWalk Wj(A, j);
-                for (int kk = gl; kk < lj; kk += G) {
-                    const int m = Wj.column(kk);
-                    if (m > i && m < n) active_next[m >> 6] = 1;
-                }
-            }
-        }
-    }
-    if (changed) atomicAdd(&C->changed, changed);
-}
-
-// G lanes per row [r03]: a row's evaluation is a chain of dependent round trips (length -> start -> columns -> first takers), a
-// group walks its rows one after the other, and the launch is as large as the chip holds — so the time of a whole-level round is
-// (rows per group) x (trips per row), and narrower groups mean more rows in flight: 8 lanes on the levels of 7 and 15 entries per
-// row, 16 beyond — was the first guess; measured, 4 lanes are the fastest on every level (ORC_AMG_EVAL_GROUP overrides).
-template <int G>
-__global__ void tail_eval_k(MatView A, const int *__restrict__ choice, const int *__restrict__ taken_by, const int *__restrict__ list_a,
-                            const int *__restrict__ list_b, TailCounters *T, int *__restrict__ flag, int *__restrict__ ch_row, int *__restrict__ ch_new,
-                            const int *__restrict__ prefs /* preference lists or null */) {
-    if (T->finished) return;
-    const int count = T->cur;
-    const int *__restrict__ list = T->first ? nullptr : (T->parity ? list_b : list_a);
-    const int gl = threadIdx.x & (G - 1);
-    const int64_t groups = ((int64_t)gridDim.x * blockDim.x) / G;
-    for (int64_t idx = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G; idx < count; idx += groups) {
-        const int i = list ? list[idx] : (int)idx;
-        int nv;
-        if (prefs) {
-            bool scan_row;
-            nv = group_eval_pref<G>(prefs, taken_by, i, gl, scan_row);
-            if (scan_row) nv = group_eval_row_g<G>(A, taken_by, i, gl);
-        } else {
-            nv = group_eval_row_g<G>(A, taken_by, i, gl);
-        }
-        bool changed = false;
-        if (gl == 0) {
-            flag[i] = 0;
-            changed = nv != choice[i];
-        }
-        const int slot = wave_append_slot(&T->changed, changed);
-        if (changed) {
-            ch_row[slot] = i;
-            ch_new[slot] = nv;
-        }
-    }
-}
-
-// commit the changes; remember who held the two touched columns before (for the exact activation interval)
-__global__ void tail_commit_k(int *__restrict__ choice, const int *__restrict__ taken_by, const TailCounters *T, const int *__restrict__ ch_row,
-                              const int *__restrict__ ch_new, int *__restrict__ ch_old, int *__restrict__ ch_t_old, int *__restrict__ ch_t_new) {
-    if (T->finished) return;
-    const int count = T->changed;
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < count; idx += gridDim.x * blockDim.x) {
-        const int i = ch_row[idx];
-        const int old = choice[i], nv = ch_new[idx];
-        ch_old[idx] = old;
-        ch_t_old[idx] = old >= 0 ? taken_by[old] : 0x7fffffff;
-        ch_t_new[idx] = nv >= 0 ? taken_by[nv] : 0x7fffffff;
-        choice[i] = nv;
-    }
-}
-
-// exact taken_by for the columns touched by the committed changes + activation of the rows that can see them.
-// Column j's first taker moves from t_old to t_new; only rows m holding j with min < m <= max see a different
-// "taken" status: if j got taken earlier, just those that had chosen it; if it was freed, all of them (they may
-// prefer it now).
-__device__ __forceinline__ void tail_touch_column(const MatView &A, const int *choice, int *taken_by, int j, int t_before, int gl, int *flag,
-                                                  int *next_list, int *next_count) {
-    const int lj = A.P.row_len[j];
-    const RowWalk W(A, j);
-    int mn = 0x7fffffff;
-    for (int kk = gl; kk < lj; kk += kG) {  // rows holding column j = (symmetric pattern) the columns of row j
-        const int m = W.column(kk);
-        if (m >= A.P.n || m == j) continue;
-        if (choice[m] == j && m < mn) mn = m;
-    }
-#pragma unroll
-    for (int off = kG / 2; off > 0; off >>= 1) mn = min(mn, __shfl_xor(mn, off, kG));
-    if (mn != t_before) {
-        const int lo = min(mn, t_before), hi = max(mn, t_before);
-        const bool taken_earlier = mn < t_before;
-        for (int kk = gl; kk < lj; kk += kG) {
-            const int m = W.column(kk);
-            if (m >= A.P.n || m <= lo || m > hi) continue;
-            const bool push = !(taken_earlier && choice[m] != j) && atomicExch(&flag[m], 1) == 0;
-            const int slot = wave_append_slot(next_count, push);
-            if (push) next_list[slot] = m;
-        }
-    }
-    if (gl == 0) taken_by[j] = mn;  // several changes touching j compute the same value
-}
-
-__global__ void tail_update_k(MatView A, const int *__restrict__ choice, int *__restrict__ taken_by, TailCounters *T,
-                              const int *__restrict__ ch_row, const int *__restrict__ ch_new, const int *__restrict__ ch_old,
-                              const int *__restrict__ ch_t_old, const int *__restrict__ ch_t_new, int *__restrict__ flag,
-                              int *__restrict__ list_a, int *__restrict__ list_b) {
-    if (T->finished) return;
-    const int count = T->changed;
-    int *__restrict__ next_list = T->parity ? list_a : list_b;
-    const int gl = threadIdx.x & (kG - 1);
-    const int64_t groups = ((int64_t)gridDim.x * blockDim.x) / kG;
-    for (int64_t idx = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kG; idx < count; idx += groups) {
-        const int old = ch_old[idx], nv = ch_new[idx];
-        if (old >= 0) tail_touch_column(A, choice, taken_by, old, ch_t_old[idx], gl, flag, next_list, &T->next);
-        if (nv >= 0) tail_touch_column(A, choice, taken_by, nv, ch_t_new[idx], gl, flag, next_list, &T->next);
-    }
-}
-
-__global__ void tail_rotate_k(TailCounters *T) {
-    if (blockIdx.x == 0 && threadIdx.x == 0 && !T->finished) {
-        if (T->changed == 0) T->finished = 1;  // an evaluation round without a change: fixed point
-        T->cur = T->next;
-        T->next = 0;
-        T->changed = 0;
-        T->rounds += 1;
-        T->parity ^= 1;
-        T->first = 0;
-        T->fetch = 0;
-    }
-}
-
-// The same rounds inside ONE workgroup while the work list is short: the cascades that remain after the first rounds
-// touch tens to hundreds of rows for hundreds of dependent rounds (one row of an x-line hands its partner on to the
-// next), and four kernel boundaries per round cost more than the round's work.  __syncthreads() separates the phases —
-// evaluate against the committed state, commit, repair taken_by and activate — exactly as the kernel boundaries do, so
-// the same fixed point is reached.  Returns when a round changes nothing (finished), when the list outgrows
-// kTailSmallMax rows (the four-kernel rounds take over), or after max_rounds.
-__global__ __launch_bounds__(1024) void tail_small_k(MatView A, int *choice, int *taken_by, TailCounters *T, int *list_a, int *list_b, int *flag,
-                                                     int *ch_row, int *ch_new, int *ch_old, int *ch_t_old, int *ch_t_new, int max_rounds, int kTailSmallMax) {
-    // (no __restrict__: every array is written in one phase and read by other waves in the next)
-    __shared__ int s_changed, s_next, s_cur, s_parity;
-    const int tid = threadIdx.x, gl = tid & (kG - 1);
-    const int groups = blockDim.x / kG;
-    if (T->finished || T->first || T->cur > kTailSmallMax) return;
-    if (tid == 0) { s_cur = T->cur; s_parity = T->parity; }
-    __syncthreads();
-    int rounds = 0;
-    bool finished = false;
-    while (rounds < max_rounds) {
-        if (tid == 0) { s_changed = 0; s_next = 0; }
-        __syncthreads();
-        const int count = s_cur;
-        const int *cur = s_parity ? list_b : list_a;
-        int *next = s_parity ? list_a : list_b;
-        // ---- evaluate the listed rows against the committed state
-        for (int idx = tid / kG; idx < count; idx += groups) {
-            const int i = cur[idx];
-            const int nv = group_eval_row(A, taken_by, i, gl);
-            bool changed = false;
-            if (gl == 0) {
-                flag[i] = 0;
-                changed = nv != choice[i];
-            }
-            const int slot = wave_append_slot(&s_changed, changed);
-            if (changed) {
-                ch_row[slot] = i;
-                ch_new[slot] = nv;
-            }
-        }
-        __syncthreads();
-        const int nchg = s_changed;
-        ++rounds;
-        if (nchg == 0) { finished = true; break; }
-        // ---- commit
-        for (int idx = tid; idx < nchg; idx += blockDim.x) {
-            const int i = ch_row[idx];
-            const int old = choice[i], nv = ch_new[idx];
-            ch_old[idx] = old;
-            ch_t_old[idx] = old >= 0 ? taken_by[old] : 0x7fffffff;
-            ch_t_new[idx] = nv >= 0 ? taken_by[nv] : 0x7fffffff;
-            choice[i] = nv;
-        }
-        __syncthreads();
-        // ---- exact taken_by of the touched columns + activation
-        for (int idx = tid / kG; idx < nchg; idx += groups) {
-            const int old = ch_old[idx], nv = ch_new[idx];
-            if (old >= 0) tail_touch_column(A, choice, taken_by, old, ch_t_old[idx], gl, flag, next, &s_next);
-            if (nv >= 0) tail_touch_column(A, choice, taken_by, nv, ch_t_new[idx], gl, flag, next, &s_next);
-        }
-        __syncthreads();
-        if (tid == 0) { s_cur = s_next; s_parity ^= 1; }
-        __syncthreads();
-        if (s_cur > kTailSmallMax) break;
-    }
-    if (tid == 0) {
-        T->cur = finished ? 0 : s_cur;
-        T->next = 0;
-        T->changed = 0;
-        T->rounds += rounds;
-        T->parity = s_parity;
-        if (finished) T->finished = 1;
-    }
-}
-
-// ---- asynchronous tail: one wavefront follows one cascade ---------------------------------------------------------
-// What is left after the first row-level round are cascades: a row changes its partner, which frees one column and takes
-// another, which makes exactly one later row change, ... for hundreds of dependent steps (the traces show work lists
-// whose every row changes, shrinking by a few rows per round).  Lock-step rounds pay four kernel boundaries per step of
-// the LONGEST cascade; here a wavefront takes a listed row and follows its cascade on its own — evaluate, commit, repair
-// the two touched columns, continue with the first row that activates — so a step costs a chain of L2 round trips
-// instead of a round of launches.  Cascades run concurrently and may meet, hence the protocol:
-//   * shared state (choice, first-taker table, row flags) is read and written with agent-scope atomics only;
-//   * a row is owned by one wavefront at a time: flag bit 1 = running, bit 0 = queued / re-run requested.  An
-//     activation that finds the row running only sets bit 0 and the owner runs it again when it is through;
-//   * the first taker of a column is kept with a version: (version << 32 | first row).  Whoever changes a row's
-//     partner bumps the versions of the old and the new column AFTER the commit, scans the column and installs its
-//     result with an atomic max, so the scan that started after the last commit is the one that stays;
-//   * each install activates the rows whose "taken before me" status differs between the value it replaced and the
-//     one it installed; a row that committed to a column and then finds an earlier taker in its own scan re-queues
-//     itself (the store-buffering race between its commit and the earlier taker's activation pass).
-// Every loop is bounded: no wavefront ever waits for another.  The fixed point is unique, so the result does not depend
-// on the interleaving; and because the row-level rounds run once more from scratch afterwards (exact first takers
-// rebuilt, every row evaluated), a flaw here could only cost time: a round that changes nothing certifies the pairing.
-// Ordering between this wavefront's accesses to the shared state: every one of them is an agent-scope atomic that is
-// performed at the device's coherence point, so all that is needed is to wait for the previous ones to complete before
-// the next is issued (s_waitcnt).  A device-scope fence would also write back and invalidate the XCD's L2 — measured at
-// hundreds of microseconds per fence with thousands of wavefronts doing it — and there is no plain shared data to flush.
-// The workgroup-scope fence keeps the COMPILER from moving accesses across this point; the wait makes the HARDWARE finish every
-// outstanding vector-memory access of this wavefront (the relaxed agent-scope atomics above it: stores and returning atomics
-// count in vmcnt, loads too) before the next one is issued — at workgroup scope the fence alone need not wait for global stores
-// to be performed.  No cache is written back or invalidated.  (r03 shipped this wait behind a build switch nobody defined; it is
-// unconditional again: no measurable cost at 10.24 M cells, and tests/test_gpu_multigrid.py asserts that the certification
-// rounds after the cascades change nothing.)
-__device__ __forceinline__ void chase_fence() {
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) expcnt(0) lgkmcnt(0)
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-}
-__device__ __forceinline__ int ld_i(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_i(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ int first_taker(const unsigned long long *tb, int j) {
-    return (int)(unsigned)(__hip_atomic_load(tb + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xffffffffull);
-}
-
-__global__ void chase_convert_k(const int *__restrict__ taken_by, unsigned long long *__restrict__ tb, int *__restrict__ ver, int64_t n) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        tb[i] = (unsigned long long)(unsigned)taken_by[i];  // version 0
-        ver[i] = 0;
-    }
-}
-
-// queue row m unless it is queued already; true when the caller has to find it a place (list or continuation)
-__device__ __forceinline__ bool chase_request(int *flag, int m) { return __hip_atomic_fetch_or(flag + m, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0; }
-
-// A cascade is followed by a group of G lanes (G = 16, 32 or 64, by the level's row length): short rows leave most of a
-// wavefront idle, and what limits the early rounds is the number of cascades in flight.  Control flow is uniform inside
-// a group; the groups of a wavefront run the same code on different rows and diverge only where their cascades do.
-template <int G>
-__device__ __forceinline__ unsigned long long group_ballot(bool p) {
-    const unsigned long long m = __ballot(p);
-    if (G == 64) return m;
-    const int shift = (threadIdx.x & 63) & ~(G - 1);
-    return (m >> shift) & ((1ull << G) - 1ull);
-}
-
-// the group's rows to queue: the first becomes its continuation when it has none, the rest go to the next list
-template <int G>
-__device__ __forceinline__ void chase_place(bool enq, int m, int gl, int &cont, int *next_list, int *next_count) {
-    unsigned long long mask = group_ballot<G>(enq);
-    if (!mask) return;
-    if (cont < 0) {
-        const int leader = __ffsll((long long)mask) - 1;
-        cont = __shfl(m, leader, G);
-        mask &= mask - 1ull;
-        if (gl == leader) enq = false;
-        if (!mask) return;
-    }
-    const int first = __ffsll((long long)mask) - 1;
-    int base = 0;
-    if (gl == first) base = atomicAdd(next_count, __popcll(mask));
-    base = __shfl(base, first, G);
-    if (enq) next_list[base + __popcll(mask & ((1ull << gl) - 1ull))] = m;
-}
-
-// Row i (running, owned by this wavefront) moved from column jj[0] to column jj[1] (-1: none).  Both columns are repaired
-// together, phase by phase, so that their memory round trips overlap — a cascade's speed is the number of dependent
-// round trips per step: versions + row geometry, column lists, the takers' choices, the two installs, the activations.
-// The geometry of the two rows (length, where their entries start) does not depend on the commit, so the caller loads it
-// BEFORE the commit and its round trip rides with the commit's; the version bumps then travel with the column lists.
-struct ChaseGeom {
-    int lj[2];
-    const int32_t *colp[2];
-    int64_t cbase[2], cstride[2];
-    __device__ __forceinline__ ChaseGeom(const MatView &A, const int (&jj)[2]) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            lj[t] = 0; colp[t] = nullptr; cbase[t] = 0; cstride[t] = 1;
-            if (jj[t] < 0) continue;
-            lj[t] = A.P.row_len[jj[t]];
-            const RowWalk W(A, jj[t]);
-            colp[t] = W.col; cbase[t] = W.base; cstride[t] = W.stride;
-        }
-    }
-};
-
-template <int G>
-__device__ __forceinline__ void chase_touch2(const MatView &A, const int *choice, unsigned long long *tb, int *ver, int *flag, const int (&jj)[2], int i,
-                                             const ChaseGeom &geo, int lane, int &cont, int *next_list, int *next_count, int &was) {
-    const int n = (int)A.P.n;
-    int m0[2] = {-1, -1}, c0[2] = {-2, -2}, mn[2] = {0x7fffffff, 0x7fffffff};
-    unsigned v[2] = {0u, 0u};
-    const int (&lj)[2] = geo.lj;
-    const int32_t *const (&colp)[2] = geo.colp;
-    const int64_t (&cbase)[2] = geo.cbase, (&cstride)[2] = geo.cstride;
-    // ---- versions (after the commit)
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        if (jj[t] < 0) continue;
-        if (lane == 0) v[t] = (unsigned)__hip_atomic_fetch_add(ver + jj[t], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-    }
-    // ---- the rows holding each column (symmetric pattern: the columns of row j); first G entries kept in registers
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-        if (jj[t] >= 0 && lane < lj[t]) m0[t] = colp[t][cbase[t] + (int64_t)lane * cstride[t]];
-    chase_fence();  // the version bumps are performed before any taker's choice is read
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-        if (m0[t] >= 0 && m0[t] < n && m0[t] != jj[t]) c0[t] = ld_i(choice + m0[t]);
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        if (jj[t] < 0) continue;
-        if (c0[t] == jj[t]) mn[t] = m0[t];
-        for (int kk = G + lane; kk < lj[t]; kk += G) {  // rows longer than the group
-            const int m = colp[t][cbase[t] + (int64_t)kk * cstride[t]];
-            if (m >= n || m == jj[t]) continue;
-            if (ld_i(choice + m) == jj[t] && m < mn[t]) mn[t] = m;
-        }
-#pragma unroll
-        for (int off = G / 2; off > 0; off >>= 1) mn[t] = min(mn[t], __shfl_xor(mn[t], off, G));
-    }
-    // ---- install (newest version wins)
-    unsigned prev_lo[2] = {0u, 0u}, prev_hi[2] = {0u, 0u};
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        if (jj[t] < 0) continue;
-        v[t] = (unsigned)__shfl((int)v[t], 0, G);
-        if (lane == 0) {
-            const unsigned long long packed = ((unsigned long long)v[t] << 32) | (unsigned long long)(unsigned)mn[t];
-            const unsigned long long prev = __hip_atomic_fetch_max(tb + jj[t], packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            prev_lo[t] = (unsigned)(prev & 0xffffffffull);
-            prev_hi[t] = (unsigned)(prev >> 32);
-        }
-    }
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        prev_lo[t] = (unsigned)__shfl((int)prev_lo[t], 0, G);
-        prev_hi[t] = (unsigned)__shfl((int)prev_hi[t], 0, G);
-    }
-    chase_fence();  // installs before activations
-    // an earlier row holds the column this row has just committed to: evaluate this row again.  Then the row is released
-    // (running -> idle, or -> queued when somebody, or the line above, asked for it): the answer travels with the
-    // activations below, which concern other rows only.
-    if (lane == 0) {
-        if (jj[1] >= 0 && mn[1] < i) __hip_atomic_fetch_or(flag + i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        was = __hip_atomic_fetch_and(flag + i, ~2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    // ---- activate the rows that see a column differently now
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        if (jj[t] < 0) continue;
-        const int t_before = (int)prev_lo[t];
-        if (prev_hi[t] < v[t] && mn[t] != t_before) {  // this scan is the newest one
-            const int lo = min(mn[t], t_before), hi = max(mn[t], t_before);
-            const bool taken_earlier = mn[t] < t_before;
-            for (int k0 = 0; k0 < lj[t]; k0 += G) {
-                const int kk = k0 + lane;
-                int m = -1, cm = -2;
-                if (k0 == 0) { m = m0[t]; cm = c0[t]; }
-                else if (kk < lj[t]) m = colp[t][cbase[t] + (int64_t)kk * cstride[t]];
-                bool want = m >= 0 && m < n && m > lo && m <= hi;
-                if (want && taken_earlier) {  // only a row that had chosen j loses it (read after this row's commit)
-                    if (k0 != 0) cm = ld_i(choice + m);
-                    want = cm == jj[t];
-                }
-                const bool enq = want && chase_request(flag, m);
-                chase_place<G>(enq, m, lane, cont, next_list, next_count);
-            }
-        }
-    }
-}
-
-// rows per claim of a cascade launch: the list spread over twice the launch's groups, 1 to 16
-__device__ __forceinline__ int chase_claim(int count, int n_groups) { return max(1, min(16, count / (2 * n_groups))); }
-
-template <int G>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8))) void tail_chase_k(MatView A, int *choice, unsigned long long *tb, int *ver, int *flag, TailCounters *T, int *list_a,
-                                                       int *list_b, int max_steps, const int *__restrict__ prefs) {
-    const int count = T->cur;
-    if (T->finished || count == 0) return;
-    const int *cur = T->parity ? list_b : list_a;
-    int *next = T->parity ? list_a : list_b;
-    const int lane = threadIdx.x & (G - 1);  // lane inside the group
-    int steps = 0;
-    // [r04] The list is a queue behind ONE counter, and same-address atomics retire at 11.4 ns per wave-instruction on this chip
-    // (scripts/microbench/atomic_rate.hip): the 8 192 wavefronts of a launch paid 93 us for their first claims alone, however short the
-    // list.  So every group OWNS a first share of the list by its index — `claim` rows, the list spread over twice the launch's groups,
-    // 1 to 16 rows a claim — and only what lies beyond those shares is claimed through the counter, `claim` rows per atomic.  (A plain-load
-    // look at the counter before every claim was measured too: +14 % on the cascades — most claims are single-step rows, and the look is one
-    // more round trip for each of them.)  Rows a group owns or claimed and did not reach go to the next list below.
-    const int n_groups = (int)gridDim.x * (kBlock / G);
-    const int claim = chase_claim(count, n_groups);
-    const int static_end = n_groups * claim;  // (chase_carry_k computes the same)
-    int c_idx = ((int)blockIdx.x * (kBlock / G) + (int)threadIdx.x / G) * claim;  // this group's entries [c_idx, c_idx + c_left)
-    int c_left = max(0, min(claim, count - c_idx));
-    int moved = 0;
-    while (steps < max_steps) {  // (rows nobody claims before the budgets run out are carried over by chase_carry_k)
-        if (c_left == 0) {
-            if (static_end >= count) break;  // the static shares were the whole list
-            int b = 0;
-            if (lane == 0) b = static_end + atomicAdd(&T->fetch, claim);
-            b = __shfl(b, 0, G);
-            if (b >= count) break;
-            c_idx = b;
-            c_left = min(claim, count - b);
-        }
-        int i = cur[c_idx];
-        ++c_idx;
-        --c_left;
-        while (i >= 0) {
-            if (steps >= max_steps) {  // hand the row (still queued) to the next launch
-                if (lane == 0) next[atomicAdd(&T->next, 1)] = i;
-                break;
-            }
-            ++steps;
-            // queued -> running.  A request that lands before this store is served by the evaluation below (its install
-            // precedes it); one that lands after finds the row running and is seen when the row is through.
-            if (lane == 0) st_i(flag + i, 2);
-            const int old = ld_i(choice + i);  // only the owner writes it
-            // ---- evaluate (group_eval_row over the wavefront, against the versioned table)
-            // [r04] from the row's preference list where the level has one (agg_init_prefs_k): a few bytes and <= kPrefs look-ups instead of
-            // the row and one look-up per entry; the full scan only when every listed column is taken and the row has more
-            bool scan_row = prefs == nullptr;
-            int pref_nv = -1;
-            if (prefs) {
-                int j = -1;
-                bool more = false;
-                if (lane < kPrefs) {
-                    const int raw = prefs[(int64_t)i * kPrefs + lane];
-                    more = raw >= 0 && (raw & kPrefMore) != 0;
-                    j = raw >= 0 ? (raw & ~kPrefMore) : -1;
-                }
-                chase_fence();  // the flag store is performed before the table is read
-                const bool is_free = j >= 0 && first_taker(tb, j) >= i;
-                const unsigned long long mine = group_ballot<G>(is_free);
-                if (mine) pref_nv = __shfl(j, __ffsll((long long)mine) - 1, G);
-                else if (!group_ballot<G>(lane < kPrefs && j < 0)) scan_row = group_ballot<G>(more) != 0ull;  // (the list did not end: more behind it?)
-            }
-            const int len = scan_row ? A.P.row_len[i] : 0;
-            const RowWalk W(A, i);
-            double best = 1.7976931348623157e308;  // Float::MAX
-            int bk = 0x7fffffff, bj = -1;
-            for (int k0 = 0; k0 < len; k0 += G) {
-                const int k = k0 + lane;
-                int j = -1;
-                double a = 0.;
-                if (k < len) { j = W.column(k); a = W.value(A, i, k); }
-                if (k0 == 0) chase_fence();  // the flag store is performed before the table is read
-                if (j < 0 || j == i || j >= A.P.n) continue;
-                if (first_taker(tb, j) < i) continue;
-                if (a < best) { best = a; bk = k; bj = j; }
-            }
-#pragma unroll
-            for (int off = G / 2; off > 0; off >>= 1) {
-                const double ob = __shfl_xor(best, off, G);
-                const int ok = __shfl_xor(bk, off, G);
-                const int oj = __shfl_xor(bj, off, G);
-                if (ob < best || (ob == best && ok < bk)) { best = ob; bk = ok; bj = oj; }
-            }
-            const int nv = scan_row ? bj : pref_nv;
-            int cont = -1, was = 0;
-            if (nv != old) {
-                ++moved;
-                const int jj[2] = {old, nv};
-                const ChaseGeom geo(A, jj);  // in flight together with the commit
-                if (lane == 0) st_i(choice + i, nv);
-                chase_fence();  // commit before the version bumps
-                chase_touch2<G>(A, choice, tb, ver, flag, jj, i, geo, lane, cont, next, &T->next, was);
-            } else if (lane == 0) {
-                was = __hip_atomic_fetch_and(flag + i, ~2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // running -> idle, or -> queued
-            }
-            was = __shfl(was, 0, G);
-            if (was & 1) {  // somebody asked for this row while it ran
-                if (cont < 0) cont = i;
-                else if (lane == 0) next[atomicAdd(&T->next, 1)] = i;
-            }
-            i = cont;
-        }
-    }
-    if (c_left > 0) {  // claimed and not reached (the step budget ran out first): still queued, the next launch takes them
-        int base = 0;
-        if (lane == 0) base = atomicAdd(&T->next, c_left);
-        base = __shfl(base, 0, G);
-        for (int e = lane; e < c_left; e += G) next[base + e] = cur[c_idx + e];
-    }
-    // statistics (evaluations of this launch): one atomic per wavefront
-    int s = lane == 0 ? steps : 0, mv = lane == 0 ? moved : 0;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { s += __shfl_down(s, off, 64); mv += __shfl_down(mv, off, 64); }
-    if ((threadIdx.x & 63) == 0 && s) { atomicAdd(&T->changed, s); if (mv) atomicAdd(&T->moved, mv); }
-}
-
-// rows of the current list that no group claimed (every budget ran out first) move to the next list
-__global__ void chase_carry_k(TailCounters *T, const int *list_a, const int *list_b, int *out_a, int *out_b, int n_groups /* of the cascade launch before */) {
-    if (T->finished) return;
-    const int count = T->cur;
-    if (count == 0) return;
-    // what the launch's groups owned by index or claimed through the counter is theirs to hand on; the rest of the list was never looked at
-    const long long taken = (long long)n_groups * chase_claim(count, n_groups) + (long long)T->fetch;
-    const int from = (int)min((long long)count, taken);
-    const int *cur = T->parity ? list_b : list_a;
-    int *next = T->parity ? out_a : out_b;
-    for (int idx = from + blockIdx.x * blockDim.x + threadIdx.x; idx < count; idx += gridDim.x * blockDim.x) next[atomicAdd(&T->next, 1)] = cur[idx];
-}
-
-__global__ void chase_rotate_k(TailCounters *T, int *steps_total) {
-    if (blockIdx.x == 0 && threadIdx.x == 0 && !T->finished) {
-        *steps_total += T->changed;
-        T->cur = T->next;
-        T->next = 0;
-        T->changed = 0;
-        T->rounds += 1;
-        T->parity ^= 1;
-        T->fetch = 0;
-    }
 }
 
 __global__ void chooser_k(const int *__restrict__ choice, int *__restrict__ chooser, int64_t n) {
@@ -1023,39 +273,12 @@ __global__ void nan_to_status3_k(const double *__restrict__ value3, int *status3
     if (blockIdx.x == 0 && threadIdx.x < 3 && isnan(value3[threadIdx.x])) atomicCAS(status3 + threadIdx.x, 0, code);
 }
 
-// ------------------------------------------------------------------ Galerkin product (R A) R^T, one wavefront per coarse row
-// (R A)[I,:] is the sum of <= 4 fine rows, R^T spreads every fine column over <= 2 coarse columns;
-// coarse rows reach a few hundred candidate products on the deeper levels.  One wavefront builds
-// one coarse row in LDS:
-//   1. gather the candidates (j, R_Ii * a_ij) in the reference's order (i ascending, then row order),
-//   2. bitonic-sort by the composite key (j << 32 | sequence)  -> equal j stay in generation order,
-//   3. the first lane of every run adds it up sequentially       -> T = (R A)[I,:], sorted by j,
-//   4. expand T through R^T into (J, T_j * R^T_jJ) in j order, sort by (J << 32 | sequence), add runs.
-// Every sum therefore associates exactly like nalgebra-sparse's spmm_csr (c += a_ik * b_kj, k in
-// row order), which keeps the coarse operators bit-identical to the CPU oracle.  galerkin_bound_k sorts the
-// rows into LDS tiers (list capacity 128 << t) by their candidate bound, one launch per non-empty tier.
-// Output goes to a scratch area through an atomic bump allocator; a second kernel packs it into
-// SELL-64 once the slice widths are known (single pass: no symbolic/numeric duplication).
-// Only the keys move: their low 32 bits are the slot the entry was generated in, so the value of the entry at sorted
-// position e is val[(unsigned)key[e]] and the value array is never permuted.
-__device__ __forceinline__ void bitonic_sort_wave(unsigned long long *__restrict__ key, int P) {
-    // P: power of two >= 64; executed by one wavefront (blockDim.x == 64): __syncthreads is a wave barrier
-    const int lane = threadIdx.x;
-    for (int k = 2; k <= P; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            // one lane per comparator (P/2 of them): element e has bit log2(j) clear, its partner has it set
-            for (int c = lane; c < (P >> 1); c += 64) {
-                const int e = ((c & ~(j - 1)) << 1) | (c & (j - 1));
-                const int partner = e | j;
-                const bool up = (e & k) == 0;
-                const unsigned long long a = key[e], b = key[partner];
-                if ((a > b) == up) { key[e] = b; key[partner] = a; }
-            }
-            __syncthreads();
-        }
-    }
-}
-
+// ------------------------------------------------------------------ Galerkin product (R A) R^T
+// (R A)[I,:] is the sum of <= 4 fine rows, R^T spreads every fine column over <= 2 coarse columns; coarse rows reach a few hundred
+// candidate products on the deeper levels.  Every sum must associate exactly like nalgebra-sparse's spmm_csr (c += a_ik * b_kj, k in row
+// order) to keep the coarse operators bit-identical to the CPU oracle.  galerkin_bound_k sorts the rows into LDS tiers (list capacity
+// 64 << t) by their candidate bound, one launch of galerkin_merge_k per non-empty tier; output goes to row-contiguous scratch at offsets
+// from a scan of per-row bounds; galerkin_pack_fused_k then writes the SELL-64 image and the packed mirror.
 // exclusive prefix sum of one int per lane across the wavefront
 __device__ __forceinline__ int wave_excl_scan(int v, int &total) {
     const int lane = threadIdx.x & 63;
@@ -1069,149 +292,14 @@ __device__ __forceinline__ int wave_excl_scan(int v, int &total) {
     return x - v;
 }
 
-__global__ __launch_bounds__(64) void galerkin_wave_k(MatView A, const int *__restrict__ choice, const int *__restrict__ chooser, int64_t n_coarse,
-                                                      int cap /* power of two */, int *__restrict__ row_len_c, const long long *__restrict__ slice_base,
-                                                      const int *__restrict__ intra_off, int *__restrict__ s_col, double *__restrict__ s_val,
-                                                      int *__restrict__ overflow_flag,
-                                                      const int *__restrict__ list, const int *__restrict__ list_count,
-                                                      int *__restrict__ ovf_list, int *__restrict__ ovf_count) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    unsigned long long *key = reinterpret_cast<unsigned long long *>(smem);
-    double *val = reinterpret_cast<double *>(key + cap);
-    unsigned long long *key2 = reinterpret_cast<unsigned long long *>(val + cap);
-    double *val2 = reinterpret_cast<double *>(key2 + cap);
-    const int lane = threadIdx.x;
-    const int64_t total_rows = list ? (int64_t)*list_count : n_coarse;
-    for (int64_t it = blockIdx.x; it < total_rows; it += gridDim.x) {
-        const int64_t I = list ? (int64_t)list[it] : it;
-        const RRow R = restriction_row(choice, I, A.P.n);
-        // ---- 1. candidates of T = (R A)[I,:]
-        int cnt = 0;
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-            if (a < R.n) cnt += A.P.row_len[R.idx[a]];
-        bool fits = cnt <= cap;
-        int cntT = 0, cnt2 = 0, lenO = 0;
-        if (fits) {
-            int base = 0;
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                if (a >= R.n) continue;
-                const int i = R.idx[a];
-                const double w = R.w[a];
-                const int len = A.P.row_len[i];
-                const int64_t rb = A.P.slice_ptr[i >> 6] + (i & 63);
-                for (int k0 = 0; k0 < len; k0 += 64) {
-                    const int k = k0 + lane;
-                    int c = -1;
-                    int64_t pos = 0;
-                    if (k < len) { pos = rb + (int64_t)k * 64; c = A.P.col[pos]; }
-                    const int valid = (c >= 0 && c < A.P.n) ? 1 : 0;  // couplings to ghost columns are dropped on the coarse levels
-                    int tot;
-                    const int slot = base + wave_excl_scan(valid, tot);
-                    if (valid) {
-                        key[slot] = ((unsigned long long)(unsigned)c << 32) | (unsigned)slot;
-                        val[slot] = w * view_value(A, i, pos);
-                    }
-                    base += tot;
-                }
-            }
-            cnt = base;
-            int P = 64;
-            while (P < cnt) P <<= 1;
-            for (int e = cnt + lane; e < P; e += 64) key[e] = ~0ull;
-            __syncthreads();
-            bitonic_sort_wave(key, P);
-            // ---- 2. runs of equal j -> T (compact, sorted by j) into key2/val2
-            for (int b0 = 0; b0 < cnt; b0 += 64) {
-                const int e = b0 + lane;
-                int head = 0;
-                if (e < cnt) head = (e == 0) || ((key[e] >> 32) != (key[e - 1] >> 32));
-                int tot;
-                const int slot = cntT + wave_excl_scan(head, tot);
-                if (head) {
-                    const unsigned j = (unsigned)(key[e] >> 32);
-                    double acc = 0. + val[(unsigned)key[e]];
-                    for (int q = e + 1; q < cnt && (unsigned)(key[q] >> 32) == j; ++q) acc += val[(unsigned)key[q]];
-                    key2[slot] = j;
-                    val2[slot] = acc;
-                }
-                cntT += tot;
-            }
-            __syncthreads();
-            // ---- 3. expand through R^T: (J, T_j * w) in j order -> key/val
-            for (int b0 = 0; b0 < cntT; b0 += 64) {
-                const int e = b0 + lane;
-                int J[2];
-                double W[2];
-                int nj = 0;
-                double tv = 0.;
-                if (e < cntT) {
-                    nj = rt_row(choice, chooser, (int)key2[e], J, W);
-                    tv = val2[e];
-                }
-                int tot;
-                const int slot = cnt2 + wave_excl_scan(nj, tot);
-                if (cnt2 + tot <= cap) {
-                    for (int q = 0; q < nj; ++q) {
-                        key[slot + q] = ((unsigned long long)(unsigned)J[q] << 32) | (unsigned)(slot + q);
-                        val[slot + q] = tv * W[q];
-                    }
-                }
-                cnt2 += tot;
-            }
-            fits = cnt2 <= cap;
-        }
-        if (!fits) {
-            if (lane == 0) {
-                if (ovf_list) ovf_list[atomicAdd(ovf_count, 1)] = (int)I;
-                else atomicExch(overflow_flag, 1);
-            }
-            __syncthreads();
-            continue;
-        }
-        {
-            int P = 64;
-            while (P < cnt2) P <<= 1;
-            for (int e = cnt2 + lane; e < P; e += 64) key[e] = ~0ull;
-            __syncthreads();
-            bitonic_sort_wave(key, P);
-            // ---- 4. runs of equal J -> the coarse row (compact, sorted) into key2/val2
-            for (int b0 = 0; b0 < cnt2; b0 += 64) {
-                const int e = b0 + lane;
-                int head = 0;
-                if (e < cnt2) head = (e == 0) || ((key[e] >> 32) != (key[e - 1] >> 32));
-                int tot;
-                const int slot = lenO + wave_excl_scan(head, tot);
-                if (head) {
-                    const unsigned Jc = (unsigned)(key[e] >> 32);
-                    double acc = 0. + val[(unsigned)key[e]];
-                    for (int q = e + 1; q < cnt2 && (unsigned)(key[q] >> 32) == Jc; ++q) acc += val[(unsigned)key[q]];
-                    key2[slot] = Jc;
-                    val2[slot] = acc;
-                }
-                lenO += tot;
-            }
-            __syncthreads();
-        }
-        // ---- output (scratch offset = exclusive scan of the per-row bound: deterministic, no atomics)
-        const long long off = slice_base[I >> 6] + intra_off[I];
-        for (int e = lane; e < lenO; e += 64) { s_col[off + e] = (int)key2[e]; s_val[off + e] = val2[e]; }
-        if (lane == 0) row_len_c[I] = lenO;
-        __syncthreads();
-    }
-}
-
-// ---- the same product without sorting --------------------------------------------------------------------------------
 // The candidates of T = (R A)[I,:] are <= 4 fine rows whose columns ascend, so T is a MERGE: every candidate finds its
 // place by binary searches in the other lists (equal columns keep the order of the fine rows, i ascending, which is the
 // reference's order of accumulation).  And (T R^T)[I,J] = sum_j T_j R_Jj is a sum over the <= 4 fine indices of row J
 // of R (restriction_row(J), ascending j — again the reference's order): once the distinct J are known each output lane
 // looks its <= 4 terms up in T.  The distinct J need no sort either: a fine column j reaches J = j >> 1 (when j has a
 // partner) and J' = chooser[j] >> 1 (when it was chosen), and whether an earlier T entry reaches the same coarse column is
-// decided by O(1) look-ups (the sibling 2J+1 / the sibling's partner).  The survivors are ranked by counting.  Compared
-// with two bitonic sorts per coarse row (dozens of LDS passes with a barrier each) this is a handful of passes, and the
-// lists need half the LDS.  Bit-identical output (same products, same order of every sum).
+// decided by O(1) look-ups (the sibling 2J+1 / the sibling's partner).  The survivors are ranked by counting.  (Round 1 sorted
+// every coarse row twice with a bitonic network: dozens of LDS passes with a barrier each, twice the LDS; same bits.)
 __device__ __forceinline__ int lds_lower_bound(const int *p, int len, int key) {
     int lo = 0, hi = len;
     while (lo < hi) {
@@ -1246,14 +334,13 @@ __device__ __forceinline__ int group_excl_scan(int v, int &total) {
 // G lanes per coarse row (64 / G rows per wavefront): the passes of a narrow row (<= 32 candidates on the first coarse
 // level) fill half a wavefront.
 // [r03] Step 1 used to walk the <= 4 fine rows one after the other — descriptor -> columns -> values, twelve dependent global
-// round trips per coarse row, 43 % of the kernel on the widest tier (ORC_GALERKIN_STAGES=1 launches the kernel cut short
-// after step 1 and after step 4: 3.6 of 8.4 ms).  Now the descriptors of all fine rows are requested together, then their
+// round trips per coarse row, 43 % of the kernel on the widest tier (a kernel cut short
+// after step 1 and after step 4 measured it: 3.6 of 8.4 ms).  Now the descriptors of all fine rows are requested together, then their
 // first G entries together, from the row-contiguous mirror where the matrix has one, and the next coarse row's index and
 // pairing travel while the current row is merged: step 1 3.6 -> 1.5 ms, the kernel 8.4 -> 7.7 ms (the later steps slow down
 // as the first one stops pacing them: the kernel as a whole moves ~800 scattered cache-line requests per coarse row).
 // Batching the pairing look-ups of step 4 (speculative second-level loads) and running the LDS searches of a step side by
 // side were measured too: +1.2 ms and +2.1 ms.  Same LDS passes, same order of every sum and output entry: bit-identical.
-// kStop (measurement only): 1 / 4 = leave a row after that step (nothing but a row length is written; the real launch follows)
 // [r04] S systems on ONE fine pattern and ONE pairing (the u, v, w momentum matrices whenever v's and w's fine-level pairings verify as u's:
 // SiblingPairing) share everything symbolic — which candidates there are, where each one merges to, which coarse columns come out and in
 // which order — so one pass carries S value sets through the same LDS passes (MergeSiblings: the values, scalings and outputs of systems
@@ -1265,7 +352,7 @@ struct MergeSiblings {
     double *s_val[2] = {nullptr, nullptr};        // scratch rows, same offsets as system 0's
 };
 
-template <int G, int kStop = 0, int S = 1>
+template <int G, int S = 1>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S == 1 ? 6 : 4))) void galerkin_merge_k(MatView A, const int *__restrict__ choice, const int *__restrict__ chooser, int64_t n_coarse,
                                                         int cap /* power of two >= 2 * candidates */, int *__restrict__ row_len_c,
                                                         const long long *__restrict__ slice_base, const int *__restrict__ intra_off, int *__restrict__ s_col,
@@ -1389,7 +476,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S == 1 ? 6 :
         }
         const int cnt = b4;
         __syncthreads();
-        if (kStop == 1) { if (active && lane == 0) row_len_c[I] = cnt; __syncthreads(); active = active_n; I = I_n; pair0 = (active_n && 2 * I_n < n_fine) ? choice[2 * I_n] : -1; pair1 = (active_n && 2 * I_n + 1 < n_fine) ? choice[2 * I_n + 1] : -1; continue; }
         // ---- 2. merge: rank = own position + entries of earlier lists with column <= c + entries of later lists with column < c
         for (int e = lane; e < cnt; e += G) {
             const int a = (e >= b1) + (e >= b2) + (e >= b3);
@@ -1482,7 +568,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S == 1 ? 6 :
             nU += tot;
         }
         __syncthreads();
-        if (kStop == 4) { if (active && lane == 0) row_len_c[I] = nU > 0 ? U[nU - 1] : 0; __syncthreads(); active = active_n; I = I_n; pair0 = pair0_n; pair1 = pair1_n; continue; }
         // ---- 5. every distinct J: position by counting, value from the <= 4 fine indices of row J of R (ascending)
         const long long off = active ? slice_base[I >> 6] + intra_off[I] : 0;
         for (int e = lane; e < nU; e += G) {
@@ -1940,104 +1025,6 @@ __global__ __launch_bounds__(64) void narrow_build_k(SellDev P, unsigned short *
     }
 }
 
-// ---- length-sorted image of the packed mirror (XSortDev, linalg.hpp): one workgroup per block of 256 rows.
-// sorted rank of a row = rows of the block that are longer + equally long rows before it; rank r -> wave r & 3, lane r >> 2.
-// R(q) = rows longer than q, so wave w owns cnt_w(q) = ceil((R(q) - w) / 4) entries at depth q, a prefix of its lanes.
-__global__ __launch_bounds__(kBlock) void xsort_build_k(SellDev P, PackedDev pk, const unsigned short *__restrict__ lidx_packed, int *__restrict__ perm,
-                                                        int *__restrict__ slen, int64_t *__restrict__ sptr, double *__restrict__ sval,
-                                                        unsigned short *__restrict__ slidx, unsigned char *__restrict__ ok, int64_t n_blocks) {
-    __shared__ int lens[kBlock];
-    __shared__ int longer[kXSortMaxLen + 1];   // hist, then R(q) = rows with length > q
-    __shared__ int offp[4][kXSortMaxLen + 1];  // exclusive prefix over the depths of cnt_w
-    __shared__ long long sb[4];
-    __shared__ int s_bad;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int64_t b = blockIdx.x; b < n_blocks; b += gridDim.x) {
-        const int64_t row = b * kXWinRows + tid;
-        const bool live = row < P.n;
-        const int len = live ? P.row_len[row] : 0;
-        lens[tid] = len;
-        for (int q = tid; q <= kXSortMaxLen; q += kBlock) longer[q] = 0;
-        if (tid == 0) s_bad = 0;
-        __syncthreads();
-        if (len > kXSortMaxLen) s_bad = 1;
-        else atomicAdd(&longer[len], 1);
-        __syncthreads();
-        if (s_bad) {  // a row too long for the tables: this block keeps the packed order
-            if (tid == 0) ok[b] = 0;
-            perm[b * kXWinRows + tid] = live ? (int)row : -1;
-            slen[b * kXWinRows + tid] = len;
-            if (tid < 4) sptr[b * 4 + tid] = (b * 4 + tid < P.n_slices) ? pk.ptr[b * 4 + tid] : 0;
-            __syncthreads();
-            continue;
-        }
-        // R(q) = sum_{l > q} hist[l]: suffix sums, two depths per thread (hist is read-only in this step)
-        int rq[3];
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            const int q = tid + t * kBlock;
-            int acc = 0;
-            if (q <= kXSortMaxLen)
-                for (int l = q + 1; l <= kXSortMaxLen; ++l) acc += longer[l];
-            rq[t] = acc;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-            if (tid + t * kBlock <= kXSortMaxLen) longer[tid + t * kBlock] = rq[t];
-        __syncthreads();
-        int rank = longer[len];
-        for (int u = 0; u < tid; ++u) rank += lens[u] == len;
-        const int sw = rank & 3, sl = rank >> 2;
-        perm[b * kXWinRows + sw * 64 + sl] = live ? (int)row : -1;
-        slen[b * kXWinRows + sw * 64 + sl] = len;
-        // offp[w][q] = sum_{q' < q} cnt_w(q'), cnt_w(q) = max(0, ceil((R(q) - w) / 4)): wave w scans its own row of the table
-        {
-            int carry = 0;
-            for (int q0 = 0; q0 <= kXSortMaxLen; q0 += 64) {
-                const int q = q0 + lane;
-                const int r_ = q <= kXSortMaxLen ? longer[q] : 0;
-                const int c = r_ > wave ? (r_ - wave + 3) >> 2 : 0;
-                int x = c;
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const int y = __shfl_up(x, off, 64);
-                    if (lane >= off) x += y;
-                }
-                if (q <= kXSortMaxLen) offp[wave][q] = carry + x - c;
-                carry += __shfl(x, 63, 64);
-            }
-            if (lane == 0) sb[wave] = carry;  // this wave's share of the block's entries
-        }
-        __syncthreads();
-        if (tid == 0) {
-            long long base = (long long)pk.ptr[b * 4];
-            for (int w = 0; w < 4; ++w) { const long long t = sb[w]; sb[w] = base; sptr[b * 4 + w] = base; base += t; }
-            ok[b] = 1;
-        }
-        __syncthreads();
-        // copy: the wave walks its slice in packed order (lane = row), every lane writes to its row's sorted place
-        const int64_t slice = b * 4 + wave;
-        if (slice < P.n_slices) {
-            const int64_t sbase = P.slice_ptr[slice];
-            const int width = (int)((P.slice_ptr[slice + 1] - sbase) >> 6);
-            int64_t off = pk.ptr[slice];
-            for (int q = 0; q < width; ++q) {
-                const bool in = q < len;
-                const unsigned long long m = __ballot(in);
-                const int rk = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                if (in) {
-                    const long long dst = sb[sw] + offp[sw][q] + sl;
-                    sval[dst] = pk.val[off + rk];
-                    slidx[dst] = lidx_packed[off + rk];
-                }
-                off += __popcll(m);
-            }
-        }
-        __syncthreads();
-    }
-}
-
 __global__ void nan_to_status_k(const double *__restrict__ value, int *status, int code) {
     if (threadIdx.x == 0 && blockIdx.x == 0 && isnan(value[0])) atomicCAS(status, 0, code);
 }
@@ -2048,7 +1035,6 @@ struct CoarseLevel {
     double *val = nullptr;
     PackedDev pk;
     XWinDev xw;
-    XSortDev xs;
     RowsDev rows;
     bool rows_transient = false;  // `rows` lives in the set-up's companion arena: valid until the next level has been built
     int64_t n = 0, padded = 0;
@@ -2467,13 +1453,8 @@ int SiblingPairing::answer(const bool adopted[2], const int *choice, const int *
     return st;
 }
 
-// warm: a starting state for the fixed-point iteration (any state is valid).  warm_kind 1: last iteration's pairing of the
-// same equation (ORC_AMG_WARM, off); 2: a sibling system's pairing of THIS iteration, taken if it IS this matrix's fixed
-// point (agg_verify_k: one pass, nothing to iterate) and dropped otherwise — measured: a sibling's pairing that is off in
-// a few per cent of the rows is a worse start than the slice sweep's state (the cascades from it multiply instead of
-// running out: 60 M evaluations against 4 M), so there is no middle way.
-// orc_debug_amg_certification: aggregations whose cascades were followed by the certifying lock-step rounds, and how many rounds
-// those took in total (equal = every certification found nothing to change: the cascades had reached the fixed point)
+// orc_debug_amg_certification: aggregations whose pairing was certified, and how many certifying passes / sweeps that took in total (equal =
+// every certification found nothing to change: the deferred-acceptance chains had reached the fixed point by themselves)
 static std::atomic<long long> g_cert_aggregations{0}, g_cert_rounds{0};
 void debug_amg_certification(long long out[2], bool reset) {
     out[0] = g_cert_aggregations.load(std::memory_order_relaxed);
@@ -2492,21 +1473,35 @@ int debug_xwin_counters(long long out[3], bool reset) {
     return ORC_OK;
 }
 
-static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, int *rounds_out, const int *warm = nullptr, int warm_kind = 1) {
+// build_restriction_matrix's pairing (linear_algebra.rs:30-60) for the matrix behind `A`: choice[i] = the column row i takes (-1: none),
+// chooser[j] = the row that took column j (-1: nobody).
+//   warm (optional): a sibling system's pairing of THIS iteration — taken if it IS this matrix's fixed point (agg_verify_k: one pass, nothing
+//     to iterate), dropped otherwise (r02 measured: a pairing that is off in a few per cent of the rows is a worse start than none).
+//   1. deferred acceptance (da_first_k, da_chase_k): the pairing, read off the holder table, certified by ONE verification pass and ONE host read;
+//   2. only if that pass finds a row that would choose differently, or a chain was cut by the step budget (ORC_AMG_DA_STEPS: a test hook) —
+//      never seen otherwise —, or with ORC_AMG_DA=0: slice-sequential sweeps against the rebuilt first-taker table until a sweep changes
+//      nothing.  Slow (one sweep per slice a chain crosses) and as simple as the reference's loop: a fallback, not a path to tune.  r02-r04's
+//      lock-step rounds and asynchronous cascades (HISTORY.md) are gone with the round that made them unnecessary.
+static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, int *rounds_out, const int *warm = nullptr) {
     const int64_t n = A.P.n;
     const int g = grid_for(n);
     const int gs = grid_for(A.P.n_slices, 64);  // one thread per slice, 64-thread workgroups spread the slices over the CUs
     int *taken_by, *snap;
-    unsigned char *act_a, *act_b;
     AggCounters *C;
     ORC_TRY(arena.alloc((size_t)std::max<int64_t>(n, 1), &taken_by));
-    ORC_TRY(arena.alloc((size_t)A.P.n_slices + 1, &act_a));
-    ORC_TRY(arena.alloc((size_t)A.P.n_slices + 1, &act_b));
     ORC_TRY(arena.alloc((size_t)1, &C));
     ORC_TRY(arena.alloc((size_t)64, &snap));
     hipStream_t st = ctx().stream;
+    const bool trace = cfg().amg_trace;
     ORC_HIP(hipMemsetAsync(C, 0, sizeof(AggCounters), st));
-    if (warm && warm_kind == 2 && n > 0) {  // a sibling's pairing: this matrix's too?
+    if (n == 0) { if (rounds_out) *rounds_out = 0; return ORC_OK; }
+    auto finish_from_choice = [&]() -> int {
+        ORC_HIP(hipMemsetAsync(chooser, 0xff, sizeof(int) * (size_t)n, st));
+        hipLaunchKernelGGL(chooser_k, dim3(g), dim3(kBlock), 0, st, (const int *)choice, chooser, n);
+        ORC_HIP(hipGetLastError());
+        return ORC_OK;
+    };
+    if (warm) {  // a sibling's pairing: this matrix's too?
         AggCounters hc;
         ORC_HIP(hipMemcpyAsync(choice, warm, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, st));
         hipLaunchKernelGGL(agg_reset_k, dim3(g), dim3(kBlock), 0, st, taken_by, n);
@@ -2515,41 +1510,31 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
         ORC_HIP(hipGetLastError());
         ORC_HIP(hipMemcpyAsync(&hc, C, sizeof(hc), hipMemcpyDeviceToHost, st));
         ORC_HIP(hipStreamSynchronize(st));
-        static const bool trace_v = getenv("ORC_AMG_TRACE") != nullptr;
-        if (trace_v) fprintf(stderr, "[amg sibling n=%lld] rows that would change: %d\n", (long long)n, hc.changed);
+        if (trace) fprintf(stderr, "[amg sibling n=%lld] rows that would change: %d\n", (long long)n, hc.changed);
         if (hc.changed == 0) {
-            ORC_HIP(hipMemsetAsync(chooser, 0xff, sizeof(int) * (size_t)n, st));
-            hipLaunchKernelGGL(chooser_k, dim3(g), dim3(kBlock), 0, st, (const int *)choice, chooser, n);
-            ORC_HIP(hipGetLastError());
             if (rounds_out) *rounds_out = 1;
-            return ORC_OK;
+            return finish_from_choice();
         }
-        ORC_HIP(hipMemsetAsync(C, 0, sizeof(AggCounters), st));
-        warm = nullptr;  // not this matrix's pairing: from scratch
+        ORC_HIP(hipMemsetAsync(C, 0, sizeof(AggCounters), st));  // not this matrix's pairing: from scratch
     }
-    static const bool trace_t = getenv("ORC_AMG_TRACE") != nullptr;
-    // [r05] the pairing by deferred acceptance (above): a coalesced first pass, the chains, the pairing read off the holder table, ONE
-    // verification pass and ONE host read.  ORC_AMG_DA=0 (read per call: the tests compare the forms): r04's sweeps + lock-step rounds + cascades.
-    const bool da_on = !(getenv("ORC_AMG_DA") && atoi(getenv("ORC_AMG_DA")) == 0) && !warm && n > 0;
-    if (da_on) {
+    if (cfg().amg_da) {
         ArenaScope da_scope(arena);  // the list is dead when the pairing is known
         DaCounters *D;
         int2 *list;
-        ORC_TRY(arena.alloc((size_t)1, &D));
         int *da_prefs;
+        ORC_TRY(arena.alloc((size_t)1, &D));
         ORC_TRY(arena.alloc((size_t)n, &list));
         ORC_TRY(arena.alloc((size_t)n * kPrefs, &da_prefs));
         ORC_HIP(hipMemsetAsync(D, 0, sizeof(DaCounters), st));
         hipLaunchKernelGGL(agg_reset_k, dim3(g), dim3(kBlock), 0, st, taken_by, n);  // holder = taken_by: nobody
-        const int da_steps = getenv("ORC_AMG_DA_STEPS") ? std::max(1, atoi(getenv("ORC_AMG_DA_STEPS"))) : (1 << 22);  // (a test cuts the chains short: the fallback must finish the job)
         hipLaunchKernelGGL(da_first_k, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, A, taken_by, list, D, da_prefs);
         // lanes per chain: the list needs four; a scan reads the row G entries at a time (kDaRegs slots per lane in registers).  Measured per level
         // of the channel (one hierarchy, us): 7 entries per row: 4 / 8 / 16 lanes 1 620 / 1 454 / 1 475; 15: 4 767 / 6 303 / 8 274; 33: 9 048 / 8 047 / 8 596
         const double da_avg = (double)A.P.padded / (double)n;
-        const int da_group = getenv("ORC_AMG_DA_GROUP") ? atoi(getenv("ORC_AMG_DA_GROUP")) : (da_avg <= 24. ? 4 : 8);
+        const int da_group = cfg().amg_da_group > 0 ? cfg().amg_da_group : (da_avg <= 24. ? 4 : 8);
+        const int da_steps = cfg().amg_da_steps;
         if (da_group == 4) hipLaunchKernelGGL(da_chase_k<4>, dim3(kMaxGrid), dim3(kBlock), 0, st, A, taken_by, (const int2 *)list, D, da_steps, (const int *)da_prefs);
         else if (da_group == 8) hipLaunchKernelGGL(da_chase_k<8>, dim3(kMaxGrid), dim3(kBlock), 0, st, A, taken_by, (const int2 *)list, D, da_steps, (const int *)da_prefs);
-        else if (da_group == 32) hipLaunchKernelGGL(da_chase_k<32>, dim3(kMaxGrid), dim3(kBlock), 0, st, A, taken_by, (const int2 *)list, D, da_steps, (const int *)da_prefs);
         else hipLaunchKernelGGL(da_chase_k<16>, dim3(kMaxGrid), dim3(kBlock), 0, st, A, taken_by, (const int2 *)list, D, da_steps, (const int *)da_prefs);
         ORC_HIP(hipMemsetAsync(choice, 0xff, sizeof(int) * (size_t)n, st));
         hipLaunchKernelGGL(da_finish_k, dim3(g), dim3(kBlock), 0, st, (const int *)taken_by, choice, chooser, n);
@@ -2561,284 +1546,42 @@ static int aggregate(const MatView &A, Arena &arena, int *choice, int *chooser, 
         ORC_HIP(hipMemcpyAsync(&hc, C, sizeof(hc), hipMemcpyDeviceToHost, st));
         ORC_HIP(hipMemcpyAsync(&hd, D, sizeof(hd), hipMemcpyDeviceToHost, st));
         ORC_HIP(hipStreamSynchronize(st));
-        if (trace_t) fprintf(stderr, "[amg da n=%lld] rows left to the chains %d, their proposals %d (%d by a scan of the row), longest chain %d, chains cut %d, rows that would change %d\n", (long long)n, hd.list, hd.steps, hd.scans, hd.longest, hd.overflow, hc.changed);
+        if (trace) fprintf(stderr, "[amg da n=%lld] rows left to the chains %d, their proposals %d (%d by a scan of the row), longest chain %d, chains cut %d, rows that would change %d\n",
+                           (long long)n, hd.list, hd.steps, hd.scans, hd.longest, hd.overflow, hc.changed);
         if (hd.overflow == 0 && hc.changed == 0) {
             g_cert_aggregations.fetch_add(1, std::memory_order_relaxed);  // certified by one pass that changed nothing
             g_cert_rounds.fetch_add(1, std::memory_order_relaxed);
             if (rounds_out) *rounds_out = 1;
             return ORC_OK;
         }
-        ORC_HIP(hipMemsetAsync(C, 0, sizeof(AggCounters), st));  // not the fixed point (a cut chain; never seen otherwise): r04's machinery, from scratch
+        ORC_HIP(hipMemsetAsync(C, 0, sizeof(AggCounters), st));
     }
-    // preference lists for the sweep's, the lock-step rounds' and the cascades' evaluations.  ORC_AMG_PREFS=0: every evaluation scans its row (r03);
-    // ORC_AMG_PREFS_MIN_LEN: stored entries per row from which on (5: every level of the channel — with the mesh pattern's 7 entries per row a list
-    // saves no look-up, only the row's own lines, and still pays: 767.0 / 768.5 / 757.5 -> 758.9 / 761.5 / 759.1 ms against lists from 12 on).  Per call.
-    int *prefs = nullptr;
-    const int prefs_min_len = getenv("ORC_AMG_PREFS_MIN_LEN") ? atoi(getenv("ORC_AMG_PREFS_MIN_LEN")) : 5;
-    if (!(getenv("ORC_AMG_PREFS") && atoi(getenv("ORC_AMG_PREFS")) == 0) && n > 0 && A.P.padded >= (int64_t)prefs_min_len * n) {
-        ORC_TRY(arena.alloc((size_t)n * kPrefs, &prefs));
-        hipLaunchKernelGGL(agg_init_prefs_k, dim3(g), dim3(kBlock), 0, st, A, choice, act_a, act_b, prefs);
-    } else
-    hipLaunchKernelGGL(agg_init_k, dim3(g), dim3(kBlock), 0, st, A, choice, act_a, act_b);  // also resets the slice flags
-    if (warm) ORC_HIP(hipMemcpyAsync(choice, warm, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, st));
+    // ---- the fallback: sweeps from the unconstrained arg-min state, four per host read
+    hipLaunchKernelGGL(agg_init_k, dim3(g), dim3(kBlock), 0, st, A, choice);
+    constexpr int kBulk = 4;
     int rounds = 0;
-    double t_mark = 0.;
-    auto lap = [&](const char *what) {  // trace only: wall time of the phase that just ended (drains the stream)
-        if (!trace_t) return;
-        (void)hipStreamSynchronize(st);
-        const double now = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
-        if (what) fprintf(stderr, "[amg phase n=%lld] %s %.3f ms\n", (long long)n, what, now - t_mark);
-        t_mark = now;
-    };
-    lap(nullptr);
-    const bool sym = A.symmetric;
-    const int all_active = sym ? 0 : 1;  // activation needs "rows holding column j" = columns of row j
-    unsigned char *cur = act_a, *nxt = act_b;
-    // ---- bulk phase: slice-sequential sweeps (all of the work on structurally asymmetric patterns)
-    static const int bulk_sym = getenv("ORC_AMG_BULK") ? atoi(getenv("ORC_AMG_BULK")) : 1;
-    const int kBulk = sym ? bulk_sym : 4;
-    static const int warm_mode = getenv("ORC_AMG_WARM") ? atoi(getenv("ORC_AMG_WARM")) : 0;
-    bool done = sym && warm != nullptr && warm_mode == 1;  // mode 1: straight to the certifying row-level rounds; 2: sweeps first
-    while (!done) {
+    for (bool done = false; !done;) {
         for (int b = 0; b < kBulk; ++b) {
             hipLaunchKernelGGL(agg_reset_k, dim3(g), dim3(kBlock), 0, st, taken_by, n);
             hipLaunchKernelGGL(agg_scatter_k, dim3(g), dim3(kBlock), 0, st, choice, taken_by, n);
-            // lanes per slice by row length (host-known padded size / rows); 0 = one thread per slice (round 2, ORC_AMG_SWEEP_GROUP=0)
-            const int group_env = getenv("ORC_AMG_SWEEP_GROUP") ? atoi(getenv("ORC_AMG_SWEEP_GROUP")) : -1;  // (per call: the forms test switches it)
-            const double avg = (A.P.padded > 0 && n > 0) ? (double)A.P.padded / (double)n : 0.;
-            // (8 / 16 / 32 lanes by row length was the first choice: 103 ms over the sweeps of six iterations on one stream; 8 on every
-            // level: 90 ms; 4: 101 ms; 16: 98 ms — more slices in flight beat fewer passes per row)
-            const int G = group_env >= 0 ? group_env : (avg <= 0. ? 0 : 8);
-            // adjacent slices per group: ORC_AMG_SWEEP_BLOCK (0 = strided); the launch shrinks to the groups that have a piece
-            const int gg = grid_for((int64_t)A.P.n_slices * std::max(G, 1));
-            if (G == 4) hipLaunchKernelGGL(agg_sweep_group_k<4>, dim3(gg), dim3(kBlock), 0, st, A, choice, taken_by, cur, nxt, C, all_active, (const int *)prefs);
-            else if (G == 8) hipLaunchKernelGGL(agg_sweep_group_k<8>, dim3(gg), dim3(kBlock), 0, st, A, choice, taken_by, cur, nxt, C, all_active, (const int *)prefs);
-            else if (G == 16) hipLaunchKernelGGL(agg_sweep_group_k<16>, dim3(gg), dim3(kBlock), 0, st, A, choice, taken_by, cur, nxt, C, all_active, (const int *)prefs);
-            else if (G == 32) hipLaunchKernelGGL(agg_sweep_group_k<32>, dim3(gg), dim3(kBlock), 0, st, A, choice, taken_by, cur, nxt, C, all_active, (const int *)prefs);
-            else hipLaunchKernelGGL(agg_sweep_k, dim3(gs), dim3(64), 0, st, A, choice, taken_by, cur, nxt, C, all_active);
+            hipLaunchKernelGGL(agg_sweep_k, dim3(gs), dim3(64), 0, st, A, choice, taken_by, C);
             hipLaunchKernelGGL(agg_rotate_k, dim3(1), dim3(1), 0, st, C, snap + b);
-            ORC_HIP(hipMemsetAsync(cur, 0, (size_t)A.P.n_slices, st));
-            std::swap(cur, nxt);
         }
         ORC_HIP(hipGetLastError());
-        if (sym) { rounds += kBulk; break; }  // hand over to the tail phase without a round trip
-        int h[8];
+        int h[kBulk];
         ORC_HIP(hipMemcpyAsync(h, snap, sizeof(int) * kBulk, hipMemcpyDeviceToHost, st));
         ORC_HIP(hipStreamSynchronize(st));
         for (int b = 0; b < kBulk; ++b) {
             ++rounds;
-            if (h[b] == 0) { done = true; break; }
+            if (h[b] == 0) { done = true; break; }  // a sweep that changed nothing has evaluated every row against the exact table
         }
         if (rounds > 8 * 1000 * 1000) return set_error(ORC_ERR_BAD_ARGUMENT, "aggregation did not reach its fixed point");
     }
-    lap("bulk sweeps");
-    int *dbg_after_sweep = nullptr, *dbg_after_round = nullptr, *dbg_count = nullptr;  // trace only: how far from the fixed point the phases leave the state
-    if (trace_t && n > 0) {
-        ORC_TRY(arena.alloc((size_t)n, &dbg_after_sweep));
-        ORC_TRY(arena.alloc((size_t)n, &dbg_after_round));
-        ORC_TRY(arena.alloc((size_t)2, &dbg_count));
-        ORC_HIP(hipMemcpyAsync(dbg_after_sweep, choice, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, st));
-        ORC_HIP(hipMemcpyAsync(dbg_after_round, choice, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, st));
-    }
-    if (sym) {
-        // ---- tail phase: exact taken_by once, then row-level rounds
-        int *flag, *listA, *listB, *ch_row, *ch_new, *ch_old, *ch_t_old, *ch_t_new;
-        TailCounters *T;
-        ORC_TRY(arena.alloc((size_t)n, &flag));
-        ORC_TRY(arena.alloc((size_t)n, &listA));
-        ORC_TRY(arena.alloc((size_t)n, &listB));
-        ORC_TRY(arena.alloc((size_t)n, &ch_row));
-        ORC_TRY(arena.alloc((size_t)n, &ch_new));
-        ORC_TRY(arena.alloc((size_t)n, &ch_old));
-        ORC_TRY(arena.alloc((size_t)n, &ch_t_old));
-        ORC_TRY(arena.alloc((size_t)n, &ch_t_new));
-        ORC_TRY(arena.alloc((size_t)1, &T));
-        hipLaunchKernelGGL(agg_reset_k, dim3(g), dim3(kBlock), 0, st, taken_by, n);
-        hipLaunchKernelGGL(agg_scatter_k, dim3(g), dim3(kBlock), 0, st, choice, taken_by, n);
-        ORC_HIP(hipMemsetAsync(flag, 0, sizeof(int) * (size_t)n, st));
-        hipLaunchKernelGGL(tail_seed_k, dim3(1), dim3(1), 0, st, T, (int)n);
-        // The first rounds see every row / long lists: four kernels per round on the whole chip.  As soon as the list is
-        // short the rounds continue inside one workgroup (tail_small_k) until the fixed point or until the list grows again.
-        static const int small_enabled = getenv("ORC_AMG_TAIL_SMALL") ? atoi(getenv("ORC_AMG_TAIL_SMALL")) : 0;  // measured: exact, fewer launches, but +2-3 % wall at 10.24 M cells
-        static const int small_max = getenv("ORC_AMG_TAIL_SMALL_MAX") ? atoi(getenv("ORC_AMG_TAIL_SMALL_MAX")) : 512;
-        static const int small_threads = getenv("ORC_AMG_TAIL_SMALL_THREADS") ? atoi(getenv("ORC_AMG_TAIL_SMALL_THREADS")) : 256;
-        static const int big_batch = getenv("ORC_AMG_TAIL_BATCH") ? atoi(getenv("ORC_AMG_TAIL_BATCH")) : 2;
-        const int kBatch = small_enabled ? big_batch : 16;  // four-kernel rounds per host round trip; a round past the fixed point is a no-op
-        bool first = true, fin = false;
-        TailCounters h;
-        const int eval_group_env = getenv("ORC_AMG_EVAL_GROUP") ? atoi(getenv("ORC_AMG_EVAL_GROUP")) : 0;  // (per call: the forms test switches it)
-        const double eval_avg = (A.P.padded > 0 && n > 0) ? (double)A.P.padded / (double)n : 0.;
-        (void)eval_avg;
-        const int eval_group = eval_group_env ? eval_group_env : 4;  // one stream, all levels of six iterations: 16 lanes 95 ms, 8: 67 ms, 4: 58 ms
-        auto launch_eval = [&](int ge) {
-            if (eval_group == 4) hipLaunchKernelGGL(tail_eval_k<4>, dim3(ge), dim3(kBlock), 0, st, A, choice, taken_by, (const int *)listA, (const int *)listB, T, flag, ch_row, ch_new, (const int *)prefs);
-            else if (eval_group == 8) hipLaunchKernelGGL(tail_eval_k<8>, dim3(ge), dim3(kBlock), 0, st, A, choice, taken_by, (const int *)listA, (const int *)listB, T, flag, ch_row, ch_new, (const int *)prefs);
-            else if (eval_group == 32) hipLaunchKernelGGL(tail_eval_k<32>, dim3(ge), dim3(kBlock), 0, st, A, choice, taken_by, (const int *)listA, (const int *)listB, T, flag, ch_row, ch_new, (const int *)prefs);
-            else hipLaunchKernelGGL(tail_eval_k<16>, dim3(ge), dim3(kBlock), 0, st, A, choice, taken_by, (const int *)listA, (const int *)listB, T, flag, ch_row, ch_new, (const int *)prefs);
-        };
-        // (read per call, not cached: the tests run one process through the lock-step-only form, a starved cascade phase
-        // that hands over to the lock-step rounds unfinished, and the default)
-        const int chase_enabled = getenv("ORC_AMG_CHASE") ? atoi(getenv("ORC_AMG_CHASE")) : 1;
-        // steps per wavefront and launch: a wavefront that is through with them hands its rows to the next launch, which
-        // spreads them over the whole chip again (unbounded: a few wavefronts with long cascades work alone — 477 ms of
-        // cascades per 3.25 iterations against 321 ms at 96; 16: 525 ms, launches dominate)
-        const int chase_steps = getenv("ORC_AMG_CHASE_STEPS") ? atoi(getenv("ORC_AMG_CHASE_STEPS")) : 96;
-        // [r04] a launch no larger than what is RESIDENT on an empty chip: a workgroup that waits for a slot owns a first share of the list (above)
-        // whose rows then wait with it.  At 68 VGPRs (seven wavefronts per SIMD) that was 1 792 workgroups of the 2 048 r03 launched — one box,
-        // interleaved: 2 048 workgroups 788.8 / 780.4 ms per SIMPLE iteration, 1 792: 783.2 / 776.2, 1 024: 787.7 / 780.4 —; the kernel is now held
-        // at 64 VGPRs (amdgpu_waves_per_eu(8): 16 bytes of scratch per lane), eight per SIMD, all 2 048 resident: 777.5 / 778.0 -> 776.3 / 771.7
-        static const int chase_resident = [] {
-            int per_cu = 0, dev = 0, cus = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, tail_chase_k<16>, kBlock, 0) != hipSuccess || per_cu <= 0) return 2048;
-            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 2048;
-            return std::min(2048, per_cu * cus);
-        }();
-        const int chase_grid = clamp_partials_grid(getenv("ORC_AMG_CHASE_GRID") ? atoi(getenv("ORC_AMG_CHASE_GRID")) : chase_resident);
-        const int chase_launches = getenv("ORC_AMG_CHASE_LAUNCHES") ? atoi(getenv("ORC_AMG_CHASE_LAUNCHES")) : 1024;
-        const int chase_batch = getenv("ORC_AMG_CHASE_BATCH") ? std::max(1, atoi(getenv("ORC_AMG_CHASE_BATCH"))) : 2;  // launches per host read
-        static const bool trace = getenv("ORC_AMG_TRACE") != nullptr;
-        if (chase_enabled) {
-            // one lock-step round over every row, the cascades it leaves followed asynchronously, then the lock-step rounds
-            // again from scratch: they certify the fixed point (one round that changes nothing) or finish the job
-            const int ge = g;
-            launch_eval(ge);
-            hipLaunchKernelGGL(tail_commit_k, dim3(ge), dim3(kBlock), 0, st, choice, taken_by, T, ch_row, ch_new, ch_old, ch_t_old, ch_t_new);
-            hipLaunchKernelGGL(tail_update_k, dim3(ge), dim3(kBlock), 0, st, A, choice, taken_by, T, ch_row, ch_new, ch_old, ch_t_old, ch_t_new, flag, listA, listB);
-            hipLaunchKernelGGL(tail_rotate_k, dim3(1), dim3(1), 0, st, T);
-            unsigned long long *tb;
-            int *ver, *steps_total;
-            ORC_TRY(arena.alloc((size_t)n, &tb));
-            ORC_TRY(arena.alloc((size_t)n, &ver));
-            ORC_TRY(arena.alloc((size_t)64, &steps_total));
-            ORC_HIP(hipMemsetAsync(steps_total, 0, sizeof(int), st));
-            hipLaunchKernelGGL(chase_convert_k, dim3(g), dim3(kBlock), 0, st, (const int *)taken_by, tb, ver, n);
-            if (dbg_after_round) ORC_HIP(hipMemcpyAsync(dbg_after_round, choice, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, st));
-            lap("first lock-step round");
-            // lanes per cascade: the narrowest group that covers a typical row in one pass
-            const int group_env = getenv("ORC_AMG_CHASE_GROUP") ? atoi(getenv("ORC_AMG_CHASE_GROUP")) : 0;
-            // (r02: 16 / 32 / 64 by row length, one pass per row = ORC_AMG_CHASE_GROUP=-1.  All cascades of six iterations on one stream:
-            // that choice 494 ms, 16 lanes on every level 477 ms, 32: 526 ms, 8: 554 ms)
-            int group = group_env > 0 ? group_env : 16;
-            if (group_env < 0) {
-                int64_t stored = 0;  // padded entries: an upper bound of the mean row length is all that is needed
-                ORC_HIP(hipMemcpyAsync(&stored, A.P.slice_ptr + A.P.n_slices, sizeof(int64_t), hipMemcpyDeviceToHost, st));
-                ORC_HIP(hipStreamSynchronize(st));
-                const double avg_len = n > 0 ? (double)stored / (double)n : 0.;
-                group = avg_len <= 14. ? 16 : (avg_len <= 28. ? 32 : 64);
-            }
-            group = group <= 16 ? 16 : (group <= 32 ? 32 : 64);  // the instantiated widths: the kernel and chase_carry_k must agree on the groups per launch
-            int launches = 0, first_list = -1, list0 = -1;
-            if (trace) {  // the list the first lock-step round left
-                TailCounters h0;
-                ORC_HIP(hipMemcpyAsync(&h0, T, sizeof(h0), hipMemcpyDeviceToHost, st));
-                ORC_HIP(hipStreamSynchronize(st));
-                list0 = h0.cur;
-            }
-            for (;;) {
-                for (int b = 0; b < chase_batch; ++b) {
-                    if (group == 16) hipLaunchKernelGGL(tail_chase_k<16>, dim3(chase_grid), dim3(kBlock), 0, st, A, choice, tb, ver, flag, T, listA, listB, chase_steps, (const int *)prefs);
-                    else if (group == 32) hipLaunchKernelGGL(tail_chase_k<32>, dim3(chase_grid), dim3(kBlock), 0, st, A, choice, tb, ver, flag, T, listA, listB, chase_steps, (const int *)prefs);
-                    else hipLaunchKernelGGL(tail_chase_k<64>, dim3(chase_grid), dim3(kBlock), 0, st, A, choice, tb, ver, flag, T, listA, listB, chase_steps, (const int *)prefs);
-                    hipLaunchKernelGGL(chase_carry_k, dim3(64), dim3(kBlock), 0, st, T, (const int *)listA, (const int *)listB, listA, listB, chase_grid * (kBlock / group));
-                    hipLaunchKernelGGL(chase_rotate_k, dim3(1), dim3(1), 0, st, T, steps_total);
-                }
-                launches += chase_batch;
-                ORC_HIP(hipGetLastError());
-                int evaluated = 0;
-                ORC_HIP(hipMemcpyAsync(&h, T, sizeof(h), hipMemcpyDeviceToHost, st));
-                ORC_HIP(hipMemcpyAsync(&evaluated, steps_total, sizeof(int), hipMemcpyDeviceToHost, st));
-                ORC_HIP(hipStreamSynchronize(st));
-                if (first_list < 0) first_list = h.cur;
-                if (h.finished || h.cur == 0 || launches >= chase_launches) break;
-                // Cascades that multiply instead of running out (seen from a state that is complete but not this matrix's:
-                // displaced rows displace later ones and the chains run through each other's rows again and again) are
-                // left to the lock-step rounds, whose order keeps every row to one decision per round: give up once the
-                // evaluations exceed four per row (the channel's levels need 0.4 to 1.5).
-                if ((int64_t)evaluated > 4 * n + 4096) break;
-            }
-            rounds += h.rounds;
-            lap("cascades");
-            if (trace) {
-                int stot = 0;
-                ORC_HIP(hipMemcpy(&stot, steps_total, sizeof(int), hipMemcpyDeviceToHost));
-                fprintf(stderr, "[amg chase n=%lld] launches %d evaluations %d (%d changed their row) first list %d left %d finished %d\n", (long long)n, launches, stot, h.moved,
-                        list0, h.cur, h.finished);
-            }
-            fin = h.finished != 0;
-            bool verified_clean = false;
-            if (!fin) {  // certification / completion: exact first takers from scratch, every row evaluated
-                hipLaunchKernelGGL(agg_reset_k, dim3(g), dim3(kBlock), 0, st, taken_by, n);
-                hipLaunchKernelGGL(agg_scatter_k, dim3(g), dim3(kBlock), 0, st, choice, taken_by, n);
-                // [r04] the cascades ran out (nothing left to evaluate): the certifying round is expected to change nothing, and "would any
-                // row choose differently against the exact table?" is one coalesced pass (agg_verify_k: the sibling check's kernel) instead of a
-                // lock-step round's evaluate / commit / update / rotate over every row.  Only a state that is NOT the fixed point goes through
-                // the lock-step rounds (ORC_AMG_CERTIFY_ROUND=1: always, r03).
-                const bool quick = h.cur == 0 && !(getenv("ORC_AMG_CERTIFY_ROUND") && atoi(getenv("ORC_AMG_CERTIFY_ROUND")) != 0);
-                if (quick) {
-                    AggCounters hc;
-                    ORC_HIP(hipMemsetAsync(C, 0, sizeof(AggCounters), st));
-                    hipLaunchKernelGGL(agg_verify_k, dim3(g), dim3(kBlock), 0, st, A, (const int *)choice, (const int *)taken_by, C);
-                    ORC_HIP(hipGetLastError());
-                    ORC_HIP(hipMemcpyAsync(&hc, C, sizeof(hc), hipMemcpyDeviceToHost, st));
-                    ORC_HIP(hipStreamSynchronize(st));
-                    verified_clean = hc.changed == 0;
-                    if (trace) fprintf(stderr, "[amg certify n=%lld] one verification pass: %d rows would change\n", (long long)n, hc.changed);
-                }
-                if (verified_clean) {
-                    fin = true;
-                    g_cert_aggregations.fetch_add(1, std::memory_order_relaxed);
-                    g_cert_rounds.fetch_add(1, std::memory_order_relaxed);
-                    rounds += 1;
-                    lap("certification pass");
-                } else {
-                    hipLaunchKernelGGL(tail_seed_k, dim3(1), dim3(1), 0, st, T, (int)n);
-                }
-            }
-        }
-        int cert_batches = 0;
-        while (!fin) {
-            const int batch = chase_enabled && cert_batches == 0 ? 1 : kBatch;  // after the cascades one round is expected to certify
-            for (int b = 0; b < batch; ++b) {
-                static const int tail_grid = clamp_partials_grid(getenv("ORC_AMG_TAIL_GRID") ? atoi(getenv("ORC_AMG_TAIL_GRID")) : 1024);
-                const int ge = first ? g : tail_grid;
-                launch_eval(ge);
-                hipLaunchKernelGGL(tail_commit_k, dim3(ge), dim3(kBlock), 0, st, choice, taken_by, T, ch_row, ch_new, ch_old, ch_t_old, ch_t_new);
-                hipLaunchKernelGGL(tail_update_k, dim3(ge), dim3(kBlock), 0, st, A, choice, taken_by, T, ch_row, ch_new, ch_old, ch_t_old, ch_t_new, flag, listA, listB);
-                hipLaunchKernelGGL(tail_rotate_k, dim3(1), dim3(1), 0, st, T);
-                first = false;
-            }
-            if (small_enabled)
-                hipLaunchKernelGGL(tail_small_k, dim3(1), dim3(small_threads), 0, st, A, choice, taken_by, T, listA, listB, flag, ch_row, ch_new, ch_old, ch_t_old, ch_t_new,
-                                   1 << 20, small_max);
-            ORC_HIP(hipGetLastError());
-            ORC_HIP(hipMemcpyAsync(&h, T, sizeof(h), hipMemcpyDeviceToHost, st));
-            ORC_HIP(hipStreamSynchronize(st));
-            fin = h.finished != 0;
-            ++cert_batches;
-            if (h.rounds > 8 * 1000 * 1000) return set_error(ORC_ERR_BAD_ARGUMENT, "aggregation did not reach its fixed point");
-        }
-        lap("lock-step rounds");
-        if (chase_enabled && cert_batches > 0) {  // test hook: a certification that takes ONE round has changed nothing
-            g_cert_aggregations.fetch_add(1, std::memory_order_relaxed);
-            g_cert_rounds.fetch_add(h.rounds, std::memory_order_relaxed);
-        }
-        if (trace && chase_enabled && cert_batches > 0) fprintf(stderr, "[amg certify n=%lld] lock-step rounds %d\n", (long long)n, h.rounds);
-        if (cert_batches > 0) rounds += h.rounds;  // (a clean verification pass has counted itself)
-    }
-    if (dbg_count) {
-        int hd[2] = {0, 0};
-        ORC_HIP(hipMemsetAsync(dbg_count, 0, 2 * sizeof(int), st));
-        hipLaunchKernelGGL(count_diff_k, dim3(g), dim3(kBlock), 0, st, (const int *)dbg_after_sweep, (const int *)choice, n, dbg_count);
-        hipLaunchKernelGGL(count_diff_k, dim3(g), dim3(kBlock), 0, st, (const int *)dbg_after_round, (const int *)choice, n, dbg_count + 1);
-        ORC_HIP(hipMemcpyAsync(hd, dbg_count, sizeof(hd), hipMemcpyDeviceToHost, st));
-        ORC_HIP(hipStreamSynchronize(st));
-        fprintf(stderr, "[amg distance n=%lld] rows whose partner differs from the fixed point: %d after the sweeps, %d after the first lock-step round\n", (long long)n, hd[0], hd[1]);
-    }
-    ORC_HIP(hipMemsetAsync(chooser, 0xff, sizeof(int) * (size_t)n, st));
-    hipLaunchKernelGGL(chooser_k, dim3(g), dim3(kBlock), 0, st, choice, chooser, n);
-    ORC_HIP(hipGetLastError());
+    if (trace) fprintf(stderr, "[amg fallback n=%lld] %d sweeps\n", (long long)n, rounds);
+    g_cert_aggregations.fetch_add(1, std::memory_order_relaxed);
+    g_cert_rounds.fetch_add(rounds, std::memory_order_relaxed);
     if (rounds_out) *rounds_out = rounds;
-    return ORC_OK;
+    return finish_from_choice();
 }
 
 // Row-contiguous mirror, compacted: the product's scratch rows (reserved at twice the candidate count per row: the bound of the
@@ -2908,7 +1651,7 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
     int64_t *slice_ptr;
     const int n_slices = (int)((nc + 63) / 64);
     const size_t ncs = (size_t)std::max<int64_t>(nc, 1);
-    static const bool trace_t = getenv("ORC_AMG_TRACE") != nullptr;
+    const bool trace_t = cfg().amg_trace;
     double t_mark = 0.;
     auto lap = [&](const char *what) {  // trace only: wall time of the phase that just ended (drains the stream)
         if (!trace_t) return;
@@ -2928,11 +1671,11 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
     ORC_TRY(tmp.alloc((size_t)2, &counters));
     ORC_HIP(hipMemsetAsync(flags, 0, 4 * sizeof(int), st));
     ORC_HIP(hipMemsetAsync(counters, 0, 2 * sizeof(unsigned long long), st));
-    const bool use_sort = getenv("ORC_GALERKIN_SORT") != nullptr && atoi(getenv("ORC_GALERKIN_SORT")) != 0;  // per call: tests compare the forms
     // lanes per coarse row by LDS tier (list capacity 64 << t); ORC_GALERKIN_GROUPS="g0,g1,..." overrides
     const std::array<int, kGalerkinTiers> tier_group = [] {
         std::array<int, kGalerkinTiers> g = {16, 16, 32, 64, 64, 64, 64};  // measured at 10.24 M fine rows (levels of 7 / 15 / 34 entries per row)
-        if (const char *e = getenv("ORC_GALERKIN_GROUPS")) {
+        if (!cfg().galerkin_groups.empty()) {
+            const char *e = cfg().galerkin_groups.c_str();
             int t = 0;
             for (const char *q = e; *q && t < kGalerkinTiers; ++t) {
                 const int v = atoi(q);
@@ -2950,7 +1693,7 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
     // (a wavefront walks at most kBoundIters slices: the grid grows with the level beyond 8 192 x kBoundIters slices = 16.8 M coarse rows)
     const int64_t bound_grid = std::max<int64_t>(std::min<int64_t>(std::max<int64_t>(n_slices, 1), 8192), ((int64_t)n_slices + kBoundIters - 1) / kBoundIters);
     hipLaunchKernelGGL(galerkin_bound_k, dim3((unsigned)bound_grid), dim3(64), 0, st, A.P, choice, nc, flags, counters + 1, intra_off,
-                       slice_tot, tier_count, tier_list, use_sort ? 1 : 0);
+                       slice_tot, tier_count, tier_list, 0);
     long long *scan_part;
     ORC_TRY(tmp.alloc((size_t)2 * kScanBlocks + 2, &scan_part));
     ORC_TRY(scan_excl_dev(slice_tot, nullptr, (int64_t)n_slices, slice_base, nullptr, false, scan_part, st));
@@ -2981,21 +1724,17 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
     lap("galerkin bounds");
     static std::once_flag attr_once;  // several lane threads reach this concurrently
     std::call_once(attr_once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&galerkin_wave_k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&galerkin_merge_k<64, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&galerkin_merge_k<64, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&galerkin_merge_k<64, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&galerkin_merge_k<64, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&galerkin_merge_k<64, 0, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&galerkin_merge_k<32, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&galerkin_merge_k<32, 0, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&galerkin_merge_k<16, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&galerkin_merge_k<16, 0, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&galerkin_merge_k<64, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&galerkin_merge_k<64, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&galerkin_merge_k<32, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&galerkin_merge_k<32, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&galerkin_merge_k<16, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&galerkin_merge_k<16, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
-    if (n_sib > 0 && use_sort) return set_error(ORC_ERR_BAD_ARGUMENT, "galerkin: the sorting form (ORC_GALERKIN_SORT) builds one system per pass");
     // LDS tiers (32 B per list slot): every row was assigned to the narrowest list that is guaranteed to hold it
     if ((size_t)2 * max_cand > (size_t)(64 << (kGalerkinTiers - 1))) return set_error(ORC_ERR_BAD_ARGUMENT, "Galerkin row too long for LDS (%d candidates)", max_cand);
-    for (int t = 0; t < kGalerkinTiers && !use_sort; ++t) {
+    for (int t = 0; t < kGalerkinTiers; ++t) {
         if (htier[t] == 0) continue;
         const int cap = 64 << t;
         int G = tier_group[t];  // narrow rows: two or four coarse rows per wavefront
@@ -3009,41 +1748,25 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
         // [r04] 80 VGPRs (amdgpu_waves_per_eu(6): 12-24 bytes of scratch per lane) and 12 instead of 16 bytes of LDS per list slot: six wavefronts per
         // SIMD are resident, 24 per CU (r03: 83-88 VGPRs, five per SIMD; 16 per CU 407 ms over six iterations, 20: 372 ms, 24: 410 ms as the launch
         // no longer fitted); the shared pass for sibling systems carries three value sets in 128 VGPRs: four per SIMD
-        static const int merge_waves_env = getenv("ORC_GALERKIN_WAVES") ? atoi(getenv("ORC_GALERKIN_WAVES")) : 0;
-        const int merge_waves = merge_waves_env > 0 ? merge_waves_env : (n_sib == 0 ? 24 : 16);
+        const int merge_waves = n_sib == 0 ? 24 : 16;
         const int waves_per_cu = (int)std::max<size_t>(1, std::min<size_t>((size_t)merge_waves, (size_t)(150 * 1024) / smem));
         const int g = (int)std::min<int64_t>(((int64_t)htier[t] + rows_per_wave - 1) / rows_per_wave, (int64_t)256 * waves_per_cu);
         const int *tl = tier_list + (int64_t)t * nc, *tc = tier_count + t;
-        static const bool stages = getenv("ORC_GALERKIN_STAGES") && atoi(getenv("ORC_GALERKIN_STAGES")) != 0;
-#define ORC_MERGE(GG, SS, NS) hipLaunchKernelGGL(HIP_KERNEL_NAME(galerkin_merge_k<GG, SS, NS>), dim3(g), dim3(64), smem, st, A, choice, chooser, nc, cap, row_len, slice_base, intra_off, s_col, s_val, tl, tc, X)
-        if (stages && n_sib == 0) {  // measurement: the kernel cut short after steps 1 and 4, then the real launch
-            if (G == 16) { ORC_MERGE(16, 1, 1); ORC_MERGE(16, 4, 1); }
-            else if (G == 32) { ORC_MERGE(32, 1, 1); ORC_MERGE(32, 4, 1); }
-            else { ORC_MERGE(64, 1, 1); ORC_MERGE(64, 4, 1); }
-        }
+#define ORC_MERGE(GG, NS) hipLaunchKernelGGL(HIP_KERNEL_NAME(galerkin_merge_k<GG, NS>), dim3(g), dim3(64), smem, st, A, choice, chooser, nc, cap, row_len, slice_base, intra_off, s_col, s_val, tl, tc, X)
         if (n_sib == 0) {
-            if (G == 16) ORC_MERGE(16, 0, 1);
-            else if (G == 32) ORC_MERGE(32, 0, 1);
-            else ORC_MERGE(64, 0, 1);
+            if (G == 16) ORC_MERGE(16, 1);
+            else if (G == 32) ORC_MERGE(32, 1);
+            else ORC_MERGE(64, 1);
         } else if (n_sib == 1) {
-            if (G == 16) ORC_MERGE(16, 0, 2);
-            else if (G == 32) ORC_MERGE(32, 0, 2);
-            else ORC_MERGE(64, 0, 2);
+            if (G == 16) ORC_MERGE(16, 2);
+            else if (G == 32) ORC_MERGE(32, 2);
+            else ORC_MERGE(64, 2);
         } else {
-            if (G == 16) ORC_MERGE(16, 0, 3);
-            else if (G == 32) ORC_MERGE(32, 0, 3);
-            else ORC_MERGE(64, 0, 3);
+            if (G == 16) ORC_MERGE(16, 3);
+            else if (G == 32) ORC_MERGE(32, 3);
+            else ORC_MERGE(64, 3);
         }
 #undef ORC_MERGE
-    }
-    for (int t = 0; t < kGalerkinTiers && use_sort; ++t) {
-        if (htier[t] == 0) continue;
-        const int cap = 64 << t;
-        const size_t smem = (size_t)cap * 32;
-        const int waves_per_cu = (int)std::max<size_t>(1, std::min<size_t>(16, (size_t)(150 * 1024) / smem));
-        const int g = (int)std::min<int64_t>(htier[t], (int64_t)256 * waves_per_cu);
-        hipLaunchKernelGGL(galerkin_wave_k, dim3(g), dim3(64), smem, st, A, choice, chooser, nc, cap, row_len, slice_base, intra_off, s_col, s_val,
-                           flags + 1, (const int *)(tier_list + (int64_t)t * nc), (const int *)(tier_count + t), (int *)nullptr, (int *)nullptr);
     }
     lap("galerkin product");
     int64_t *pk_ptr, *w_sell, *w_pk;
@@ -3071,7 +1794,7 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
     // Packed mirror + LDS x windows for the levels whose rows are long enough for a window to be re-used (measured at
     // 10.24 M fine rows: 33 entries per row +2 %, 70 entries per row +17 % against the padded product; 15 entries per row
     // -10 %, so that level keeps the padded image).  ORC_SPMV_XWIN_MIN_NNZ < 0 switches the mirror off.
-    const int xwin_min = getenv("ORC_SPMV_XWIN_MIN_NNZ") ? atoi(getenv("ORC_SPMV_XWIN_MIN_NNZ")) : 24;  // (per call: the tests switch it)
+    const int xwin_min = cfg().spmv_xwin_min_nnz;
     const bool mirror = xwin_min >= 0 && packed_total > 0 && packed_total >= (int64_t)xwin_min * nc;
     int *pk_col = nullptr;
     double *pk_val = nullptr;
@@ -3094,7 +1817,7 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
     lap("galerkin pack");
     // narrow column image for the levels the uniform kernels multiply (no packed mirror: the first coarse level): 2-byte columns in
     // their products' stream; all or nothing, decided on the host (the kernel variant is a template argument)
-    static const bool narrow_on = !(getenv("ORC_SPMV_NARROW_COLS") && atoi(getenv("ORC_SPMV_NARROW_COLS")) == 0);
+    const bool narrow_on = cfg().spmv_narrow_cols;
     if (narrow_on && !mirror && padded > 0) {
         unsigned short *c16;
         int *cbase, *wide;
@@ -3112,7 +1835,6 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
     L.P = Pc; L.val = val; L.n = nc; L.padded = padded;
     L.pk = PackedDev();
     L.xw = XWinDev();
-    L.xs = XSortDev();
     L.rows = RowsDev();
     for (int x = 0; x < n_sib; ++x) {
         CoarseLevel &Lx = *sib[x].L;
@@ -3120,28 +1842,26 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
         Lx.P = Pc; Lx.val = x_val[x]; Lx.n = nc; Lx.padded = padded; Lx.rounds = L.rounds;
         Lx.choice = L.choice; Lx.chooser = L.chooser;
     }
-    static const bool rows_enabled = !(getenv("ORC_AMG_ROWS_MIRROR") && atoi(getenv("ORC_AMG_ROWS_MIRROR")) == 0);
-    if (rows_enabled && !scratch) { L.rows.slice_base = slice_base; L.rows.intra_off = intra_off; L.rows.col = s_col; L.rows.val = s_val; }
-    if (rows_enabled && scratch && packed_total > 0 && !last_level) {  // exact-size copy; the slices start where the packed mirror's do (pk_ptr); the last level is never aggregated
+    if (!scratch) { L.rows.slice_base = slice_base; L.rows.intra_off = intra_off; L.rows.col = s_col; L.rows.val = s_val; }
+    if (scratch && packed_total > 0 && !last_level) {  // exact-size copy; the slices start where the packed mirror's do (pk_ptr); the last level is never aggregated
         // Only the NEXT level's aggregation and Galerkin product walk it, and the mirror of the level below (A.rows) is dead now
         // that this product's kernels are queued (same stream): both take turns in the scratch arena's companion, so a hierarchy
-        // keeps no mirror once it is built (2 GB of 10.3 GB per hierarchy at 10.24 M rows).  ORC_AMG_MIRROR_ARENA=0: in `arena`.
-        static const bool mirror_arena_on = !(getenv("ORC_AMG_MIRROR_ARENA") && atoi(getenv("ORC_AMG_MIRROR_ARENA")) == 0);
-        Arena &rows_arena = mirror_arena_on ? scratch->companion() : arena;
-        if (mirror_arena_on) rows_arena.release(Arena::Mark{0, 0});
+        // keeps no mirror once it is built (2 GB of 10.3 GB per hierarchy at 10.24 M rows).
+        Arena &rows_arena = scratch->companion();
+        rows_arena.release(Arena::Mark{0, 0});
         int *r_col, *r_intra;
         double *r_val;
         ORC_TRY(rows_arena.alloc((size_t)packed_total, &r_col));
         ORC_TRY(rows_arena.alloc((size_t)packed_total, &r_val));
         ORC_TRY(rows_arena.alloc(ncs, &r_intra));
-        L.rows_transient = mirror_arena_on;
+        L.rows_transient = true;
         hipLaunchKernelGGL(rows_compact_k, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(n_slices, 256 * 16))), dim3(64), 0, st, (const int *)row_len, nc, n_slices,
                            (const long long *)slice_base, (const int *)intra_off, (const int *)s_col, (const double *)s_val, (const int64_t *)pk_ptr, r_intra, r_col, r_val);
         ORC_HIP(hipGetLastError());
         L.rows.slice_base = reinterpret_cast<const long long *>(pk_ptr); L.rows.intra_off = r_intra; L.rows.col = r_col; L.rows.val = r_val;
         for (int x = 0; x < n_sib; ++x) {  // a whole copy per sibling: the leader's is gone when ITS next level is built
-            Arena &xa = (mirror_arena_on && sib[x].rows_arena) ? *sib[x].rows_arena : *sib[x].arena;
-            if (mirror_arena_on && sib[x].rows_arena) xa.release(Arena::Mark{0, 0});
+            Arena &xa = sib[x].rows_arena ? *sib[x].rows_arena : *sib[x].arena;
+            if (sib[x].rows_arena) xa.release(Arena::Mark{0, 0});
             int *xr_col, *xr_intra;
             double *xr_val;
             ORC_TRY(xa.alloc((size_t)packed_total, &xr_col));
@@ -3152,7 +1872,7 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
             ORC_HIP(hipGetLastError());
             CoarseLevel &Lx = *sib[x].L;
             Lx.rows.slice_base = reinterpret_cast<const long long *>(pk_ptr); Lx.rows.intra_off = xr_intra; Lx.rows.col = xr_col; Lx.rows.val = xr_val;
-            Lx.rows_transient = mirror_arena_on && sib[x].rows_arena != nullptr;
+            Lx.rows_transient = sib[x].rows_arena != nullptr;
         }
     }
     if (mirror) {
@@ -3163,9 +1883,9 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
         ORC_TRY(arena.alloc((size_t)n_blocks * kXWinCap, &wcol));
         ORC_TRY(arena.alloc((size_t)n_blocks, &wsize));
         ORC_TRY(arena.alloc((size_t)packed_total, &lidx));
-        const int win_cap = getenv("ORC_XWIN_CAP") ? std::max(1, std::min(kXWinCap, atoi(getenv("ORC_XWIN_CAP")))) : kXWinCap;  // (per call: test hook)
-        const int bit_words = getenv("ORC_XWIN_BITWORDS") ? std::max(1, std::min(kXBitWords, atoi(getenv("ORC_XWIN_BITWORDS")))) : kXBitWords;
-        const int small_words = getenv("ORC_XWIN_SMALL_BITWORDS") ? std::max(1, std::min(kXBitWordsSmall, atoi(getenv("ORC_XWIN_SMALL_BITWORDS")))) : kXBitWordsSmall;
+        const int win_cap = cfg().xwin_cap > 0 ? std::min(kXWinCap, cfg().xwin_cap) : kXWinCap;  // (test hooks: forced fallbacks)
+        const int bit_words = cfg().xwin_bitwords > 0 ? std::min(kXBitWords, cfg().xwin_bitwords) : kXBitWords;
+        const int small_words = cfg().xwin_small_bitwords > 0 ? std::min(kXBitWordsSmall, cfg().xwin_small_bitwords) : kXBitWordsSmall;
         int *pending;
         ORC_TRY(tmp.alloc((size_t)1, &pending));
         ORC_HIP(hipMemsetAsync(pending, 0, sizeof(int), st));
@@ -3188,7 +1908,7 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
             Lx.pk.val = x_pk_val[x];
             Lx.xw = L.xw;
         }
-        static const bool xwin_stats = getenv("ORC_XWIN_STATS") && atoi(getenv("ORC_XWIN_STATS")) != 0;
+        const bool xwin_stats = cfg().debug_xwin;
         if (xwin_stats) {
             unsigned long long *d_st, h_st[5];
             ORC_TRY(tmp.alloc((size_t)5, &d_st));
@@ -3199,29 +1919,6 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
             fprintf(stderr, "[orc xwin] rows %lld nnz %lld blocks %lld: window entries %llu (%.1f per row), runs %llu (%.1f entries per run), in runs >= 8: %.1f %%, span < 65536: %llu blocks, no window: %llu\n",
                     (long long)nc, (long long)packed_total, (long long)n_blocks, h_st[0], (double)h_st[0] / (double)nc, h_st[1], (double)h_st[0] / (double)std::max<unsigned long long>(h_st[1], 1),
                     100. * (double)h_st[2] / (double)std::max<unsigned long long>(h_st[0], 1), h_st[3], h_st[4]);
-        }
-        // Length-sorted image (XSortDev): OFF by default.  Measured at 10.24 M cells: the sorted product needs a third of the vector
-        // instructions per entry of the packed one and is NOT faster (level 2: 229-236 us against 235-237, level 3: 239-247 against
-        // 227-244, same box), while building the image costs +45-65 ms and 11 GB per SIMPLE iteration — the window product is not
-        // bound by instruction issue after all.  Kept behind the switch with its exactness test.  (read per call: the test switches it)
-        const bool xsort_on = getenv("ORC_SPMV_XSORT") && atoi(getenv("ORC_SPMV_XSORT")) != 0;
-        if (xsort_on && n_sib > 0) return set_error(ORC_ERR_BAD_ARGUMENT, "galerkin: the length-sorted image (ORC_SPMV_XSORT) is built one system per pass");
-        if (xsort_on) {
-            int *perm, *slen;
-            int64_t *sptr;
-            double *sval;
-            unsigned short *slidx;
-            unsigned char *ok;
-            ORC_TRY(arena.alloc((size_t)n_blocks * kXWinRows, &perm));
-            ORC_TRY(arena.alloc((size_t)n_blocks * kXWinRows, &slen));
-            ORC_TRY(arena.alloc((size_t)n_blocks * 4, &sptr));
-            ORC_TRY(arena.alloc((size_t)packed_total, &sval));
-            ORC_TRY(arena.alloc((size_t)packed_total, &slidx));
-            ORC_TRY(arena.alloc((size_t)n_blocks, &ok));
-            hipLaunchKernelGGL(xsort_build_k, dim3((unsigned)std::min<int64_t>(n_blocks, 4096)), dim3(kBlock), 0, st, Pc, L.pk, (const unsigned short *)lidx, perm, slen, sptr, sval,
-                               slidx, ok, n_blocks);
-            ORC_HIP(hipGetLastError());
-            L.xs.perm = perm; L.xs.slen = slen; L.xs.sptr = sptr; L.xs.val = sval; L.xs.lidx = slidx; L.xs.ok = ok;
         }
     }
     lap("galerkin mirrors");
@@ -3293,29 +1990,19 @@ static int multigrid_solve_dev(const MatView &A, const double *r, uint64_t level
         // :80, :84 were done ahead of time (multigrid_prepare_dev) for exactly this matrix
         const AmgHierarchy::Level &h = hier->level[level - 1];
         choice = h.choice; chooser = h.chooser;
-        L.P = h.P; L.val = h.val; L.pk = h.pk; L.xw = h.xw; L.xs = h.xs; L.rows = h.rows; L.n = h.n; L.padded = h.padded; L.rounds = h.rounds;
+        L.P = h.P; L.val = h.val; L.pk = h.pk; L.xw = h.xw; L.rows = h.rows; L.n = h.n; L.padded = h.padded; L.rounds = h.rounds;
     } else {
         ORC_TRY(arena.alloc((size_t)std::max<int64_t>(n, 1), &choice));
         ORC_TRY(arena.alloc((size_t)std::max<int64_t>(n, 1), &chooser));
-        AmgCache *cache = stats ? stats->cache : nullptr;
         const int *warm = nullptr;
-        static const bool warm_enabled = getenv("ORC_AMG_WARM") != nullptr && atoi(getenv("ORC_AMG_WARM")) != 0;
-        if (warm_enabled && cache && level < 8 && cache->size[level] == n) warm = cache->choice[level].p;
-        int warm_kind = 1;
         SiblingPairing *sib = stats ? stats->sibling : nullptr;
-        if (sib && stats->sibling_role == 2 && level == 1) {  // the fine level only: there the systems share their pattern
-            if (const int *w = sib->wait((int)level, n, st)) { warm = w; warm_kind = 2; }
-        }
-        const int agg_st = aggregate(A, arena, choice, chooser, &L.rounds, warm, warm_kind);  // :80 (scratch is released with the level)
+        if (sib && stats->sibling_role == 2 && level == 1) warm = sib->wait((int)level, n, st);  // the fine level only: there the systems share their pattern
+        const int agg_st = aggregate(A, arena, choice, chooser, &L.rounds, warm);  // :80 (scratch is released with the level)
         if (sib && stats->sibling_role == 1 && level == 1) {
             if (agg_st == ORC_OK) ORC_TRY(sib->publish((int)level, choice, n, st));
             sib->finish();  // nothing more will be published
         }
         ORC_TRY(agg_st);
-        if (cache && level < 8) {
-            if (cache->size[level] != n) { ORC_TRY(cache->choice[level].alloc((size_t)std::max<int64_t>(n, 1))); cache->size[level] = n; }
-            ORC_HIP(hipMemcpyAsync(cache->choice[level].p, choice, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, st));
-        }
         ORC_TRY(galerkin(A, choice, chooser, arena, L));  // :84
     }
     const int64_t nc = L.n;
@@ -3331,7 +2018,6 @@ static int multigrid_solve_dev(const MatView &A, const double *r, uint64_t level
     Ac.val = L.val;
     Ac.pk = L.pk;
     Ac.xw = L.xw;
-    Ac.xs = L.xs;
     Ac.rows = L.rows;
     Ac.symmetric = A.symmetric;  // halo stays null: coarse levels are solved per rank
     double *r_prime, *e_prime, *partials, *scal;
@@ -3382,8 +2068,6 @@ int multigrid_prepare_dev(const MatView &A_in, int preconditioner, Arena &arena,
         bool spoken = false;
         ~SpeakGuard() { if (s && !spoken) s->withdraw(slot); }
     } speak{(sibling && sibling_role >= 2) ? sibling : nullptr, sibling_role - 2};
-    static const bool scratch_on = !(getenv("ORC_AMG_SCRATCH") && atoi(getenv("ORC_AMG_SCRATCH")) == 0);  // 0: everything in `arena` (round 2)
-    if (!scratch_on) scratch = nullptr;
     if (n == 0) return ORC_OK;
     if (scratch) {  // nothing of an earlier set-up's mirrors is alive
         scratch->companion().release(Arena::Mark{0, 0});
@@ -3396,8 +2080,7 @@ int multigrid_prepare_dev(const MatView &A_in, int preconditioner, Arena &arena,
     // rows, and in SELL every entry of a row is a cache line of its own.  No gain on one stream, -10 ... -14 ms in the concurrent iteration
     // (sell_from_csr_host).
     if (!views[0].rows.col && A_in.P.rows_col && A_in.P.rows_base && A_in.val && A_in.P.csr_row_ptr && A_in.P.nnz > 0) {
-        const char *e = getenv("ORC_AMG_L0_MIRROR");  // (per call: the tests compare the forms)
-        if (!(e && atoi(e) == 0)) {
+        if (cfg().amg_l0_mirror) {
             double *rv;
             ORC_TRY(arena.alloc((size_t)A_in.P.nnz, &rv));
             ORC_TRY(sell_rows_values_dev(A_in.P, A_in.val, rv));
@@ -3415,8 +2098,7 @@ int multigrid_prepare_dev(const MatView &A_in, int preconditioner, Arena &arena,
     const uint64_t max_levels = 3;  // MULTIGRID_COARSENING_LEVELS, :10
     // [r04] one Galerkin pass for the momentum systems that share the fine pairing (SiblingPairing::make_offer ...; ORC_AMG_SHARED_GALERKIN=0:
     // every system multiplies for itself, r03).  Read per call: the tests compare the two forms.
-    const bool share_on = !(getenv("ORC_AMG_SHARED_GALERKIN") && atoi(getenv("ORC_AMG_SHARED_GALERKIN")) == 0) && scratch != nullptr &&
-                          !(getenv("ORC_GALERKIN_SORT") && atoi(getenv("ORC_GALERKIN_SORT")) != 0) && !(getenv("ORC_SPMV_XSORT") && atoi(getenv("ORC_SPMV_XSORT")) != 0);
+    const bool share_on = cfg().amg_shared_galerkin && scratch != nullptr;
     for (uint64_t level = 1; level <= max_levels; ++level) {
         const MatView &A = views[level - 1];
         const int64_t nf = A.P.n;
@@ -3444,7 +2126,7 @@ int multigrid_prepare_dev(const MatView &A_in, int preconditioner, Arena &arena,
         // the aggregation's work lists (48 bytes per row) are dead when it returns: they live in `scratch` when there is one
         Arena &agg_arena = scratch ? *scratch : arena;
         const Arena::Mark agg_mark = agg_arena.mark();
-        const int agg_st = aggregate(A, agg_arena, h.choice, h.chooser, &L.rounds, warm, 2);
+        const int agg_st = aggregate(A, agg_arena, h.choice, h.chooser, &L.rounds, warm);
         if (scratch) scratch->release(agg_mark);
         GalerkinSibling gs[2];
         int n_sib = 0;
@@ -3476,7 +2158,7 @@ int multigrid_prepare_dev(const MatView &A_in, int preconditioner, Arena &arena,
                     AggCounters hc[2];
                     ORC_HIP(hipMemcpyAsync(hc, C, sizeof(hc), hipMemcpyDeviceToHost, st));
                     ORC_HIP(hipStreamSynchronize(st));
-                    static const bool trace_v = getenv("ORC_AMG_TRACE") != nullptr;
+                    const bool trace_v = cfg().amg_trace;
                     for (int q = 0; q < n_off; ++q) {
                         const MatView &B = *offers[q]->view;
                         const bool same = B.P.n == nf && B.P.col == A.P.col && hc[q].changed == 0;
@@ -3503,7 +2185,7 @@ int multigrid_prepare_dev(const MatView &A_in, int preconditioner, Arena &arena,
         ORC_TRY(gal_st);
         }
         // a mirror in the companion arena lives until the next level is built: the hierarchy does not carry it
-        h.P = L.P; h.val = L.val; h.pk = L.pk; h.xw = L.xw; h.xs = L.xs; h.rows = L.rows_transient ? RowsDev() : L.rows; h.n = L.n; h.padded = L.padded; h.rounds = L.rounds;
+        h.P = L.P; h.val = L.val; h.pk = L.pk; h.xw = L.xw; h.rows = L.rows_transient ? RowsDev() : L.rows; h.n = L.n; h.padded = L.padded; h.rounds = L.rounds;
         H.n_levels = (int)level;
         if (!(level < max_levels && L.n > 16)) break;  // :109
         MatView Ac;
@@ -3511,8 +2193,7 @@ int multigrid_prepare_dev(const MatView &A_in, int preconditioner, Arena &arena,
         Ac.val = L.val;
         Ac.pk = L.pk;
         Ac.xw = L.xw;
-        Ac.xs = L.xs;
-        Ac.rows = L.rows;
+            Ac.rows = L.rows;
         Ac.symmetric = A.symmetric;
         views[level] = Ac;
     }
@@ -3626,9 +2307,9 @@ int multigrid_arm3_dev(const MatView3 &A3, const double *const b[3], double *con
         if (hipStreamSynchronize(local[k].stream) != hipSuccess && stp == ORC_OK) stp = set_error(ORC_ERR_HIP, "stream synchronisation failed in a set-up thread");
         // test hook (tests/mp_worker.py, mode gpu_lane_error): ORC_DEBUG_INJECT_LANE_ERROR="rank:lane" fails that rank's set-up thread
         // locally — the level-0 collectives of every rank still complete and the caller's status agreement tells all of them
-        if (const char *inj = getenv("ORC_DEBUG_INJECT_LANE_ERROR")) {
+        if (!cfg().inject_lane_error.empty()) {
             int r_ = -1, k_ = -1;
-            if (sscanf(inj, "%d:%d", &r_, &k_) == 2 && r_ == local[k].rank && k_ == k && stp == ORC_OK)
+            if (sscanf(cfg().inject_lane_error.c_str(), "%d:%d", &r_, &k_) == 2 && r_ == local[k].rank && k_ == k && stp == ORC_OK)
                 stp = set_error(ORC_ERR_HIP, "injected lane error (rank %d, lane %d)", r_, k_);
         }
         st_prep[k] = stp;
@@ -3649,9 +2330,6 @@ int multigrid_arm3_dev(const MatView3 &A3, const double *const b[3], double *con
         try { th[k] = std::thread(prepare, k); if (k > 0) ++n_follower_threads; } catch (...) { /* no thread to be had: prepared below, before the join */ }
     }
 
-    // ORC_TRIPLE_SETUP_FIRST=1 (measurement): the three set-ups run with the chip to themselves, the level-0 solve follows (beside the
-    // p' hierarchy, which the callback starts) instead of sharing the chip with them
-    static const bool setup_first = getenv("ORC_TRIPLE_SETUP_FIRST") && atoi(getenv("ORC_TRIPLE_SETUP_FIRST")) != 0;
     auto join_hierarchies = [&] {
         for (int k = 0; k < 3; ++k) {
             if (th[k].joinable()) th[k].join();
@@ -3659,7 +2337,6 @@ int multigrid_arm3_dev(const MatView3 &A3, const double *const b[3], double *con
         }
         if (on_hierarchies_built) on_hierarchies_built();
     };
-    if (setup_first) join_hierarchies();
 
     // ---- level 0 in lock-step
     double *b3, *x3, *r3;
@@ -3688,7 +2365,7 @@ int multigrid_arm3_dev(const MatView3 &A3, const double *const b[3], double *con
     ORC_TRACE("arm3: level-0 solve queued; joining the hierarchies");
 
     // ---- the hierarchies
-    if (!setup_first) join_hierarchies();
+    join_hierarchies();
     for (int k = 0; k < 3; ++k)
         if (st_prep[k] != ORC_OK) { g.last_error = local[k].last_error; return st_prep[k]; }
     const AmgHierarchy *H[3] = {&lanes[0].hierarchy, &lanes[1].hierarchy, &lanes[2].hierarchy};
@@ -3710,7 +2387,7 @@ int multigrid_arm3_dev(const MatView3 &A3, const double *const b[3], double *con
         ORC_HIP(hipStreamSynchronize(st));
         shared = hd == 0;
     }
-    static const bool trace = getenv("ORC_AMG_TRACE") != nullptr;
+    const bool trace = cfg().amg_trace;
     if (trace) fprintf(stderr, "[amg triple n=%lld] level 1 %s\n", (long long)n, shared ? "in lock-step" : "per system");
     ORC_TRACE("arm3: hierarchies joined, level 1 %s", shared ? "in lock-step" : "per system");
 
@@ -3769,7 +2446,7 @@ int multigrid_arm3_dev(const MatView3 &A3, const double *const b[3], double *con
         ORC_TRY(arena.alloc(nc3, &e1));
         ORC_TRY(arena.alloc((size_t)3 * kMaxPartials, &partials));
         ORC_TRY(arena.alloc((size_t)4, &norm3));
-        static const int dbg_mask = getenv("ORC_DEBUG_SYNC") ? atoi(getenv("ORC_DEBUG_SYNC")) : 0;  // debugging aid: drain the stream after chosen steps
+        const int dbg_mask = cfg().debug_sync;  // debugging aid: drain the stream after chosen steps
         int step_no = 0;
         auto step = [&](const char *what) { if (dbg_mask & (1 << step_no)) { (void)hipStreamSynchronize(st); ORC_TRACE("arm3 level 1: %s done", what); } ++step_no; };
         const bool dbg_sync = (dbg_mask & 64) != 0;
@@ -3801,7 +2478,7 @@ int multigrid_arm3_dev(const MatView3 &A3, const double *const b[3], double *con
             ORC_HIP(hipEventRecord(ev_main, st));
             for (int k = 0; k < 3; ++k) {
                 MatView Ak;
-                Ak.P = H[k]->level[0].P; Ak.val = H[k]->level[0].val; Ak.pk = H[k]->level[0].pk; Ak.xw = H[k]->level[0].xw; Ak.xs = H[k]->level[0].xs;
+                Ak.P = H[k]->level[0].P; Ak.val = H[k]->level[0].val; Ak.pk = H[k]->level[0].pk; Ak.xw = H[k]->level[0].xw;
                 Ak.rows = H[k]->level[0].rows;
                 Ak.symmetric = plain[k].symmetric;
                 ORC_HIP(hipStreamWaitEvent(lanes[k].solve_stream, ev_main, 0));
@@ -3858,7 +2535,7 @@ int amg_debug_coarsen(const MatView &A, Arena &arena, std::vector<int> &choice_h
     if (mirror_out) *mirror_out = (L.pk.ptr && L.xw.lidx) ? 1 : 0;
     if (x_h && y_h && nc > 0) {
         MatView V;
-        V.P = L.P; V.val = L.val; V.pk = L.pk; V.xw = L.xw; V.xs = L.xs; V.symmetric = A.symmetric;
+        V.P = L.P; V.val = L.val; V.pk = L.pk; V.xw = L.xw; V.symmetric = A.symmetric;
         double *x, *y, *d1;
         ORC_TRY(arena.alloc((size_t)nc, &x));
         ORC_TRY(arena.alloc((size_t)nc, &y));

@@ -701,7 +701,7 @@ int orc_bench_amg_levels(OrcSolver *s, int reps, int64_t *rows, int64_t *nnz, in
             const AmgHierarchy::Level &h = H.level[l - 1];
             V.P = h.P; V.val = h.val; V.pk = h.pk; V.xw = h.xw; V.symmetric = A.symmetric;
             n_l = h.n; padded_l = h.padded;
-            if (getenv("ORC_DEBUG_XWIN") && h.xw.wsize) {  // window statistics of the level (measurement runs only)
+            if (cfg().debug_xwin && h.xw.wsize) {  // window statistics of the level (measurement runs only)
                 const int64_t nb = ((int64_t)h.P.n_slices + 3) / 4;
                 std::vector<int32_t> ws((size_t)nb);
                 ORC_HIP(hipStreamSynchronize(ctx().stream));

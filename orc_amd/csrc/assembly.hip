@@ -957,11 +957,12 @@ int solver_init(SolverState &s, OrcMesh *m, const OrcSettings *settings, double 
     s.mesh = m;
     s.settings = *settings;
     s.rho = rho; s.mu = mu; s.n = m->n_cells; s.n_own = m->n_own;
-    s.concurrent_momentum = !(getenv("ORC_CONCURRENT_MOMENTUM") && atoi(getenv("ORC_CONCURRENT_MOMENTUM")) == 0);
-    s.two_stream_multigrid = !(getenv("ORC_TWO_STREAM_MULTIGRID") && atoi(getenv("ORC_TWO_STREAM_MULTIGRID")) == 0);
-    s.triple_momentum = !(getenv("ORC_TRIPLE_MOMENTUM") && atoi(getenv("ORC_TRIPLE_MOMENTUM")) == 0);
-    s.early_p_hierarchy = !(getenv("ORC_EARLY_P_HIERARCHY") && atoi(getenv("ORC_EARLY_P_HIERARCHY")) == 0);
-    s.sibling_pairing = !(getenv("ORC_AMG_SIBLING") && atoi(getenv("ORC_AMG_SIBLING")) == 0);
+    // the schedule of THIS solver: fixed at its creation (config.hpp; a solver never changes schedule between iterations)
+    s.concurrent_momentum = cfg().concurrent_momentum;
+    s.two_stream_multigrid = cfg().two_stream_multigrid;
+    s.triple_momentum = cfg().triple_momentum;
+    s.early_p_hierarchy = cfg().early_p_hierarchy;
+    s.sibling_pairing = cfg().amg_sibling;
     ORC_TRY(validate_settings(s.settings));
     const size_t n = (size_t)s.n, pad = (size_t)std::max<int64_t>(m->pat.padded, 1), F = (size_t)m->n_faces;
     DevBuf<double> *nvec[] = {&s.u, &s.v, &s.w, &s.p, &s.p_prime, &s.b_u_di, &s.b_v_di, &s.b_w_di, &s.b_u, &s.b_v, &s.b_w, &s.b_p, &s.du, &s.dv, &s.dw};
@@ -1152,7 +1153,6 @@ static int solve_field_on(SolverState &s, DevBuf<double> &a, DevBuf<double> &b, 
     CtxDefaultsScope restore_defaults(ctx());  // this solver's guard and reduction order for the solve only
     ctx().breakdown_guard = t.breakdown_guard != 0;
     ctx().reduction_order = t.reduction_order;
-    stats.cache = &s.amg_cache[eq];
     stats.side = nullptr;
     // the momentum systems share their pairing's starting state (the caller has opened the exchange: SiblingPairing::begin)
     stats.sibling = (s.sibling_pairing && eq < 3) ? &s.sibling : nullptr;
@@ -1331,9 +1331,9 @@ static int solve_momentum_partitioned(SolverState &s) {
         if (st == ORC_OK && hipStreamSynchronize(local[k].stream) != hipSuccess) st = set_error(ORC_ERR_HIP, "stream synchronisation failed in a solve thread");
         // test hook (tests/mp_worker.py, mode gpu_lane_error): ORC_DEBUG_INJECT_LANE_ERROR="rank:lane" makes that rank's lane fail
         // locally after its set-up — every rank must still leave the solve with the same verdict and nobody may hang
-        if (const char *inj = getenv("ORC_DEBUG_INJECT_LANE_ERROR")) {
+        if (!cfg().inject_lane_error.empty()) {
             int r_ = -1, k_ = -1;
-            if (sscanf(inj, "%d:%d", &r_, &k_) == 2 && r_ == local[k].rank && k_ == k && st == ORC_OK)
+            if (sscanf(cfg().inject_lane_error.c_str(), "%d:%d", &r_, &k_) == 2 && r_ == local[k].rank && k_ == k && st == ORC_OK)
                 st = set_error(ORC_ERR_HIP, "injected lane error (rank %d, lane %d)", r_, k_);
         }
         {
@@ -1364,7 +1364,7 @@ static int solve_momentum_partitioned(SolverState &s) {
     // (1) on the library stream, one system after the other
     int st_main = ORC_OK;
     for (int k = 0; k < 3 && st_main == ORC_OK; ++k) {
-        s.stats.cache = nullptr; s.stats.side = nullptr; s.stats.hierarchy = nullptr;
+        s.stats.side = nullptr; s.stats.hierarchy = nullptr;
         st_main = iterative_solve_dev(view[k], b_used[k], sol[k]->p, t.iterations, ORC_SOLVER_BICGSTAB, t.relaxation, t.relative_convergence_threshold,
                                       t.preconditioner, s.arena, &s.stats);  // :273-282 (nested scaling, Q4)
         if (st_main == ORC_OK) st_main = residual_dev(view[k], b_used[k], sol[k]->p, r[k]);  // :283
@@ -1584,7 +1584,7 @@ int solver_iterate(SolverState &s, uint64_t iterations, double *report) {
     // orc_set_reduction_order: what orc_iterative_solve uses) are put back on every exit
     CtxDefaultsScope restore_defaults(ctx());
     const bool tvd = is_tvd(s.settings.momentum);
-    const bool dbg = getenv("ORC_DEBUG_NAN") != nullptr;
+    const bool dbg = cfg().debug_nan;
     HaloPlan &H = s.mesh->halo;
     const int64_t n = s.n;
     for (uint64_t it = 0; it < iterations; ++it) {
@@ -1620,8 +1620,7 @@ int solver_iterate(SolverState &s, uint64_t iterations, double *report) {
         // The p' hierarchy is needed after the momentum solves.  Beside the per-system lanes it is built from the start; in the
         // lock-step schedule the momentum set-ups are the critical path of the first phase (nothing bandwidth-bound but the
         // level-0 solve runs beside them), so it starts when they are through and runs beside the bandwidth-bound coarse levels.
-        static const int p_late_env = getenv("ORC_P_HIERARCHY_LATE") ? atoi(getenv("ORC_P_HIERARCHY_LATE")) : 1;
-        const bool p_late = early_p && triple_ok && method == ORC_SOLVER_MULTIGRID && p_late_env != 0;
+        const bool p_late = early_p && triple_ok && method == ORC_SOLVER_MULTIGRID;
         s.p_scratch_shared = p_late;
         if (early_p && !p_late) {
             ORC_HIP(hipStreamSynchronize(ctx().stream));  // the diagonals (and their ghosts) are in place
@@ -1637,9 +1636,7 @@ int solver_iterate(SolverState &s, uint64_t iterations, double *report) {
             if (H.active()) st3 = comm_global_status(st3);
             ORC_TRY(st3);
         } else if (lanes_ok) {
-            static const int setup_first_env = getenv("ORC_SETUP_FIRST") ? atoi(getenv("ORC_SETUP_FIRST")) : 0;  // measured: exact, +8 % wall (1.24 s against 1.15 s)
-            const bool setup_first = setup_first_env != 0 && method == ORC_SOLVER_MULTIGRID;
-            ORC_TRY(solve_momentum_concurrently(s, setup_first, prep.running ? &prep : nullptr));  // :99-136, the three systems side by side
+            ORC_TRY(solve_momentum_concurrently(s, false, prep.running ? &prep : nullptr));  // :99-136, the three systems side by side
         } else if (lanes_partitioned) {
             ORC_TRY(solve_momentum_partitioned(s));                     // the same with every RCCL call on the library stream
         } else {
@@ -1727,7 +1724,6 @@ int initialize_pressure_field_dev(SolverState &s) {
     ORC_TRY(s.a_p.zero());
     hipLaunchKernelGGL(laplace_p_k, dim3(grid_for(s.n)), dim3(kBlock), 0, ctx().stream, m.dev(), m.pat.dev(), s.a_p.p, s.b_p.p, s.dev_status.p);
     ORC_HIP(hipGetLastError());
-    s.stats.cache = nullptr;
     ORC_TRY(iterative_solve_dev(mesh_view(s, s.a_p.p), s.b_p.p, s.p.p, 10, ORC_SOLVER_JACOBI, 0.1, 1e-6, ORC_PRECOND_JACOBI, s.arena, &s.stats));
     return fetch_status(s);
 }
@@ -1743,7 +1739,6 @@ int initialize_velocity_field_dev(SolverState &s) {
     CtxDefaultsScope restore_defaults(ctx());
     ctx().breakdown_guard = s.settings.breakdown_guard != 0;
     ctx().reduction_order = s.settings.reduction_order;
-    s.stats.cache = nullptr;
     ORC_TRY(iterative_solve_dev(mesh_view(s, s.a_p.p), s.b_p.p, s.p_prime.p, 10, ORC_SOLVER_BICGSTAB, 0.1, 1e-6, ORC_PRECOND_JACOBI, s.arena, &s.stats));  // :595-604
     if (m.halo.active()) ORC_TRY(m.halo.exchange(s.p_prime.p));
     hipLaunchKernelGGL(psi_velocity_k, dim3(grid_for(s.n)), dim3(kBlock), 0, ctx().stream, m.dev(), s.p_prime.p, s.u.p, s.v.p, s.w.p);
@@ -1786,7 +1781,6 @@ int initialize_flow_dev(SolverState &s, uint64_t iteration_count) {
             hipLaunchKernelGGL(blend_k, dim3(grid_for(len)), dim3(kBlock), 0, ctx().stream, len, mats[k]->p, s.a_di.p, 1. - diffusion_fraction,
                                diffusion_fraction, s.a_p.p);
             ORC_HIP(hipGetLastError());
-            s.stats.cache = nullptr;
             ORC_TRY(iterative_solve_dev(mesh_view(s, s.a_p.p), rhs[k]->p, x[k]->p, iteration_count, ORC_SOLVER_BICGSTAB, 0.5, 1e-6,
                                         ORC_PRECOND_JACOBI, s.arena, &s.stats));
         }

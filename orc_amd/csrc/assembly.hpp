@@ -72,7 +72,6 @@ struct SolverState {
     DevBuf<int> dev_status;
     Arena arena;
     SolveStats stats;
-    AmgCache amg_cache[4];  // u, v, w, p' (warm start of the per-solve hierarchy set-up)
     SiblingPairing sibling;  // u's pairing of this iteration as the starting state of v's and w's (linalg.hpp)
     // The u, v and w systems of an iteration are independent (solver.rs:99-136 solves them one after the other, none
     // reads another's result): each gets its own stream, arena and host thread, so the latency-bound set-up rounds of

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/orc_amd.h"
+#include "config.hpp"
 
 namespace orc {
 
@@ -28,7 +29,6 @@ struct Ctx {
     bool profile = false;
     bool breakdown_guard = true;  // OrcSettings.breakdown_guard of the running solve
     int reduction_order = 0;      // OrcReductionOrder of the running solve: 0 = wave trees, 1 = the reference's (nalgebra) association
-    int spmv_variant = 0;         // orc_debug_set_spmv_variant (measurement only)
     long long halo_overlaps = 0;  // level-0 products that ran beside their halo exchange (orc_debug_halo_overlaps)
     int *guard_events = nullptr;  // device counter: BiCGSTAB solves in which the breakdown guard fired (orc_breakdown_guard_events)
     // multi-GPU (comm.cpp)
@@ -59,8 +59,7 @@ int set_error(int code, const char *fmt, ...);
 // ORC_DEBUG_TRACE=1: progress markers of the SIMPLE driver and the solves on stderr (rank, thread-agnostic): where does a run stand?
 #define ORC_TRACE(...)                                                                     \
     do {                                                                                   \
-        static const bool on__ = getenv("ORC_DEBUG_TRACE") != nullptr;                     \
-        if (on__) { fprintf(stderr, "[orc trace r%d] ", orc::ctx().rank); fprintf(stderr, __VA_ARGS__); fprintf(stderr, "\n"); fflush(stderr); } \
+        if (orc::cfg().trace) { fprintf(stderr, "[orc trace r%d] ", orc::ctx().rank); fprintf(stderr, __VA_ARGS__); fprintf(stderr, "\n"); fflush(stderr); } \
     } while (0)
 
 #define ORC_HIP(call)                                                                                     \

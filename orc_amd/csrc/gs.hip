@@ -69,29 +69,6 @@ __device__ __forceinline__ bool prio_greater(int a, int b) {  // strict total or
 
 __device__ __forceinline__ int64_t row_base_sell(const SellDev &P, int64_t i) { return P.slice_ptr[i >> 6] + (i & 63); }
 
-// one Jones-Plassmann round: an uncoloured row whose priority beats all its uncoloured neighbours takes the smallest
-// colour none of its coloured neighbours has.  Reads the colours committed by earlier rounds only (colour_in).
-__global__ void jp_round_k(SellDev P, const int *__restrict__ color_in, int *__restrict__ color_out, int *__restrict__ remaining, int *__restrict__ overflow) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P.n; i += (int64_t)gridDim.x * blockDim.x) {
-        if (color_in[i] >= 0) { color_out[i] = color_in[i]; continue; }
-        const int len = P.row_len[i];
-        const int64_t base = P.slice_ptr[i >> 6] + (i & 63);
-        unsigned long long used = 0ull;
-        bool local_max = true;
-        for (int k = 0; k < len; ++k) {
-            const int j = P.col[base + (int64_t)k * 64];
-            if (j == i || j >= P.n) continue;  // ghost columns do not constrain the colouring
-            const int cj = color_in[j];
-            if (cj >= 0) used |= 1ull << cj;
-            else if (prio_greater(j, (int)i)) { local_max = false; break; }
-        }
-        if (!local_max) { color_out[i] = -1; atomicAdd(remaining, 1); continue; }
-        const unsigned long long freec = ~used;
-        if (freec == 0ull) { atomicExch(overflow, 1); color_out[i] = -1; continue; }
-        color_out[i] = __ffsll((long long)freec) - 1;
-    }
-}
-
 // Speculative first-fit colouring with conflict resolution (Gebremedhin-Manne), two kernels per round, Jacobi style so
 // that the result does not depend on scheduling: every uncoloured row takes the smallest colour none of its neighbours
 // holds in the previous round's state (tentative), then a row that shares its tentative colour with a neighbour coloured
@@ -172,15 +149,10 @@ static int build_coloring(const SellDev &P, Coloring &C, Arena *arena = nullptr,
     ORC_HIP(hipMemsetAsync(C.color_p, 0xff, sizeof(int) * (size_t)n, st));
     int *in = C.color_p, *out = tmp;
     const int g = grid_for(n);
-    static const bool speculative = !(getenv("ORC_GS_JONES_PLASSMANN") && atoi(getenv("ORC_GS_JONES_PLASSMANN")) != 0);
     for (int round = 0; round < 10000; ++round) {
         ORC_HIP(hipMemsetAsync(flags, 0, 2 * sizeof(int), st));
-        if (speculative) {
-            hipLaunchKernelGGL(spec_assign_k, dim3(g), dim3(kBlock), 0, st, P, in, tent, flags + 1);
-            hipLaunchKernelGGL(spec_resolve_k, dim3(g), dim3(kBlock), 0, st, P, in, tent, out, flags);
-        } else {
-            hipLaunchKernelGGL(jp_round_k, dim3(g), dim3(kBlock), 0, st, P, in, out, flags, flags + 1);
-        }
+        hipLaunchKernelGGL(spec_assign_k, dim3(g), dim3(kBlock), 0, st, P, in, tent, flags + 1);
+        hipLaunchKernelGGL(spec_resolve_k, dim3(g), dim3(kBlock), 0, st, P, in, tent, out, flags);
         ORC_HIP(hipGetLastError());
         int h[2];
         ORC_HIP(hipMemcpyAsync(h, flags, sizeof(h), hipMemcpyDeviceToHost, st));
@@ -538,16 +510,14 @@ static int get_coloring(const MatView &A, std::unique_ptr<Coloring> &owned, cons
         if (it == cache.end()) {
             auto c = std::make_unique<Coloring>();
             ORC_TRY(build_coloring(A.P, *c));
-            static const bool sorted_enabled = !(getenv("ORC_GS_SORTED") && atoi(getenv("ORC_GS_SORTED")) == 0);
-            if (sorted_enabled) ORC_TRY(build_color_sell(A.P, *c));
+            ORC_TRY(build_color_sell(A.P, *c));
             it = cache.emplace((const void *)A.P.col, std::move(c)).first;
         }
         *out = it->second.get();
         return ORC_OK;
     }
     owned = std::make_unique<Coloring>();
-    static const bool sorted_on = !(getenv("ORC_GS_SORTED") && atoi(getenv("ORC_GS_SORTED")) == 0);
-    ORC_TRY(build_coloring(A.P, *owned, arena, !sorted_on));
+    ORC_TRY(build_coloring(A.P, *owned, arena, false));
     *out = owned.get();
     return ORC_OK;
 }
@@ -1019,7 +989,7 @@ static int gsx_bicgstab(const SlotMat<S> &M, const std::vector<int> &color_slice
 }
 
 // is the slot-space solver used?  (ORC_GS_SLOTSPACE=0: r03's row-space recurrences; read per solve: the tests compare the two)
-static inline bool gsx_enabled() { return !(getenv("ORC_GS_SLOTSPACE") && atoi(getenv("ORC_GS_SLOTSPACE")) == 0); }
+static inline bool gsx_enabled() { return cfg().gs_slotspace; }
 
 // The u, v, w momentum systems of a SIMPLE iteration (solver.rs:99-136) under ORC_SOLVER_BICGSTAB_GS_PRECOND, in lock-step: the views
 // share the mesh pattern (persistent: its colouring and colour-sorted layout are cached); b[k], x[k] in row order.  Single GPU.
@@ -1072,7 +1042,7 @@ int gs_arm_dev(const MatView &A, const double *b, double *x, uint64_t iteration_
     ORC_TRY(arena.alloc((size_t)1, &status));
     ORC_HIP(hipMemsetAsync(status, 0, sizeof(int), st));
     // the matrix in colour-sorted storage: cached layout + this solve's values, or all of it built now (coarse levels)
-    static const bool sorted_enabled = !(getenv("ORC_GS_SORTED") && atoi(getenv("ORC_GS_SORTED")) == 0);
+    constexpr bool sorted_enabled = true;  // (colour-sorted storage; r02's row-list kernel gs_color_k serves what has no sorted image)
     SortedView view;
     if (C->sorted.built) {
         double *vals;

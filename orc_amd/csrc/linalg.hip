@@ -160,8 +160,6 @@ int sum_reference(const double *a, int64_t n, double *out) {
     return ORC_OK;
 }
 
-static std::atomic<long long> g_xsort_products{0};  // products launched on a length-sorted image, any thread (test hook)
-long long debug_xsort_products() { return g_xsort_products.load(std::memory_order_relaxed); }
 
 static inline bool reference_order(const MatView &A) { return ctx().reduction_order == ORC_REDUCTION_REFERENCE && A.halo == nullptr; }
 
@@ -169,8 +167,7 @@ static inline bool reference_order(const MatView &A) { return ctx().reduction_or
 // product 198 -> 178 us) and cost where it lives in the 256 MB Infinity Cache (1.03 M cells, 62 MB: 0.65 -> 0.60 of peak).
 // ORC_SPMV_NT=0 / 1 forces the policy.
 static inline int stream_nt(int64_t stream_bytes) {
-    const char *e = getenv("ORC_SPMV_NT");  // per launch: the tests run one process through both policies
-    const int forced = e ? atoi(e) : -1;
+    const int forced = cfg().spmv_nt;
     if (forced >= 0) return forced != 0;
     return stream_bytes > ((int64_t)128 << 20);
 }
@@ -179,8 +176,7 @@ int matview_stream_nt(const MatView &A) { return stream_nt(A.pk.ptr && A.xw.lidx
 
 static inline int spmv_grid(int32_t n_slices) {
     int64_t g = ((int64_t)n_slices + 3) / 4;  // 4 waves (slices) per workgroup
-    // ORC_SPMV_GRID (measurement): fewer resident workgroups per CU leave wave slots to the set-up kernels of other streams
-    const int cap = getenv("ORC_SPMV_GRID") ? std::max(8, atoi(getenv("ORC_SPMV_GRID"))) : kMaxGrid;  // (per launch: the switch test sweeps it)
+    const int cap = cfg().spmv_grid > 0 ? std::max(8, cfg().spmv_grid) : kMaxGrid;  // (ORC_SPMV_GRID: a test hook of the partial-sum bound)
     if (g > cap) g = cap;
     if (g >= 8) g = (g / 8) * 8;  // multiple of 8 for the XCD-aware walk
     return clamp_partials_grid(g);
@@ -229,7 +225,7 @@ int sell_from_csr_host(int64_t n, int64_t ncols, const int64_t *row_ptr, const i
     ORC_TRY(out.row_len.upload(row_len.data(), (size_t)n));
     ORC_TRY(out.col.upload(scol.data(), (size_t)padded));
     // narrow column image (SellDev): per slice and depth the smallest column among the rows that reach that depth + 16-bit offsets
-    static const bool narrow_on = !(getenv("ORC_SPMV_NARROW_COLS") && atoi(getenv("ORC_SPMV_NARROW_COLS")) == 0);
+    const bool narrow_on = cfg().spmv_narrow_cols;
     if (narrow_on && padded > 0) {
         std::vector<uint16_t> c16((size_t)padded, 0);
         std::vector<int32_t> cbase((size_t)(padded / 64), 0);
@@ -262,7 +258,7 @@ int sell_from_csr_host(int64_t n, int64_t ncols, const int64_t *row_ptr, const i
     // latency-bound either way — and 2.8 GB more: off.  End of the round, with the set-up's counters and launches out of the way, in the CONCURRENT
     // iteration: 788.3 / 780.9 -> 774.0 / 771.4 ms on one box — a row is 2 cache lines instead of 15, and the fine level's sweeps and cascades
     // stop taking ~150 GB per iteration from the products beside them.  ON by default; ORC_AMG_L0_MIRROR=0 leaves it out.)
-    static const bool l0_mirror = !(getenv("ORC_AMG_L0_MIRROR") && atoi(getenv("ORC_AMG_L0_MIRROR")) == 0);
+    const bool l0_mirror = cfg().amg_l0_mirror;
     if (l0_mirror && n > 0 && nnz > 0 && nnz < ((int64_t)1 << 31)) {
         std::vector<long long> rb((size_t)n_slices);
         std::vector<int32_t> ri((size_t)n), rc((size_t)nnz);
@@ -401,15 +397,14 @@ static int launch_spmv(const MatView &A_in, const double *x, const Epi &epi, dou
     MatView A = A_in;
     A.nt = matview_stream_nt(A);
     int g = spmv_grid(A.P.n_slices);
-    const int variant = ctx().spmv_variant;  // measurement hook (orc_debug_set_spmv_variant); 0 in production
-    const bool xwin = A.xw.lidx != nullptr && A.pk.ptr != nullptr && (variant == 0 || (variant >= 20 && variant <= 22));
+    const bool xwin = A.xw.lidx != nullptr && A.pk.ptr != nullptr;
     if (xwin) {
         // One workgroup per 256-row block.  The blocks differ in cost (row lengths; blocks without a window gather from global
         // memory), and a workgroup's share is fixed, so MORE workgroups than are resident balance better: r02's 5 per CU left the
         // chip at 10 of 20 waves per CU on average (profiles/r03_pmc_products.csv: SQ_WAVE_CYCLES / GRBM_GUI_ACTIVE; 4 are resident
         // with 32.7 KB of LDS and 92-96 VGPRs each); 8 per CU = the 2048 partial sums a product may write (kMaxPartials) measured
         // level 2: 251 -> 245 us, level 3: 289 -> 270 us.
-        const int per_cu = getenv("ORC_XWIN_WGS_PER_CU") ? std::max(1, atoi(getenv("ORC_XWIN_WGS_PER_CU"))) : 8;  // (per launch: the switch test sweeps it)
+        const int per_cu = cfg().xwin_wgs_per_cu;  // (8; a test hook sweeps it far past the partial-sum bound)
         static const int n_cu = [] {
             hipDeviceProp_t prop;
             int dev = 0;
@@ -421,13 +416,11 @@ static int launch_spmv(const MatView &A_in, const double *x, const Epi &epi, dou
         if (gb >= 8) gb = (gb / 8) * 8;
         g = (int)std::max<int64_t>(gb, 1);
     }
-    static const bool ragged_on = !(getenv("ORC_SPMV_RAGGED") && atoi(getenv("ORC_SPMV_RAGGED")) == 0);
-    const char *ov_env = A.halo ? getenv("ORC_HALO_OVERLAP") : nullptr;  // read per product: tests compare the two forms in one process
-    const bool overlap_on = !(ov_env && atoi(ov_env) == 0);
+    const bool overlap_on = cfg().halo_overlap;
     // Partitioned level-0 operator: the rows without a ghost column (a contiguous run of slices, HaloPlan::interior_*) are
     // multiplied on a second stream while the exchange travels; the rows along the cuts follow it on the library stream.
     HaloPlan *H = A.halo;
-    const bool uniform_kernel = variant == 0 && !A.pk.ptr && !(ragged_on && A.P.ragged == 1);
+    const bool uniform_kernel = !A.pk.ptr && A.P.ragged != 1;
     if (H && overlap_on && uniform_kernel && A.slice_hi < 0 && ctx().world > 1 && g >= 64 &&
         (int64_t)(H->interior_hi - H->interior_lo) * 2 >= (int64_t)A.P.n_slices) {
         const int g_b = std::max(8, (g / 8 / 8) * 8), g_i = std::max(8, ((g - 2 * g_b) / 8) * 8);
@@ -473,37 +466,15 @@ static int launch_spmv(const MatView &A_in, const double *x, const Epi &epi, dou
     if (A.P.n == 0) return ORC_OK;
     if (A.halo) ORC_TRY(A.halo->exchange(const_cast<double *>(x)));  // C1: refresh the ghost entries of x
     if (xwin) {
-        static const bool xwin_early = getenv("ORC_XWIN_EARLY") && atoi(getenv("ORC_XWIN_EARLY")) != 0;
-        if (variant == 21) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_xwin_k<Epi, 1>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
-        else if (variant == 22) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_xwin_k<Epi, 2>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
-        else if (A.xs.val && variant == 0 && !A.s1 && !A.s2) { hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_xsort_k<Epi, false>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags); g_xsort_products.fetch_add(1, std::memory_order_relaxed); }
-        else if (A.xs.val && variant == 0) { hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_xsort_k<Epi, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags); g_xsort_products.fetch_add(1, std::memory_order_relaxed); }
-        else if (!A.s1 && !A.s2 && xwin_early) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_xwin_k<Epi, 3, false>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
-        else if (!A.s1 && !A.s2 && A.nt) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_xwin_k<Epi, 0, false, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
-        else if (!A.s1 && !A.s2) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_xwin_k<Epi, 0, false>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
+        if (!A.s1 && !A.s2 && A.nt) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_xwin_k<Epi, false, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
+        else if (!A.s1 && !A.s2) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_xwin_k<Epi, false>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_xwin_k<Epi>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
         ORC_HIP(hipGetLastError());
         return ORC_OK;
     }
-    static const bool ragged_enabled = !(getenv("ORC_SPMV_RAGGED") && atoi(getenv("ORC_SPMV_RAGGED")) == 0);
-    if (variant >= 10) {  // pipelined kernels: 10 = production layout choice, 11 = padded, 12 = padded-predicated
-        if (variant == 10 && A.pk.ptr) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_pipe_k<Epi, kSpmvPacked>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
-        else if (variant == 12) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_pipe_k<Epi, kSpmvRagged>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_pipe_k<Epi, kSpmvPlain>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
-    } else if (variant != 0) {
-        if (variant == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi, kSpmvPlain>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
-        else if (variant == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi, kSpmvRagged>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
-        else if (variant == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_uniform_k<Epi, false>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
-        else if (variant == 9) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_uniform_k<Epi, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
-        else if (variant == 6) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi, kSpmvPlain, false, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
-        else if (variant == 7) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi, kSpmvRagged, false, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
-        else if (variant == 4 && A.pk.ptr) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi, kSpmvPacked, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
-        else if (variant == 5 || variant == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi, kSpmvPlain, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
-        else if (A.pk.ptr) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi, kSpmvPacked>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi, kSpmvPlain>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
-    } else if (A.pk.ptr)
+    if (A.pk.ptr)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi, kSpmvPacked>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
-    else if (ragged_enabled && A.P.ragged == 1)  // long ragged rows without a mirror: every slot clamped, nothing skipped
+    else if (A.P.ragged == 1)  // long ragged rows without a mirror: every slot clamped, nothing skipped
         hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_k<Epi, kSpmvRagged>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
     else if (A.persistent_pattern) {  // mesh-pattern matrices (level 0): wave-uniform loads, predicated gathers
         const bool narrow = A.P.col16 != nullptr, scaled = A.s1 || A.s2;
@@ -739,8 +710,7 @@ static int bicg_iteration(const MatView &A, double *x, const BicgWork &w, uint64
     const bool ref = reference_order(A);  // dot products in nalgebra's association (verification mode)
     // Single GPU, tree reductions: the three sums of the iteration are folded by the kernels that consume them (every
     // workgroup folds, workgroup 0 stores the scalar for the later kernels) instead of by one-workgroup launches in between.
-    static const bool fuse_env = !(getenv("ORC_BICG_FUSED_SUMS") && atoi(getenv("ORC_BICG_FUSED_SUMS")) == 0);
-    const bool fused = fuse_env && !ref && A.halo == nullptr;
+    const bool fused = !ref && A.halo == nullptr;
     ORC_TRY(launch_spmv(A, w.p, EpiStoreSum{w.nu}, w.partials, &g, skip));     // nu = A p, sum(nu)
     if (ref) ORC_TRY(dot_reference(nullptr, w.nu, n, w.scal + S_SUM_NU, skip));            // r_hat_0 . nu  (:257)
     else if (!fused) ORC_TRY(reduce_partials(w.partials, g, 1, w.scal + S_SUM_NU, A.halo != nullptr));
@@ -787,7 +757,7 @@ __global__ __launch_bounds__(kBlock) void scale_values_k(MatView A, double *__re
 }
 // from how many iterations on a solve materialises its scaled values (ORC_MATERIALIZE_SCALING=0: never)
 static inline bool materialize_scaling(uint64_t iteration_count) {
-    static const int min_its = getenv("ORC_MATERIALIZE_SCALING") ? atoi(getenv("ORC_MATERIALIZE_SCALING")) : 4;
+    const int min_its = cfg().materialize_scaling;
     return min_its > 0 && iteration_count >= (uint64_t)min_its;
 }
 
@@ -818,50 +788,15 @@ __global__ __launch_bounds__(kBlock) void scale_packed_k(MatView A, double *__re
     }
 }
 
-// the same over the length-sorted image (XSortDev): slot (block, wave, lane) owns entry k at its wave's running offset + lane
-__global__ __launch_bounds__(kBlock) void scale_xsort_k(MatView A, double *__restrict__ out) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t n_blocks = ((int64_t)A.P.n_slices + 3) >> 2;
-    for (int64_t b = blockIdx.x; b < n_blocks; b += gridDim.x) {
-        if (!A.xs.ok[b]) continue;  // packed order: its products read the packed mirror (scale_packed_k)
-        const int64_t slot = b * kXWinRows + threadIdx.x;
-        const int row = A.xs.perm[slot];
-        const int len = A.xs.slen[slot];
-        const double s1 = (A.s1 && row >= 0) ? A.s1[row] : 1.;
-        const double s2 = (A.s2 && row >= 0) ? A.s2[row] : 1.;
-        const int width = __builtin_amdgcn_readfirstlane(len);
-        int64_t off = A.xs.sptr[b * 4 + wave];
-        for (int k = 0; k < width; ++k) {
-            const bool in = k < len;
-            const int cnt = __popcll(__ballot(in));
-            if (in) {
-                double t = A.xs.val[off + lane];
-                if (A.s1) t = s1 * t;
-                if (A.s2) t = s2 * t;
-                out[off + lane] = t;
-            }
-            off += cnt;
-        }
-    }
-}
-
 int materialize_scaled_view(MatView &A, uint64_t iteration_count, Arena &arena) {
     if (!((A.s1 || A.s2) && A.P.n > 0 && materialize_scaling(iteration_count))) return ORC_OK;
     if (A.pk.ptr) {
         // levels with a packed mirror + LDS windows: their products stream pk.val only (launch_spmv: production variant)
-        if (!(A.xw.lidx && A.pk.total > 0 && ctx().spmv_variant == 0)) return ORC_OK;
+        if (!(A.xw.lidx && A.pk.total > 0)) return ORC_OK;
         double *scaled;
         ORC_TRY(arena.alloc((size_t)A.pk.total, &scaled));
         hipLaunchKernelGGL(scale_packed_k, dim3(spmv_grid(A.P.n_slices)), dim3(kBlock), 0, ctx().stream, A, scaled);
         ORC_HIP(hipGetLastError());
-        if (A.xs.val) {
-            double *scaled_sorted;
-            ORC_TRY(arena.alloc((size_t)A.pk.total, &scaled_sorted));
-            const int64_t n_blocks = ((int64_t)A.P.n_slices + 3) >> 2;
-            hipLaunchKernelGGL(scale_xsort_k, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(n_blocks, kMaxGrid))), dim3(kBlock), 0, ctx().stream, A, scaled_sorted);
-            ORC_HIP(hipGetLastError());
-            A.xs.val = scaled_sorted;
-        }
         A.pk.val = scaled;
         A.val = nullptr;  // the padded image keeps the unscaled values: nothing may read it through this view
         A.s1 = A.s2 = nullptr;
@@ -1012,8 +947,7 @@ static int launch_spmv3(const MatView3 &A_in, const double *x3, const Epi3 &epi,
     // multiplied on a second stream while the exchange of the interleaved iterate travels; the rows along the cuts follow it on the library
     // stream.  Same slice ranges, same grids and same layout of the partial sums as the one-system form: per system the same bits.
     HaloPlan *H = A.halo;
-    const char *ov_env = H ? getenv("ORC_HALO_OVERLAP") : nullptr;  // read per product: tests compare the two forms in one process
-    const bool overlap_on = !(ov_env && atoi(ov_env) == 0);
+    const bool overlap_on = cfg().halo_overlap;
     const bool plain_kernel = A.mesh_pattern && A.P.col16 != nullptr && !(A.s1 || A.s2);  // the variant the solves launch (materialised, narrow columns)
     if (H && overlap_on && plain_kernel && ctx().world > 1 && g >= 64 && (int64_t)(H->interior_hi - H->interior_lo) * 2 >= (int64_t)A.P.n_slices) {
         const int g_b = std::max(8, (g / 8 / 8) * 8), g_i = std::max(8, ((g - 2 * g_b) / 8) * 8);
@@ -1058,18 +992,8 @@ static int launch_spmv3(const MatView3 &A_in, const double *x3, const Epi3 &epi,
         return ORC_OK;
     }
     if (A.halo) ORC_TRY(A.halo->exchange_interleaved(const_cast<double *>(x3), 3));  // C1: the ghost entries of the three systems in one message per peer
-    // [r04] ORC_SPMV3_LAUNCH = W: W resident workgroups walk the one-system grid's shares (MatView3::vgrid, spmv3_uniform_k) and write ITS partial
-    // sums — the same bits (tests/test_gpu_triple.py).  OFF by default, measured on one box, interleaved: alone the product gains (2 048 workgroups
-    // 517 us, 1 024 walking 2 048 shares 499-507 us: 82 VGPRs let five workgroups live on a CU and the launch's last three per CU ran on a half-empty
-    // chip), but the SIMPLE iteration loses 14 ms (778-784 -> 792-799 ms): beside the set-up kernels of the other streams a product with half the
-    // wavefronts gets less of the memory system, and the lock-step solve is the critical path of that phase.  Read per launch: the tests compare the forms.
-    const int launch_env = getenv("ORC_SPMV3_LAUNCH") ? atoi(getenv("ORC_SPMV3_LAUNCH")) : 0;
-    int g_launch = g;
-    if (launch_env >= 8 && (launch_env & 7) == 0 && launch_env < g && (g & 7) == 0) { A.vgrid = g; g_launch = launch_env; }
-    static const int chunk = getenv("ORC_SPMV3_CHUNK") ? atoi(getenv("ORC_SPMV3_CHUNK")) : 4;
-    if (chunk == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 8>), dim3(g_launch), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
-    else if (chunk == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 2>), dim3(g_launch), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
-    else if (A.mesh_pattern) {
+    const int g_launch = g;
+    if (A.mesh_pattern) {
         const bool narrow = A.P.col16 != nullptr, scaled = A.s1 || A.s2;
         if (narrow && !scaled && A.nt) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4, true, true, false, true>), dim3(g_launch), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
         else if (narrow && !scaled) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4, true, true, false>), dim3(g_launch), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);

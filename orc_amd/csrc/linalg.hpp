@@ -70,23 +70,6 @@ struct XWinDev {
     const uint16_t *lidx = nullptr;  // [packed entries] window position of the entry's column
 };
 
-// Length-sorted image of the packed mirror [r03]: inside every block of kXWinRows rows the rows are sorted by length
-// (descending, ties by row) and dealt round-robin to the block's four wavefronts — sorted rank r sits in wave r & 3, lane r >> 2.
-// Within a wavefront the lengths then descend with the lane, so the lanes that still own an entry at depth k always form a
-// PREFIX: entry k of the wavefront's rows sit back to back at sptr[slice] + sum_{k' < k} cnt(k') + lane.  The product's address
-// is a running scalar offset plus the lane — no v_mbcnt rank, no clamping — and the four wavefronts of a block carry the same
-// share of its entries (they meet at a barrier).  Same entries, same per-row order, same sums per row; rows are handed back to
-// their own index through `perm`.  A block shares its entry range with the packed mirror ([pk.ptr[4 b], pk.ptr[4 b + 4])).
-constexpr int kXSortMaxLen = 512;  // longest row a sorted block may hold; a block with a longer one keeps the packed order (ok = 0)
-struct XSortDev {
-    const int32_t *perm = nullptr;        // [n_blocks * kXWinRows] row of slot (block, wave, lane), -1 = none
-    const int32_t *slen = nullptr;        // [n_blocks * kXWinRows] its length
-    const int64_t *sptr = nullptr;        // [n_blocks * 4] first entry of every wavefront's rows
-    const double *val = nullptr;          // [pk.total]
-    const uint16_t *lidx = nullptr;       // [pk.total] window position of the entry's column
-    const unsigned char *ok = nullptr;    // [n_blocks] 1 = the block is stored in sorted order
-};
-
 // Row-contiguous mirror (the Galerkin product's scratch rows, kept alive with their level): entry k of row r sits at
 // slice_base[r >> 6] + intra_off[r] + k.  The set-up kernels that walk single, scattered rows (aggregation rounds) read
 // a row's columns and values from two or three cache lines here instead of one line per entry in the SELL image.
@@ -108,7 +91,6 @@ struct MatView {
     int nt = 0;             // set by the launch: the matrix streams are loaded with the non-temporal hint (launch_spmv)
     PackedDev pk;           // optional packed mirror (same pattern, same values): what the product streams when present
     XWinDev xw;             // optional LDS x-window description of the packed mirror
-    XSortDev xs;            // optional length-sorted image of the packed mirror (what the window product streams when present)
     RowsDev rows;           // optional row-contiguous mirror for single-row walks
     bool symmetric = true;  // structural symmetry of the pattern (aggregation fast path)
     bool persistent_pattern = false;  // the pattern outlives the solve (mesh pattern): derived data such as a colouring may be cached
@@ -139,7 +121,6 @@ struct MatView3 {
     HaloPlan *halo = nullptr;
     // the pieces of a product that overlaps its halo exchange (MatView::slice_lo / slice_hi / part_stride / part_base)
     int32_t slice_lo = 0, slice_hi = -1, part_stride = 0, part_base = 0;
-    int32_t vgrid = 0;  // > 0: the launch walks the shares of a grid of this many workgroups and writes ITS partial sums (launch_spmv3 sets it)
 };
 
 // Owning pattern (built on the host from CSR, e.g. the mesh pattern or a user matrix).
@@ -169,14 +150,6 @@ int sell_import_values(const SellMatrix &m, const double *csr_vals_dev, double *
 int sell_export_values(const SellMatrix &m, const double *sell_vals_dev, double *csr_vals_dev);
 int sell_rows_values_dev(const SellDev &P, const double *sell_vals_dev, double *rows_vals_dev);  // -> the value half of the level-0 row mirror
 
-// Warm start of the AMG set-up: the greedy pairing is a fixed point that the device reaches by iteration from ANY
-// initial state, and a SIMPLE run changes its matrices slowly, so each (equation, level) keeps its last pairing as
-// the next solve's starting guess.  The result is the same exact fixed point; only the number of rounds changes.
-struct AmgCache {
-    DevBuf<int> choice[8];  // per level: partner of every fine row of that level
-    int64_t size[8] = {0};
-};
-
 // Optional second stream of a solve (Multigrid arm): the hierarchy set-up of level l+1 — host-synchronised rounds,
 // latency-bound — needs only the level-l matrix, while the smoothing solve of level l — 100 products, bandwidth-bound,
 // no host interaction — needs the matrix and the restricted residual.  Set-up work stays on ctx().stream, everything
@@ -197,7 +170,6 @@ struct AmgHierarchy {
         double *val = nullptr;
         PackedDev pk;
         XWinDev xw;
-        XSortDev xs;
         RowsDev rows;
         int64_t n = 0, padded = 0;
         int rounds = 0;
@@ -252,7 +224,6 @@ struct SiblingPairing {
 };
 
 struct SolveStats {
-    AmgCache *cache = nullptr;  // optional, owned by the caller (one per equation)
     SiblingPairing *sibling = nullptr;  // optional, owned by the caller (shared by the momentum systems of an iteration)
     int sibling_role = 0;               // 1 = leader (publishes), 2 = follower (starts from the leader's pairing)
     SolveSide *side = nullptr;  // optional, owned by the caller

@@ -315,10 +315,9 @@ __global__ __launch_bounds__(kBlock) void spmv3_uniform_k(MatView3 A, const doub
     const Vec3d *__restrict__ xv3 = reinterpret_cast<const Vec3d *>(x3);
     const Vec3d *__restrict__ s1v = reinterpret_cast<const Vec3d *>(A.s1);
     const Vec3d *__restrict__ s2v = reinterpret_cast<const Vec3d *>(A.s2);
-    // [r04] vgrid: the grid whose shares and partial sums this launch produces (launch_spmv3, ORC_SPMV3_LAUNCH: fewer, resident workgroups walk the
-    // shares of the one-system product's grid, whose partial sums the three-system product must reproduce bit for bit — same rows per share, same
-    // order, same sums; measured, off by default: see launch_spmv3).
-    const int vgrid = A.vgrid > 0 ? A.vgrid : (int)gridDim.x;
+    // (the walk is written for a VIRTUAL grid — r04 measured fewer, resident workgroups walking the one-system grid's shares: the product
+    // alone gained 3 %, the iteration lost 14 ms, HISTORY.md — and runs with the launch's own grid: one share per workgroup)
+    const int vgrid = (int)gridDim.x;
     for (int vb = blockIdx.x; vb < vgrid; vb += gridDim.x) {
     double red[3][2] = {{0., 0.}, {0., 0.}, {0., 0.}};
     SliceWalk w(A.slice_hi >= 0 ? A.slice_hi : A.P.n_slices, A.slice_lo, vb, vgrid);  // a slice range when the product overlaps its halo exchange (launch_spmv3)
@@ -430,73 +429,12 @@ struct SpmvSliceMeta {
     }
 };
 
-template <class Epi, int kLayout = kSpmvPlain>
-__global__ __launch_bounds__(kBlock) void spmv_pipe_k(MatView A, const double *__restrict__ x, Epi epi, double *__restrict__ partials,
-                                                      const double *__restrict__ skip_flags) {
-    __shared__ double lds[8];
-    if (skip_flags && (skip_flags[0] != 0. || skip_flags[1] != 0.)) return;
-    const int lane = threadIdx.x & 63;
-    double r0 = 0., r1 = 0.;
-    SliceWalk w(A.P.n_slices);
-    int64_t slice = w.begin;
-    if (slice < w.end) {
-        SpmvSliceMeta<kLayout> cur;
-        cur.load(A, slice, lane);
-        int k0 = 0;
-        int c[8];
-        double v[8];
-        cur.issue(A, k0, lane, c, v);
-        double acc = 0.;
-        while (true) {
-            const bool same = k0 + 8 < cur.width;
-            const int64_t nslice = same ? slice : slice + w.step;
-            const bool has_next = same || nslice < w.end;
-            const int nk0 = same ? k0 + 8 : 0;
-            SpmvSliceMeta<kLayout> nxt = cur;
-            if (!same && has_next) nxt.load(A, nslice, lane);
-            double xv[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) xv[u] = x[c[u]];      // gathers of the current chunk
-            int cn[8];
-            double vn[8];
-            if (has_next) nxt.issue(A, nk0, lane, cn, vn);      // prefetch: stays in flight across the gather wait
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                double t = v[u];
-                if (A.s1) t = cur.s1 * t;
-                if (A.s2) t = cur.s2 * t;
-                const double next = acc + t * xv[u];
-                acc = (k0 + u < cur.len) ? next : acc;
-            }
-            if (!same) {
-                if (cur.live) epi.apply(cur.row, acc, r0, r1);
-                acc = 0.;
-            }
-            if (!has_next) break;
-            cur = nxt;
-            slice = nslice;
-            k0 = nk0;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { c[u] = cn[u]; v[u] = vn[u]; }
-        }
-    }
-    if (Epi::kReductions > 0) {
-        double t = block_sum(r0, lds);
-        if (threadIdx.x == 0) partials[blockIdx.x] = t;
-    }
-    if (Epi::kReductions > 1) {
-        double t = block_sum(r1, lds);
-        if (threadIdx.x == 0) partials[gridDim.x + blockIdx.x] = t;
-    }
-}
-
 // Product on the packed mirror with LDS-staged x windows (XWinDev): one workgroup per block of 256 rows, its 4 waves on
 // the block's 4 slices.  Workgroups b and b + 8 share an XCD, so XCD g walks a contiguous eighth of the blocks.
-// kDebug (measurement only): 1 = window loads skipped, 2 = stream phase skipped, 3 = first chunk of the stream requested before the window
 // kScaled = false: the view carries no row scaling (a smoothing solve has materialised its scaled values, materialize_scaled_view):
 // the two scaling multiplications per entry and their selects are not compiled in — the stream loop of this kernel is bound by
 // instruction issue as much as by memory (39 vector instructions per entry and wavefront, profiles/r03_pmc_products.csv)
-template <class Epi, int kDebug = 0, bool kScaled = true, bool kNT = false>
+template <class Epi, bool kScaled = true, bool kNT = false>
 __global__ __launch_bounds__(kBlock) void spmv_xwin_k(MatView A, const double *__restrict__ x, Epi epi, double *__restrict__ partials,
                                                       const double *__restrict__ skip_flags) {
     __shared__ double lds[8];
@@ -517,10 +455,10 @@ __global__ __launch_bounds__(kBlock) void spmv_xwin_k(MatView A, const double *_
     }
     for (int64_t b = b_begin; b < b_end; b += b_step) {
         const int ws = A.xw.wsize[b];  // workgroup-uniform
-        // the slice's own stream does not depend on the window: its descriptors — and with kDebug == 3 (experiment,
-        // ORC_XWIN_EARLY=1) its first chunk — are requested before the window is loaded
+        // the slice's own stream does not depend on the window: its descriptors are requested before the window is loaded (requesting its
+        // first chunk there too was measured: neutral)
         const int64_t slice = b * 4 + wave;
-        const bool has_slice = slice < A.P.n_slices && kDebug != 2;
+        const bool has_slice = slice < A.P.n_slices;
         const int64_t row = slice * 64 + lane;
         const bool live = has_slice && row < A.P.n;
         int width = 0, len = 0;
@@ -551,8 +489,7 @@ __global__ __launch_bounds__(kBlock) void spmv_xwin_k(MatView A, const double *_
                 off32 += __popcll(m);
             }
         };
-        if (kDebug == 3 && has_slice && ws >= 0 && width > 0) issue(0, c, v);
-        if (ws > 0 && kDebug != 1) {
+        if (ws > 0) {
             // window -> LDS: all column loads of a pass are issued before the x gathers, those before the LDS writes
             // (a rolled loop would cost two dependent round trips per element)
             const int32_t *wc = A.xw.wcol + b * kXWinCap;
@@ -598,7 +535,7 @@ __global__ __launch_bounds__(kBlock) void spmv_xwin_k(MatView A, const double *_
                         acc = (k0 + u < len) ? next : acc;
                     }
                 };
-                if (kDebug != 3 && width > 0) issue(0, c, v);
+                if (width > 0) issue(0, c, v);
                 int k0 = 0;
                 for (; k0 + 8 < width; k0 += 16) {  // at the top: chunk k0 is on its way into (c, v)
                     issue(k0 + 8, cn, vn);
@@ -634,166 +571,6 @@ __global__ __launch_bounds__(kBlock) void spmv_xwin_k(MatView A, const double *_
                 }
             }
             if (live) epi.apply(row, acc, r0, r1);
-        }
-        __syncthreads();  // the next block overwrites the window
-    }
-    if (Epi::kReductions > 0) {
-        double t = block_sum(r0, lds);
-        if (threadIdx.x == 0) partials[blockIdx.x] = t;
-    }
-    if (Epi::kReductions > 1) {
-        double t = block_sum(r1, lds);
-        if (threadIdx.x == 0) partials[gridDim.x + blockIdx.x] = t;
-    }
-}
-
-// Product on the length-sorted image (XSortDev) with LDS-staged x windows: spmv_xwin_k's block walk and window load, but the
-// stream phase addresses its entries as "running scalar offset + lane".  A wavefront's lengths descend with the lane, so
-//   * depths below the SHORTEST row (lane 63) are owned by all 64 lanes: entry (k, lane) at base + 64 k + lane — eight loads per
-//     array at compile-time offsets from one chunk base, no masks;
-//   * above it the active lanes form a prefix of cnt(k) = popcount(k < len) lanes: one wave-uniform count per depth.
-// Blocks without a window (wsize < 0) or too long for the sort tables (ok = 0) take spmv_xwin_k's packed path.
-template <class Epi, bool kScaled = true>
-__global__ __launch_bounds__(kBlock) void spmv_xsort_k(MatView A, const double *__restrict__ x, Epi epi, double *__restrict__ partials,
-                                                       const double *__restrict__ skip_flags) {
-    __shared__ double lds[8];
-    __shared__ double xs[kXWinCap];
-    if (skip_flags && (skip_flags[0] != 0. || skip_flags[1] != 0.)) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double r0 = 0., r1 = 0.;
-    const int64_t n_blocks = ((int64_t)A.P.n_slices + 3) >> 2;
-    int64_t b_begin, b_end, b_step;
-    if ((gridDim.x & 7) == 0 && gridDim.x >= 8) {
-        const int xcd = blockIdx.x & 7, bl = blockIdx.x >> 3, nb = gridDim.x >> 3;
-        const int64_t per = (n_blocks + 7) / 8;
-        b_begin = (int64_t)xcd * per + bl;
-        b_end = (int64_t)(xcd + 1) * per < n_blocks ? (int64_t)(xcd + 1) * per : n_blocks;
-        b_step = nb;
-    } else {
-        b_begin = blockIdx.x; b_end = n_blocks; b_step = gridDim.x;
-    }
-    for (int64_t b = b_begin; b < b_end; b += b_step) {
-        const int ws = A.xw.wsize[b];  // workgroup-uniform
-        const bool sorted = ws >= 0 && A.xs.ok[b] != 0;
-        if (ws > 0) {
-            const int32_t *wc = A.xw.wcol + b * kXWinCap;
-            for (int j0 = 0; j0 < ws; j0 += 8 * kBlock) {
-                int wj[8];
-                double xw[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int j = j0 + q * kBlock + (int)threadIdx.x;
-                    wj[q] = wc[j < ws ? j : 0];
-                }
-#pragma unroll
-                for (int q = 0; q < 8; ++q) xw[q] = x[wj[q]];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int j = j0 + q * kBlock + (int)threadIdx.x;
-                    if (j < ws) xs[j] = xw[q];
-                }
-            }
-        }
-        __syncthreads();
-        if (sorted) {
-            const int64_t slot = b * kXWinRows + threadIdx.x;
-            const int row = A.xs.perm[slot];
-            const int len = A.xs.slen[slot];
-            const double s1 = (kScaled && A.s1 && row >= 0) ? A.s1[row] : 1.;
-            const double s2 = (kScaled && A.s2 && row >= 0) ? A.s2[row] : 1.;
-            const int width = __builtin_amdgcn_readfirstlane(len);     // lane 0 holds the longest row
-            const int minlen = __builtin_amdgcn_readlane(len, 63);     // lane 63 the shortest
-            const int64_t sbase = A.xs.sptr[b * 4 + wave];
-            const double *__restrict__ vb = A.xs.val + sbase;
-            const unsigned short *__restrict__ lb = A.xs.lidx + sbase;
-            double acc = 0.;
-            int k = 0;
-            // depths owned by every lane
-            for (; k + 8 <= minlen; k += 8) {
-                double v[8];
-                int li[8];
-                const int p0 = k * 64 + lane;
-#pragma unroll
-                for (int u = 0; u < 8; ++u) { v[u] = vb[p0 + u * 64]; li[u] = (int)lb[p0 + u * 64]; }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    double t = v[u];
-                    if (kScaled && A.s1) t = s1 * t;
-                    if (kScaled && A.s2) t = s2 * t;
-                    acc += t * xs[li[u]];
-                }
-            }
-            for (; k < minlen; ++k) {
-                double t = vb[k * 64 + lane];
-                const int li = (int)lb[k * 64 + lane];
-                if (kScaled && A.s1) t = s1 * t;
-                if (kScaled && A.s2) t = s2 * t;
-                acc += t * xs[li];
-            }
-            // prefix depths: four at a time, every load clamped to an entry that is being read anyway
-            int off = minlen * 64;
-            for (; k < width; k += 4) {
-                double v[4];
-                int li[4];
-                bool in[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    in[u] = k + u < len;
-                    const int cnt = __popcll(__ballot(in[u]));
-                    const int p = in[u] ? off + lane : (cnt > 0 ? off : off - 1);
-                    v[u] = vb[p];
-                    li[u] = (int)lb[p];
-                    off += cnt;
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    double t = v[u];
-                    if (kScaled && A.s1) t = s1 * t;
-                    if (kScaled && A.s2) t = s2 * t;
-                    const double next = acc + t * xs[li[u]];
-                    acc = in[u] ? next : acc;
-                }
-            }
-            if (row >= 0) epi.apply(row, acc, r0, r1);
-        } else {
-            // packed order (spmv_xwin_k): blocks without a window gather from global memory
-            const int64_t slice = b * 4 + wave;
-            if (slice < A.P.n_slices) {
-                const int64_t row = slice * 64 + lane;
-                const int64_t base = A.P.slice_ptr[slice];
-                const int width = (int)((A.P.slice_ptr[slice + 1] - base) >> 6);
-                const bool live = row < A.P.n;
-                const int len = live ? A.P.row_len[row] : 0;
-                const double s1 = (kScaled && A.s1 && live) ? A.s1[row] : 1.;
-                const double s2 = (kScaled && A.s2 && live) ? A.s2[row] : 1.;
-                double acc = 0.;
-                int64_t pk_off = A.pk.ptr[slice];
-                for (int k0 = 0; k0 < width; k0 += 8) {
-                    int c[8];
-                    double v[8], xv[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const bool in = k0 + u < len;
-                        const unsigned long long m = __ballot(in);
-                        const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                        const int64_t p = in ? pk_off + rank : (m != 0ull ? pk_off : pk_off - 1);
-                        c[u] = ws >= 0 ? (int)A.xw.lidx[p] : A.pk.col[p];
-                        v[u] = A.pk.val[p];
-                        pk_off += __popcll(m);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) xv[u] = ws >= 0 ? xs[c[u]] : x[c[u]];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        double t = v[u];
-                        if (kScaled && A.s1) t = s1 * t;
-                        if (kScaled && A.s2) t = s2 * t;
-                        const double next = acc + t * xv[u];
-                        acc = (k0 + u < len) ? next : acc;
-                    }
-                }
-                if (live) epi.apply(row, acc, r0, r1);
-            }
         }
         __syncthreads();  // the next block overwrites the window
     }

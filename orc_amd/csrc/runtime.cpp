@@ -4,9 +4,9 @@
 #include <mutex>
 
 #include "common.hpp"
+#include "config.hpp"
 
 namespace orc {
-long long debug_xsort_products();  // linalg.hip
 void debug_amg_certification(long long out[2], bool reset);  // amg.hip
 long long debug_shared_galerkin(bool reset);                   // amg.hip
 int debug_xwin_counters(long long out[3], bool reset);       // amg.hip
@@ -29,6 +29,59 @@ int set_error(int code, const char *fmt, ...) {
     va_end(ap);
     ctx().last_error = buf;
     return code;
+}
+
+
+// ------------------------------------------------------------------ environment switches (config.hpp)
+static Config g_cfg;
+static std::mutex g_cfg_mu;
+static bool g_cfg_loaded = false;
+static int env_int(const char *name, int dflt) { const char *e = getenv(name); return (e && *e) ? atoi(e) : dflt; }
+static bool env_on(const char *name, bool dflt) { const char *e = getenv(name); return (e && *e) ? atoi(e) != 0 : dflt; }
+static bool env_set(const char *name) { return getenv(name) != nullptr; }
+static std::string env_str(const char *name) { const char *e = getenv(name); return e ? std::string(e) : std::string(); }
+
+void config_reload() {
+    Config c;
+    c.triple_momentum = env_on("ORC_TRIPLE_MOMENTUM", true);
+    c.concurrent_momentum = env_on("ORC_CONCURRENT_MOMENTUM", true);
+    c.two_stream_multigrid = env_on("ORC_TWO_STREAM_MULTIGRID", true);
+    c.early_p_hierarchy = env_on("ORC_EARLY_P_HIERARCHY", true);
+    c.stream_priorities = env_int("ORC_STREAM_PRIORITIES", 3);
+    c.halo_overlap = env_on("ORC_HALO_OVERLAP", true);
+    c.amg_da = env_on("ORC_AMG_DA", true);
+    c.amg_da_steps = std::max(1, env_int("ORC_AMG_DA_STEPS", 1 << 22));
+    c.amg_da_group = env_int("ORC_AMG_DA_GROUP", 0);
+    c.amg_sibling = env_on("ORC_AMG_SIBLING", true);
+    c.amg_shared_galerkin = env_on("ORC_AMG_SHARED_GALERKIN", true);
+    c.amg_l0_mirror = env_on("ORC_AMG_L0_MIRROR", true);
+    c.galerkin_groups = env_str("ORC_GALERKIN_GROUPS");
+    c.spmv_nt = env_int("ORC_SPMV_NT", -1);
+    c.spmv_narrow_cols = env_on("ORC_SPMV_NARROW_COLS", true);
+    c.materialize_scaling = env_int("ORC_MATERIALIZE_SCALING", 4);
+    c.spmv_xwin_min_nnz = env_int("ORC_SPMV_XWIN_MIN_NNZ", 24);
+    c.spmv_grid = env_int("ORC_SPMV_GRID", 0);
+    c.xwin_wgs_per_cu = std::max(1, env_int("ORC_XWIN_WGS_PER_CU", 8));
+    c.xwin_cap = env_int("ORC_XWIN_CAP", 0);
+    c.xwin_bitwords = env_int("ORC_XWIN_BITWORDS", 0);
+    c.xwin_small_bitwords = env_int("ORC_XWIN_SMALL_BITWORDS", 0);
+    c.gs_slotspace = env_on("ORC_GS_SLOTSPACE", true);
+    c.trace = env_set("ORC_DEBUG_TRACE");
+    c.amg_trace = env_set("ORC_AMG_TRACE");
+    c.arena_trace = env_set("ORC_ARENA_TRACE");
+    c.debug_nan = env_set("ORC_DEBUG_NAN");
+    c.debug_xwin = env_set("ORC_DEBUG_XWIN") || env_on("ORC_XWIN_STATS", false);
+    c.debug_sync = env_int("ORC_DEBUG_SYNC", 0);
+    c.inject_lane_error = env_str("ORC_DEBUG_INJECT_LANE_ERROR");
+    c.keep_priority_classes = env_on("ORC_DEBUG_KEEP_PRIORITY_CLASSES", false);
+    std::lock_guard<std::mutex> lk(g_cfg_mu);
+    g_cfg = c;
+    g_cfg_loaded = true;
+}
+
+const Config &cfg() {
+    if (!g_cfg_loaded) config_reload();  // (before orc_init: host-only entries)
+    return g_cfg;
 }
 
 // ------------------------------------------------------------------ streams
@@ -66,10 +119,8 @@ int stream_create(hipStream_t *out, int role, int lane, const char *name) {
     // ORC_STREAM_PRIORITIES: 3 (default) = solve streams above set-up streams — since the round-2 set-up rework the solves are the critical
     // path of the momentum phase (0.863-0.879 s per iteration against 0.903-0.909 s with 2 = set-up above solve and 0.926-0.957 s with 0 =
     // no classes, r02); 1 = one class per lane
-    static const int prio_env = getenv("ORC_STREAM_PRIORITIES") ? atoi(getenv("ORC_STREAM_PRIORITIES")) : 3;
     // ORC_DEBUG_KEEP_PRIORITY_CLASSES=1 (scripts/gpu_r05_b.sh only): the r04 behaviour — classes even when ranks share the card — to reproduce the stall
-    static const bool keep_classes = getenv("ORC_DEBUG_KEEP_PRIORITY_CLASSES") && atoi(getenv("ORC_DEBUG_KEEP_PRIORITY_CLASSES")) != 0;
-    const int prio_mode = (role == kPlainStream || (device_shared_between_ranks() && !keep_classes)) ? 0 : prio_env;
+    const int prio_mode = (role == kPlainStream || (device_shared_between_ranks() && !cfg().keep_priority_classes)) ? 0 : cfg().stream_priorities;
     int least = 0, greatest = 0, prio = 0;
     bool with_prio = false;
     if (prio_mode != 0 && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) {
@@ -102,8 +153,7 @@ int ensure_init() {
 }
 
 Arena::~Arena() {
-    static const bool trace = getenv("ORC_ARENA_TRACE") != nullptr;
-    if (trace && !chunks_.empty())
+    if (cfg().arena_trace && !chunks_.empty())
         fprintf(stderr, "[orc arena %p] %zu chunk(s), reserved %.2f GB, high water %.2f GB\n", (void *)this, chunks_.size(), (double)reserved() / 1e9, (double)high_ / 1e9);
     for (auto &c : chunks_)
         if (c.p) (void)hipFree(c.p);
@@ -113,7 +163,6 @@ int Arena::reset() {
     cur_ = 0;
     off_ = 0;
     live_ = 0;
-    static const bool compact = !(getenv("ORC_ARENA_COMPACT") && atoi(getenv("ORC_ARENA_COMPACT")) == 0);
     // the most any cycle since the last compaction needed: an arena that serves solves of very different footprints in turn
     // (u, v, w, p' on one stream) must be sized for the largest, not for whichever came last — or it would shrink after a
     // small solve, spill into extra chunks in the next large one and compact again, freeing and allocating (hipFree
@@ -121,12 +170,11 @@ int Arena::reset() {
     peak_ = std::max(peak_, high_);
     const size_t used = peak_;
     high_ = 0;
-    if (!compact || chunks_.empty() || used == 0) return ORC_OK;
+    if (chunks_.empty() || used == 0) return ORC_OK;
     // a single chunk is never shrunk: only a fragmented reservation (several chunks) is folded into one
     if (chunks_.size() == 1) return ORC_OK;
     const size_t want = used + used / 16 + ((size_t)16 << 20);  // what the largest cycle needed, plus slack for the next one's drift
-    static const bool trace = getenv("ORC_ARENA_TRACE") != nullptr;
-    if (trace) fprintf(stderr, "[orc arena %p] compacting %zu chunk(s), reserved %.2f GB -> %.2f GB\n", (void *)this, chunks_.size(), (double)reserved() / 1e9, (double)want / 1e9);
+    if (cfg().arena_trace) fprintf(stderr, "[orc arena %p] compacting %zu chunk(s), reserved %.2f GB -> %.2f GB\n", (void *)this, chunks_.size(), (double)reserved() / 1e9, (double)want / 1e9);
     for (auto &c : chunks_)
         if (c.p) (void)hipFree(c.p);
     chunks_.clear();
@@ -185,6 +233,7 @@ int orc_init(int device_ordinal) {
     orc::Ctx &c = orc::ctx();
     int n = orc_device_count();
     if (n <= 0) return orc::set_error(ORC_ERR_NO_DEVICE, "no HIP device visible: liborc_amd has no CPU fallback");
+    if (!c.inited) orc::config_reload();  // the environment switches: read here and by orc_reload_environment(), nowhere else
     if (c.inited && (device_ordinal < 0 || device_ordinal == c.device)) return ORC_OK;
     if (device_ordinal < 0) device_ordinal = 0;
     if (device_ordinal >= n) return orc::set_error(ORC_ERR_BAD_ARGUMENT, "device %d out of range (%d visible)", device_ordinal, n);
@@ -295,13 +344,7 @@ int64_t orc_breakdown_guard_events(int reset) {
     return h;
 }
 
-int orc_debug_set_spmv_variant(int variant) {
-    orc::ctx().spmv_variant = variant;
-    return ORC_OK;
-}
-
 long long orc_debug_halo_overlaps(void) { return orc::ctx().halo_overlaps; }
-long long orc_debug_xsort_products(void) { return orc::debug_xsort_products(); }
 int orc_debug_clamp_partials_grid(long long requested) { return orc::clamp_partials_grid(requested); }
 int orc_debug_max_partials(void) { return orc::kMaxPartials; }
 int orc_debug_amg_certification(long long out[2], int reset) {
@@ -335,6 +378,11 @@ int orc_debug_stream_report(char *buf, int cap) {
         off += w;
     }
     return busy;
+}
+
+int orc_reload_environment(void) {
+    orc::config_reload();
+    return ORC_OK;
 }
 
 int orc_profile_enable(int on) {

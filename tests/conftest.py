@@ -45,6 +45,30 @@ def mesh_path(tmp_path_factory):
     return get
 
 
+@pytest.fixture
+def monkeypatch():
+    """pytest's monkeypatch, whose setenv / delenv also tell liborc_amd: the library reads its ORC_* switches ONCE (orc_init) and again only when
+    told (orc_reload_environment, orc_amd/csrc/config.hpp) — nothing on its hot path calls getenv.  Undone (and reloaded) at the end of the test."""
+    def reload():
+        m = sys.modules.get("orc_amd._lib")
+        if m is not None and getattr(m, "_lib", None) is not None:
+            m._lib.orc_reload_environment()
+
+    class Patch(pytest.MonkeyPatch):
+        def setenv(self, name, value, prepend=None):
+            super().setenv(name, value, prepend)
+            reload()
+
+        def delenv(self, name, raising=True):
+            super().delenv(name, raising)
+            reload()
+
+    mp = Patch()
+    yield mp
+    mp.undo()
+    reload()
+
+
 @pytest.fixture(scope="session")
 def gpu():
     import orc_amd

@@ -442,6 +442,7 @@ def gpu_triple_partitioned_checks(rank, world):
             for mode in ("triple", "single"):
                 os.environ["ORC_TRIPLE_MOMENTUM"] = "1" if mode == "triple" else "0"
                 os.environ["ORC_HALO_OVERLAP"] = overlap
+                orc_amd.reload_environment()  # (the library reads its switches once: config.hpp)
                 try:
                     sol = Solver(parallel.PartitionedMesh(a, halo), s, 1000.0, 1e-3)
                     sol.set_fields(*[f[gids] for f in ug])
@@ -454,6 +455,7 @@ def gpu_triple_partitioned_checks(rank, world):
                     out[mode] = (st1, st2, sol.get_fields())
                 finally:
                     del os.environ["ORC_TRIPLE_MOMENTUM"], os.environ["ORC_HALO_OVERLAP"]
+                    orc_amd.reload_environment()  # (the library reads its switches once: config.hpp)
             same = all(np.array_equal(x[:n_own].view(np.uint64), y[:n_own].view(np.uint64)) for x, y in zip(out["triple"][2], out["single"][2]))
             finite = all(np.isfinite(x[:n_own]).all() for x in out["triple"][2])
             ratio = coll["triple"] / max(coll["single"], 1)
@@ -495,10 +497,12 @@ def gpu_lane_error_checks(rank, world):
     for bad_rank in range(world):
         for lane in range(3):
             os.environ["ORC_DEBUG_INJECT_LANE_ERROR"] = "%d:%d" % (bad_rank, lane)
+            orc_amd.reload_environment()  # (the library reads its switches once: config.hpp)
             try:
                 st = run()
             finally:
                 del os.environ["ORC_DEBUG_INJECT_LANE_ERROR"]
+                orc_amd.reload_environment()  # (the library reads its switches once: config.hpp)
             sts = [None] * world
             dist.all_gather_object(sts, int(st))
             good = all(x == sts[0] for x in sts) and sts[0] != 0
@@ -611,6 +615,7 @@ def gpu_overlap_checks(rank, world):
         for form in ("overlapped", "plain"):
             if form == "plain":
                 os.environ["ORC_HALO_OVERLAP"] = "0"
+                orc_amd.reload_environment()  # (the library reads its switches once: config.hpp)
             try:
                 before = L.orc_debug_halo_overlaps()
                 pm = parallel.PartitionedMesh(a, halo)
@@ -620,6 +625,7 @@ def gpu_overlap_checks(rank, world):
                 runs[form] = (st, sol.get_fields(), L.orc_debug_halo_overlaps() - before)
             finally:
                 os.environ.pop("ORC_HALO_OVERLAP", None)
+                orc_amd.reload_environment()  # (the library reads its switches once: config.hpp)
         st, loc, overlapped = runs["overlapped"]
         st_p, loc_p, overlapped_p = runs["plain"]
         gm = Mesh(ag)
@@ -686,6 +692,7 @@ def gpu_checks(rank, world, a, halo, gids, ag):
             os.environ["ORC_CONCURRENT_MOMENTUM"] = "0"
             os.environ["ORC_EARLY_P_HIERARCHY"] = "0"
             os.environ["ORC_TWO_STREAM_MULTIGRID"] = "0"
+            orc_amd.reload_environment()  # (the library reads its switches once: config.hpp)
             try:
                 seq = Solver(pm, s, 1000.0, 1e-3)
                 seq.set_fields(*[f[gids] for f in ug])
@@ -694,6 +701,7 @@ def gpu_checks(rank, world, a, halo, gids, ag):
             finally:
                 for k in ("ORC_CONCURRENT_MOMENTUM", "ORC_EARLY_P_HIERARCHY", "ORC_TWO_STREAM_MULTIGRID"):
                     del os.environ[k]
+                    orc_amd.reload_environment()  # (the library reads its switches once: config.hpp)
             flags = [None] * world
             dist.all_gather_object(flags, bool(same))
             if rank == 0:

@@ -17,8 +17,9 @@ pytestmark = pytest.mark.gpu
 
 MULTIGRID, BICGSTAB = 2, 3
 SWEEP = [("ORC_XWIN_WGS_PER_CU", ["1", "3", "8", "12", "40", "100000"]),
-         ("ORC_SPMV_GRID", ["8", "24", "1024", "2048", "4096", "100000000"]),
-         ("ORC_AMG_CHASE_GRID", ["1", "8", "2048", "4096", "100000000"])]
+         ("ORC_SPMV_GRID", ["8", "24", "1024", "2048", "4096", "100000000"])]
+# (r04 swept ORC_AMG_CHASE_GRID too: the cascades whose grid it sized are gone with r05's pairing by deferred acceptance, whose chain kernel
+# writes no partial sums and is launched with kMaxGrid workgroups)
 
 
 def _system():

@@ -50,21 +50,13 @@ def test_aggregation_and_galerkin_bit_exact(gpu, oracle, shape):
     assert rounds >= 1
 
 
-@pytest.mark.parametrize("env", [{"ORC_AMG_DA": "0"}, {"ORC_AMG_DA_STEPS": "3"}, {"ORC_AMG_DA": "0", "ORC_AMG_CHASE": "0"}, {"ORC_AMG_DA": "0", "ORC_AMG_CHASE_STEPS": "2", "ORC_AMG_CHASE_LAUNCHES": "2"},
-                                 {"ORC_AMG_DA": "0", "ORC_AMG_CHASE_GROUP": "64", "ORC_AMG_CHASE_GRID": "8"},
-                                 {"ORC_AMG_DA": "0", "ORC_AMG_CHASE_STEPS": "1", "ORC_AMG_CHASE_GRID": "8", "ORC_AMG_CHASE_LAUNCHES": "100000"},
-                                 {"ORC_GALERKIN_SORT": "1"}, {"ORC_GALERKIN_GROUPS": "64,64,64,64"}, {"ORC_GALERKIN_GROUPS": "16,16,16,32"},
-                                 {"ORC_AMG_DA": "0", "ORC_AMG_EVAL_GROUP": "16", "ORC_AMG_SWEEP_GROUP": "32"}, {"ORC_AMG_DA": "0", "ORC_AMG_EVAL_GROUP": "8", "ORC_AMG_SWEEP_GROUP": "0"},
-                                 {"ORC_AMG_DA": "0", "ORC_AMG_CHASE_GROUP": "-1", "ORC_AMG_SWEEP_GROUP": "4"}])
+@pytest.mark.parametrize("env", [{"ORC_AMG_DA": "0"}, {"ORC_AMG_DA_STEPS": "3"}, {"ORC_AMG_DA_GROUP": "16"}, {"ORC_AMG_DA_GROUP": "8", "ORC_AMG_L0_MIRROR": "0"},
+                                 {"ORC_GALERKIN_GROUPS": "64,64,64,64"}, {"ORC_GALERKIN_GROUPS": "16,16,16,32"}])
 def test_set_up_forms_agree(gpu, monkeypatch, env):
-    """Every form of the set-up lands on the same pairing and the same coarse operator, bit for bit.  The default [r05] is the pairing by
-    deferred acceptance (da_propose_k: one launch of proposals); ORC_AMG_DA=0 is r04's machinery, which stays as the fallback — reached here by
-    cutting every chain of proposals after three steps (ORC_AMG_DA_STEPS=3).  r04's forms, behind ORC_AMG_DA=0: lock-step rounds only;
-    a cascade phase cut off after two steps and two launches (the lock-step rounds finish the job); cascades followed by
-    16- and by 64-lane groups on a tiny grid; one step per wavefront and launch on a tiny grid (every launch carries
-    unclaimed rows and continuations over to the next); the Galerkin product by sorting and by merging with every group size;
-    the lock-step evaluation with 16 and 8 lanes per row (default 4), the slice sweeps with 32, 4 and one lane per slice (default
-    8), cascade groups chosen by row length as in round 2 (default 16)."""
+    """Every form of the set-up lands on the same pairing and the same coarse operator, bit for bit.  The pairing [r05] is by deferred
+    acceptance (da_first_k + da_chase_k); ORC_AMG_DA=0 is the fallback (slice-sequential sweeps until one changes nothing), also reached by
+    cutting every chain of proposals after three steps (ORC_AMG_DA_STEPS=3); chains followed by 16 and by 8 lanes (default: 4 or 8 by row
+    length), without the fine level's row mirror; the Galerkin merge with every group size."""
     from orc_amd.linear_algebra import amg_coarsen
     results = []
     for form in ({}, env):
@@ -269,36 +261,3 @@ def test_last_slice_dead_lanes_regression(gpu, oracle, mesh_path):
         out.append(s.get_fields())
     for x, y in zip(*out):
         assert np.isfinite(x).all() and np.array_equal(x, y)
-
-
-def test_length_sorted_window_products_are_exercised_and_exact(gpu, oracle, monkeypatch):
-    """ORC_SPMV_XSORT=1 (off by default: measured no faster): levels whose rows average 24 entries or more stream
-    a length-sorted image of their packed mirror (XSortDev: rows of a 256-row block sorted by length and dealt round-robin to
-    the four wavefronts, active lanes of every depth a prefix).  Every row is still summed in ascending-column order, so with
-    the reference's reduction order the whole Multigrid arm stays bit-identical to the oracle — and the hook says the sorted
-    products really ran."""
-    import ctypes
-    from conftest import fv_like_matrix, splitmix64_uniform
-    from orc_amd._lib import lib
-    from orc_amd.linear_algebra import iterative_solve, set_breakdown_guard, set_reduction_order
-    L = lib()
-    L.orc_debug_xsort_products.restype = ctypes.c_longlong
-    a = fv_like_matrix(64, 40, 12)
-    n = a.shape[0]
-    b = a @ splitmix64_uniform(n, 7)
-    x0 = 0.1 * splitmix64_uniform(n, 8)
-    monkeypatch.setenv("ORC_SPMV_XSORT", "1")
-    set_reduction_order(1)
-    set_breakdown_guard(False)
-    try:
-        xo = x0.copy()
-        sto = oracle.iterative_solve(oracle.Csr.from_scipy(a), b, xo, 50, MULTIGRID, 0.5, 1e-3, 1)
-        before = L.orc_debug_xsort_products()
-        x = x0.copy()
-        st = iterative_solve(a, b, x, 50, MULTIGRID, 0.5, 1e-3, 1, raise_on_error=False)
-        ran = L.orc_debug_xsort_products() - before
-        assert st == sto and ran > 0, (st, sto, ran)
-        assert np.array_equal(x.view(np.uint64), xo.view(np.uint64))
-    finally:
-        set_reduction_order(0)
-        set_breakdown_guard(True)

@@ -124,6 +124,7 @@ def test_rccl_overlapped_product_on_a_self_loop_communicator(gpu):
     set_channel_bcs(a)
     halo = dict(halo)
     halo["peers"] = np.zeros_like(np.asarray(halo["peers"]))  # the only peer is this rank
+    import orc_amd
     from orc_amd.mesh import hex_channel
     ag = set_channel_bcs(hex_channel(nx, ny, nzl * 2))
     ug = mp_worker.global_fields(ag)
@@ -142,6 +143,7 @@ def test_rccl_overlapped_product_on_a_self_loop_communicator(gpu):
             for form in ("overlapped", "plain"):
                 if form == "plain":
                     os.environ["ORC_HALO_OVERLAP"] = "0"
+                    orc_amd.reload_environment()  # (the library reads its switches once: config.hpp)
                 try:
                     before = L.orc_debug_halo_overlaps()
                     sol = Solver(parallel.PartitionedMesh(a, halo), NumericalSettings.default(**kw), 1000.0, 1e-3)
@@ -150,6 +152,7 @@ def test_rccl_overlapped_product_on_a_self_loop_communicator(gpu):
                     runs[form] = (st, sol.get_fields(), L.orc_debug_halo_overlaps() - before)
                 finally:
                     os.environ.pop("ORC_HALO_OVERLAP", None)
+                    orc_amd.reload_environment()  # (the library reads its switches once: config.hpp)
             n_own = halo["n_owned"]
             (st, f, overlapped), (st_p, f_p, overlapped_p) = runs["overlapped"], runs["plain"]
             assert st == st_p == 0, name

@@ -123,27 +123,6 @@ def test_shared_galerkin_pass_with_one_sibling_and_switched_off(gpu, monkeypatch
             assert same_bits(results["0"][1][k], x1), "system %d (every system for itself)" % k
 
 
-@pytest.mark.parametrize("launch", ["8", "16", "0"])
-@pytest.mark.parametrize("method", [BICGSTAB, MULTIGRID])
-def test_three_system_product_walks_the_one_system_grid(gpu, monkeypatch, launch, method):
-    """[r04] The three-system product is LAUNCHED with fewer workgroups than the one-system product (1 024 resident ones at bench size) and walks the
-    one-system grid's shares several each (MatView3::vgrid): the rows of a share, their order and the partial sum per share are those of the
-    one-system launch, so every system's solve keeps its bits.  Forced here on a small matrix: 8 or 16 workgroups walk 120 shares; 0 = one workgroup
-    per share (round 3)."""
-    from orc_amd.linear_algebra import iterative_solve, iterative_solve3
-    monkeypatch.setenv("ORC_SPMV3_LAUNCH", launch)
-    mats, bs, xs = three_systems((64, 40, 12), distinct_pairings="scaled")
-    x3 = [x.copy() for x in xs]
-    st, st3 = iterative_solve3(mats, bs, x3, 9, method, 0.5, 1e-3, PRE_JACOBI)
-    assert st == 0
-    for k in range(3):
-        x1 = xs[k].copy()
-        st1 = iterative_solve(mats[k], bs[k], x1, 9, method, 0.5, 1e-3, PRE_JACOBI, raise_on_error=False)
-        assert st1 == st3[k]
-        if st1 == 0:
-            assert same_bits(x3[k], x1), "system %d" % k
-
-
 def test_breakdown_guard_acts_per_system(gpu):
     """System 1 starts from its exact solution with a zero right-hand side (rho = 0: frozen at once), system 2 is the identity
     (s = r - alpha nu vanishes in the first half step: x = h, then frozen) — the reference would return NaN for both
