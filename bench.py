@@ -25,7 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PMC_FILE = "r04_spmv_pmc.json"  # written by scripts/pmc_summary_r04.py from the rocprofv3 --pmc passes of scripts/gpu_pmc_r04.sh
+PMC_FILE = "r05_spmv_pmc.json"  # written by scripts/pmc_summary.py from the rocprofv3 --pmc passes of scripts/gpu_pmc.sh
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy ceiling)
 REF_CELLS = 400 * 160 * 160
 
@@ -521,7 +521,7 @@ def main():
         workload_name += " on %dx MI355X (strong scaling: ONE %dx%dx%d mesh cut into %d z-slabs)" % (world, nx, ny, nz_total, world)
     bicg_bytes = 2.0 * spmv_bytes + 104.0 * n_local
     # Memory-side traffic per launch from the PMC counters (TCC_EA0_RDREQ by request size + TCC_EA0_WRREQ, separate rocprofv3
-    # --pmc passes: scripts/gpu_pmc_r02.sh; equal to FETCH_SIZE x 2 + WRITE_SIZE of MI355X_MICROARCH.md §HBM for this
+    # --pmc passes: scripts/gpu_pmc.sh; equal to FETCH_SIZE x 2 + WRITE_SIZE of MI355X_MICROARCH.md §HBM for this
     # kernel): bench.py cannot collect counters itself, so it quotes the committed profile of the same kernel on the same
     # matrix when one exists, else null.
     variant = getattr(solver, "inloop_variant", "false, true, false")  # "<narrow columns>, <scaled on the fly>, <non-temporal matrix loads>" as launched

@@ -185,76 +185,24 @@ def main():
     mode = sys.argv[1]
     dist.init_process_group(backend="gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    if mode == "gpu_triple_partitioned":
-        ok = gpu_triple_partitioned_checks(rank, world)
-        t = torch.tensor([1.0 if ok else 0.0])
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        dist.barrier()
+    # modes that are one function each; "several:<mode>,<mode>,..." runs some of them in ONE launch (one process start, one torch import and one
+    # HIP initialisation per rank instead of one per mode: the GPU suite's multi-process tests cost minutes of exactly that)
+    table = {"gpu_triple_partitioned": gpu_triple_partitioned_checks, "gpu_mixed_slabs": gpu_mixed_slab_checks, "cpu_mixed_slabs": mixed_slab_checks,
+             "gpu_general": gpu_general_checks, "gpu_lane_error": gpu_lane_error_checks, "gpu_converged": gpu_converged_checks,
+             "gpu_overlap": gpu_overlap_checks, "cpu_general": general_partition_checks}
+    todo = mode[len("several:"):].split(",") if mode.startswith("several:") else ([mode] if mode in table else [])
+    if todo:
+        ok = True
+        for m in todo:
+            good = bool(table[m](rank, world))
+            t = torch.tensor([1.0 if good else 0.0])
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            dist.barrier()
+            if rank == 0:
+                print("MP_WORKER_MODE %s %s" % (m, "ok" if t.item() == 1.0 else "FAIL"), flush=True)
+            ok = ok and t.item() == 1.0
         if rank == 0:
-            print("MP_WORKER_OK" if t.item() == 1.0 else "MP_WORKER_FAIL", flush=True)
-        dist.destroy_process_group()
-        return
-    if mode == "gpu_mixed_slabs":
-        ok = gpu_mixed_slab_checks(rank, world)
-        t = torch.tensor([1.0 if ok else 0.0])
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        dist.barrier()
-        if rank == 0:
-            print("MP_WORKER_OK" if t.item() == 1.0 else "MP_WORKER_FAIL", flush=True)
-        dist.destroy_process_group()
-        return
-    if mode == "cpu_mixed_slabs":
-        ok = mixed_slab_checks(rank, world)
-        t = torch.tensor([1.0 if ok else 0.0])
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        dist.barrier()
-        if rank == 0:
-            print("MP_WORKER_OK" if t.item() == 1.0 else "MP_WORKER_FAIL", flush=True)
-        dist.destroy_process_group()
-        return
-    if mode == "gpu_general":
-        ok = gpu_general_checks(rank, world)
-        t = torch.tensor([1.0 if ok else 0.0])
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        dist.barrier()
-        if rank == 0:
-            print("MP_WORKER_OK" if t.item() == 1.0 else "MP_WORKER_FAIL", flush=True)
-        dist.destroy_process_group()
-        return
-    if mode == "gpu_lane_error":
-        ok = gpu_lane_error_checks(rank, world)
-        t = torch.tensor([1.0 if ok else 0.0])
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        dist.barrier()
-        if rank == 0:
-            print("MP_WORKER_OK" if t.item() == 1.0 else "MP_WORKER_FAIL", flush=True)
-        dist.destroy_process_group()
-        return
-    if mode == "gpu_converged":
-        ok = gpu_converged_checks(rank, world)
-        t = torch.tensor([1.0 if ok else 0.0])
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        dist.barrier()
-        if rank == 0:
-            print("MP_WORKER_OK" if t.item() == 1.0 else "MP_WORKER_FAIL", flush=True)
-        dist.destroy_process_group()
-        return
-    if mode == "gpu_overlap":
-        ok = gpu_overlap_checks(rank, world)
-        t = torch.tensor([1.0 if ok else 0.0])
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        dist.barrier()
-        if rank == 0:
-            print("MP_WORKER_OK" if t.item() == 1.0 else "MP_WORKER_FAIL", flush=True)
-        dist.destroy_process_group()
-        return
-    if mode == "cpu_general":
-        ok = general_partition_checks(rank, world)
-        t = torch.tensor([1.0 if ok else 0.0])
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        dist.barrier()
-        if rank == 0:
-            print("MP_WORKER_OK" if t.item() == 1.0 else "MP_WORKER_FAIL", flush=True)
+            print("MP_WORKER_OK" if ok else "MP_WORKER_FAIL", flush=True)
         dist.destroy_process_group()
         return
     nx, ny, nzl = 6, 5, 3

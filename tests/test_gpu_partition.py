@@ -13,20 +13,20 @@ def test_two_ranks_match_single_rank(gpu):
     assert "MP_WORKER_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-4000:]
 
 
-def test_general_partitioner_two_ranks_match_single_rank(gpu):
-    """orc_mesh_partition (geometric and RCM orderings) on the read prism + hexahedron mesh: two ranks on one GPU."""
-    r = launch(2, "gpu_general", timeout=900)
-    print(r.stdout[-1500:])
-    assert "MP_WORKER_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-4000:]
-
-
-def test_overlapped_level0_product_two_ranks(gpu):
-    """Slabs of 260 slices per rank: the level-0 products run their interior slices beside the halo exchange; fields against
-    the same partitioned run without the overlap (1e-11 / 1e-8: only the layout of the partial sums differs), against the
-    single-rank run, and the overlap counter > 0."""
-    r = launch(2, "gpu_overlap", timeout=900)
-    print(r.stdout[-1500:])
-    assert "MP_WORKER_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-4000:]
+def test_two_ranks_general_partitioner_overlapped_products_lock_step_and_mixed_slabs(gpu):
+    """Four checks in ONE two-rank launch (each was a launch of its own until r05: a process start, a torch import and a HIP initialisation per rank
+    and check — most of these tests' time):
+    * gpu_general — orc_mesh_partition (geometric and RCM orderings) on the read prism + hexahedron mesh against the single-rank run;
+    * gpu_overlap — slabs of 260 slices per rank: the level-0 products run their interior slices beside the halo exchange; fields against the same
+      partitioned run without the overlap (1e-11 / 1e-8: only the layout of the partial sums differs), against the single-rank run, counter > 0;
+    * gpu_triple_partitioned — the three momentum systems in lock-step across two ranks (interleaved halo exchange, one all-reduce per step for the
+      three systems): bit-identical per system to the one-system partitioned solves, about half the collectives per SIMPLE iteration;
+    * gpu_mixed_slabs — BASELINE configs[4] as an N-rank run: each rank generates ITS slab of the mixed tet / hex / poly channel (two ghost block
+      layers, orc_mesh_partition_owner, ghost geometry verified over the control plane) and the partitioned SIMPLE iterations — Jacobi, BiCGSTAB,
+      the Multigrid arm — agree with the single-rank run on the whole mesh."""
+    r = launch(2, "several:gpu_general,gpu_overlap,gpu_triple_partitioned,gpu_mixed_slabs", timeout=1500)
+    print(r.stdout[-3000:])
+    assert "MP_WORKER_OK" in r.stdout and r.stdout.count("MP_WORKER_MODE") == 4, r.stdout[-3000:] + r.stderr[-4000:]
 
 
 def test_two_ranks_converged_default_stack_matches_the_oracle(gpu):
@@ -39,30 +39,12 @@ def test_two_ranks_converged_default_stack_matches_the_oracle(gpu):
     assert "MP_WORKER_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-4000:]
 
 
-def test_lock_step_momentum_solve_on_a_partitioned_mesh(gpu):
-    """The three momentum systems in lock-step across two ranks (interleaved halo exchange, one all-reduce per step for the three
-    systems): bit-identical per system to the one-system partitioned solves, with about half the collectives per SIMPLE iteration
-    (a third in the momentum phase)."""
-    r = launch(2, "gpu_triple_partitioned", timeout=900)
-    print(r.stdout[-1500:])
-    assert "MP_WORKER_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-4000:]
-
-
 def test_lock_step_momentum_solve_on_three_ranks(gpu):
     """The same with three ranks on the card: the middle rank has two peers, so every interleaved exchange packs and lands two blocks.  Still
     bit-identical per system: the debug transport folds the ranks' terms in rank order whatever travels together (gloo's own ring all-reduce
     starts every chunk at another rank, which made a 3-scalar reduction and three 1-scalar reductions differ in the last bit — and the
     reference's r_hat_0 = 1 recurrences turn a last bit into 1e-2 within two SIMPLE iterations of the Multigrid arm: measured, hence this note)."""
     r = launch(3, "gpu_triple_partitioned", timeout=900)
-    print(r.stdout[-1500:])
-    assert "MP_WORKER_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-4000:]
-
-
-def test_two_ranks_on_rank_local_mixed_poly_slabs_match_single_rank(gpu):
-    """BASELINE configs[4] as an N-rank run (Missing #1): each of two ranks generates ITS slab of the mixed tet / hex /
-    poly channel (two ghost block layers, orc_mesh_partition_owner) and the partitioned SIMPLE iterations — Jacobi, BiCGSTAB and the
-    Multigrid arm — agree with the single-rank run on the whole mesh."""
-    r = launch(2, "gpu_mixed_slabs", timeout=900)
     print(r.stdout[-1500:])
     assert "MP_WORKER_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-4000:]
 
