@@ -974,6 +974,22 @@ __global__ __launch_bounds__(kBlock) void xwin_build_k(SellDev P, PackedDev pk, 
 
 // ORC_XWIN_STATS=1 (measurement): how the windows of a level are made up — entries, maximal runs of consecutive columns, runs of
 // eight or more, blocks whose columns span fewer than 65 536
+// candidates for a level's LDS share (XWinDev::cap), ascending; over[q] = blocks whose window holds more than kXWinCapSize[q] entries
+constexpr int kXWinCapSizes = 5;
+__device__ __constant__ int kXWinCapSizeDev[kXWinCapSizes] = {2048, 2560, 3200, 4000, kXWinCap};
+static const int kXWinCapSize[kXWinCapSizes] = {2048, 2560, 3200, 4000, kXWinCap};
+__global__ __launch_bounds__(kBlock) void xwin_cap_k(const int *__restrict__ wsize, int64_t n_blocks, int *__restrict__ over) {
+    int c[kXWinCapSizes] = {0, 0, 0, 0, 0};
+    for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n_blocks; b += (int64_t)gridDim.x * blockDim.x) {
+        const int ws = wsize[b];
+#pragma unroll
+        for (int q = 0; q < kXWinCapSizes; ++q) c[q] += ws > kXWinCapSizeDev[q] ? 1 : 0;
+    }
+#pragma unroll
+    for (int q = 0; q < kXWinCapSizes; ++q)
+        if (c[q]) atomicAdd(over + q, c[q]);
+}
+
 __global__ __launch_bounds__(kBlock) void xwin_stats_k(const int *__restrict__ wcol, const int *__restrict__ wsize, int64_t n_blocks, unsigned long long *__restrict__ out) {
     for (int64_t b = blockIdx.x; b < n_blocks; b += gridDim.x) {
         const int ws = wsize[b];
@@ -1902,6 +1918,22 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
         }
         ORC_HIP(hipGetLastError());
         L.xw.wcol = wcol; L.xw.wsize = wsize; L.xw.lidx = lidx;
+        {   // [r05] this level's LDS share per workgroup: the smallest of a few sizes that leaves <= 1 % of the blocks without a window
+            // (+ whatever had none to begin with); one small kernel and one host read per level with windows
+            int *over;
+            ORC_TRY(tmp.alloc((size_t)kXWinCapSizes, &over));
+            ORC_HIP(hipMemsetAsync(over, 0, kXWinCapSizes * sizeof(int), st));
+            hipLaunchKernelGGL(xwin_cap_k, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((n_blocks + kBlock - 1) / kBlock, 64))), dim3(kBlock), 0, st, (const int *)wsize, n_blocks, over);
+            int h_over[kXWinCapSizes];
+            ORC_HIP(hipMemcpyAsync(h_over, over, sizeof(h_over), hipMemcpyDeviceToHost, st));
+            ORC_HIP(hipStreamSynchronize(st));
+            int cap = win_cap;
+            for (int q = 0; q < kXWinCapSizes && cfg().xwin_level_cap; ++q)
+                if (kXWinCapSize[q] <= win_cap && (int64_t)h_over[q] * 100 <= n_blocks) { cap = kXWinCapSize[q]; break; }
+            L.xw.cap = cap;
+            if (trace_t) fprintf(stderr, "[amg windows n=%lld] LDS share %d entries per workgroup (%d of %lld blocks have larger windows)\n", (long long)nc, cap,
+                                 cap < win_cap ? h_over[std::find(kXWinCapSize, kXWinCapSize + kXWinCapSizes, cap) - kXWinCapSize] : 0, (long long)n_blocks);
+        }
         for (int x = 0; x < n_sib; ++x) {  // same structure, own values
             CoarseLevel &Lx = *sib[x].L;
             Lx.pk = L.pk;

@@ -466,9 +466,10 @@ static int launch_spmv(const MatView &A_in, const double *x, const Epi &epi, dou
     if (A.P.n == 0) return ORC_OK;
     if (A.halo) ORC_TRY(A.halo->exchange(const_cast<double *>(x)));  // C1: refresh the ghost entries of x
     if (xwin) {
-        if (!A.s1 && !A.s2 && A.nt) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_xwin_k<Epi, false, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
-        else if (!A.s1 && !A.s2) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_xwin_k<Epi, false>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_xwin_k<Epi>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
+        const size_t xwin_smem = sizeof(double) * (size_t)std::max(1, std::min(A.xw.cap, kXWinCap));
+        if (!A.s1 && !A.s2 && A.nt) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_xwin_k<Epi, false, true>), dim3(g), dim3(kBlock), xwin_smem, ctx().stream, A, x, epi, partials, skip_flags);
+        else if (!A.s1 && !A.s2) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_xwin_k<Epi, false>), dim3(g), dim3(kBlock), xwin_smem, ctx().stream, A, x, epi, partials, skip_flags);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_xwin_k<Epi>), dim3(g), dim3(kBlock), xwin_smem, ctx().stream, A, x, epi, partials, skip_flags);
         ORC_HIP(hipGetLastError());
         return ORC_OK;
     }

@@ -68,6 +68,10 @@ struct XWinDev {
     const int32_t *wcol = nullptr;   // [n_blocks * kXWinCap]
     const int32_t *wsize = nullptr;  // [n_blocks], -1 = no window for this block
     const uint16_t *lidx = nullptr;  // [packed entries] window position of the entry's column
+    // [r05] the LDS entries a product of THIS level provides per workgroup (<= kXWinCap): the smallest of a few sizes that leaves <= 1 % of the
+    // level's blocks without a window.  The compiled worst case (5 000 entries = 40 KB) held a CU to four workgroups whatever the level needed
+    // (the channel's level 2: 2 200 per block); blocks whose window is larger gather from global memory, as blocks without a window always did.
+    int32_t cap = kXWinCap;
 };
 
 // Row-contiguous mirror (the Galerkin product's scratch rows, kept alive with their level): entry k of row r sits at

@@ -434,11 +434,15 @@ struct SpmvSliceMeta {
 // kScaled = false: the view carries no row scaling (a smoothing solve has materialised its scaled values, materialize_scaled_view):
 // the two scaling multiplications per entry and their selects are not compiled in — the stream loop of this kernel is bound by
 // instruction issue as much as by memory (39 vector instructions per entry and wavefront, profiles/r03_pmc_products.csv)
-template <class Epi, bool kScaled = true, bool kNT = false>
+// kC: entries per lane and chunk of the stream (two chunks in flight): 8 = 92-94 VGPRs, five workgroups per CU where the level's LDS share
+// (XWinDev::cap) allows them.  [r05] measured: 4 (58 VGPRs, up to 24 wavefronts per CU on the level whose windows fit 25 KB) is no faster — 233.1 /
+// 226.6 against 226.2 / 227.5 us on that level, 226.4 / 219.7 against 224.9 / 218.6 on the last (scripts/gpu_r05_j.sh): like the per-level LDS
+// share itself (16 -> 20 wavefronts per CU: -1 ... -3 %), occupancy is not what holds this product at 4.6-4.8 TB/s
+template <class Epi, bool kScaled = true, bool kNT = false, int kC = 8>
 __global__ __launch_bounds__(kBlock) void spmv_xwin_k(MatView A, const double *__restrict__ x, Epi epi, double *__restrict__ partials,
                                                       const double *__restrict__ skip_flags) {
     __shared__ double lds[8];
-    __shared__ double xs[kXWinCap];
+    extern __shared__ __align__(16) double xs[];  // A.xw.cap entries (dynamic: sized per level by the launch)
     if (skip_flags && (skip_flags[0] != 0. || skip_flags[1] != 0.)) return;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // (scalar: the slice's descriptors go through the scalar cache)
     double r0 = 0., r1 = 0.;
@@ -454,7 +458,8 @@ __global__ __launch_bounds__(kBlock) void spmv_xwin_k(MatView A, const double *_
         b_begin = blockIdx.x; b_end = n_blocks; b_step = gridDim.x;
     }
     for (int64_t b = b_begin; b < b_end; b += b_step) {
-        const int ws = A.xw.wsize[b];  // workgroup-uniform
+        const int ws_built = A.xw.wsize[b];                  // workgroup-uniform
+        const int ws = ws_built <= A.xw.cap ? ws_built : -1;  // a window larger than this level's LDS share: global gathers, like a block without one
         // the slice's own stream does not depend on the window: its descriptors are requested before the window is loaded (requesting its
         // first chunk there too was measured: neutral)
         const int64_t slice = b * 4 + wave;
@@ -475,11 +480,11 @@ __global__ __launch_bounds__(kBlock) void spmv_xwin_k(MatView A, const double *_
         const unsigned short *s_lidx = A.xw.lidx + sb;
         const double *s_val = A.pk.val + sb;
         int off32 = 0;  // wave-uniform running offset of the chunk inside the slice
-        int c[8], cn[8];
-        double v[8], vn[8];
-        auto issue = [&](int k0, int (&cc)[8], double (&vv)[8]) {
+        int c[kC], cn[kC];
+        double v[kC], vn[kC];
+        auto issue = [&](int k0, int (&cc)[kC], double (&vv)[kC]) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {  // branch-free loads, see spmv_k
+            for (int u = 0; u < kC; ++u) {  // branch-free loads, see spmv_k
                 const bool in = k0 + u < len;
                 const unsigned long long m = __ballot(in);
                 const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
@@ -522,12 +527,12 @@ __global__ __launch_bounds__(kBlock) void spmv_xwin_k(MatView A, const double *_
                 // pass, and a copy reads its source — `s_waitcnt vmcnt(0)` in front of the copies (listing), i.e. every pass ended by
                 // waiting for the chunk it had just requested.  Now the two register sets take turns (the loop is unrolled by two): a pass
                 // waits for the OLDER chunk only (vmcnt retires in order), the younger one travels while it is multiplied.
-                auto consume = [&](int k0, const int (&cc)[8], const double (&vv)[8]) {
-                    double xv[8];
+                auto consume = [&](int k0, const int (&cc)[kC], const double (&vv)[kC]) {
+                    double xv[kC];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) xv[u] = xs[cc[u]];
+                    for (int u = 0; u < kC; ++u) xv[u] = xs[cc[u]];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
+                    for (int u = 0; u < kC; ++u) {
                         double t = vv[u];
                         if (kScaled && A.s1) t = s1 * t;
                         if (kScaled && A.s2) t = s2 * t;
@@ -537,11 +542,11 @@ __global__ __launch_bounds__(kBlock) void spmv_xwin_k(MatView A, const double *_
                 };
                 if (width > 0) issue(0, c, v);
                 int k0 = 0;
-                for (; k0 + 8 < width; k0 += 16) {  // at the top: chunk k0 is on its way into (c, v)
-                    issue(k0 + 8, cn, vn);
+                for (; k0 + kC < width; k0 += 2 * kC) {  // at the top: chunk k0 is on its way into (c, v)
+                    issue(k0 + kC, cn, vn);
                     consume(k0, c, v);
-                    if (k0 + 16 < width) issue(k0 + 16, c, v);
-                    consume(k0 + 8, cn, vn);
+                    if (k0 + 2 * kC < width) issue(k0 + 2 * kC, c, v);
+                    consume(k0 + kC, cn, vn);
                 }
                 if (k0 < width) consume(k0, c, v);
             } else {
