@@ -2053,6 +2053,8 @@ static int multigrid_solve_dev(const MatView &A, const double *r, uint64_t level
     Ac.rows = L.rows;
     Ac.symmetric = A.symmetric;  // halo stays null: coarse levels are solved per rank
     double *r_prime, *e_prime, *partials, *scal;
+    const bool shared_scaling = cfg().amg_shared_scaling && mp.smoother == ORC_SOLVER_BICGSTAB && mp.preconditioner == ORC_PRECOND_JACOBI;
+    ScaledOperator scaled;
     {
         StreamSwitch sw(side);
         hipStream_t vs = ctx().stream;
@@ -2065,7 +2067,10 @@ static int multigrid_solve_dev(const MatView &A, const double *r, uint64_t level
         hipLaunchKernelGGL(restrict_k, dim3(grid_for(nc)), dim3(kBlock), 0, vs, choice, n, nc, r, r_prime);  // :82
         ORC_HIP(hipGetLastError());
         ORC_TRY(vec_fill(e_prime, 0., nc));  // :86
-        int stt = iterative_solve_dev(Ac, r_prime, e_prime, mp.iters, mp.smoother, mp.relaxation, threshold, mp.preconditioner, varena, stats);  // :87-96
+        // both smoothing solves of this level scale Ac the same way (:159-166): prepared once, held in varena until the level unwinds
+        if (shared_scaling) ORC_TRY(jacobi_scaling_prepare_dev(Ac, mp.iters, varena, scaled));
+        int stt = shared_scaling ? bicgstab_scaled_dev(scaled, r_prime, e_prime, varena)
+                                 : iterative_solve_dev(Ac, r_prime, e_prime, mp.iters, mp.smoother, mp.relaxation, threshold, mp.preconditioner, varena, stats);  // :87-96
         if (stt != ORC_OK) return leave(stt);
         // :97-105  |r' - a' e'| is NaN -> "Multigrid diverged"
         ORC_TRY(residual_norm2_dev(Ac, r_prime, e_prime, partials, scal, r_check));
@@ -2076,7 +2081,8 @@ static int multigrid_solve_dev(const MatView &A, const double *r, uint64_t level
         int stt = multigrid_solve_dev(Ac, r_prime, level + 1, mp, threshold, arena, stats, dev_status, nullptr, e_prime, side);
         if (stt != ORC_OK) return leave(stt);
         StreamSwitch sw(side);
-        stt = iterative_solve_dev(Ac, r_prime, e_prime, mp.iters, mp.smoother, mp.relaxation, threshold / 10., mp.preconditioner, varena, stats);  // :123-132
+        stt = shared_scaling ? bicgstab_scaled_dev(scaled, r_prime, e_prime, varena)
+                             : iterative_solve_dev(Ac, r_prime, e_prime, mp.iters, mp.smoother, mp.relaxation, threshold / 10., mp.preconditioner, varena, stats);  // :123-132
         if (stt != ORC_OK) return leave(stt);
     }
     {
@@ -2487,7 +2493,10 @@ int multigrid_arm3_dev(const MatView3 &A3, const double *const b[3], double *con
         ORC_HIP(hipGetLastError());
         ORC_TRY(vec_fill(e1, 0., (int64_t)nc3));                                                                                      // :86
         step("restriction");
-        ORC_TRY(bicgstab3_dev(Ac3, r1, e1, iteration_count, preconditioner, arena));                                                  // :87-96
+        const bool shared_scaling = cfg().amg_shared_scaling && preconditioner == ORC_PRECOND_JACOBI;  // as in multigrid_solve_dev
+        ScaledOperator3 scaled3;
+        if (shared_scaling) ORC_TRY(jacobi_scaling_prepare3_dev(Ac3, iteration_count, arena, scaled3));
+        ORC_TRY(shared_scaling ? bicgstab3_scaled_dev(scaled3, r1, e1, arena) : bicgstab3_dev(Ac3, r1, e1, iteration_count, preconditioner, arena));  // :87-96
         step("pre-smoothing");
         ORC_TRY(residual_norm2_3_dev(Ac3, r1, e1, partials, norm3));                                                                  // :97-105
         step("residual norm");
@@ -2524,7 +2533,7 @@ int multigrid_arm3_dev(const MatView3 &A3, const double *const b[3], double *con
             hipLaunchKernelGGL(vec_add3_k, dim3(grid_for(nc)), dim3(kBlock), 0, st, e1, (const double *)ck[0], (const double *)ck[1], (const double *)ck[2], nc);  // e' += ...
             ORC_HIP(hipGetLastError());
             step("corrections added");
-            ORC_TRY(bicgstab3_dev(Ac3, r1, e1, iteration_count, preconditioner, arena));  // :123-132
+            ORC_TRY(shared_scaling ? bicgstab3_scaled_dev(scaled3, r1, e1, arena) : bicgstab3_dev(Ac3, r1, e1, iteration_count, preconditioner, arena));  // :123-132
             step("post-smoothing");
         }
         hipLaunchKernelGGL(prolong3_k, dim3(grid_for(n)), dim3(kBlock), 0, st, (const int *)L0.choice, (const int *)L0.chooser, n, (const double *)e1, x3);  // :140, :284

@@ -22,6 +22,7 @@ struct Config {
     int amg_da_steps = 1 << 22;         // ORC_AMG_DA_STEPS: proposals per chain before it is cut (test hook: the fallback finishes the job)
     int amg_da_group = 0;               // ORC_AMG_DA_GROUP: lanes per chain (0: by row length)
     bool amg_sibling = true;            // ORC_AMG_SIBLING: v and w try u's fine-level pairing first
+    bool amg_shared_scaling = true;     // ORC_AMG_SHARED_SCALING: a level's two smoothing solves share one inverse diagonal and one set of scaled values
     bool amg_shared_galerkin = true;    // ORC_AMG_SHARED_GALERKIN: one symbolic Galerkin pass for u, v, w when their pairings agree
     bool amg_l0_mirror = true;          // ORC_AMG_L0_MIRROR: row-contiguous mirror of the fine level for the set-up's row walks
     std::string galerkin_groups;        // ORC_GALERKIN_GROUPS: lanes per coarse row by tier, "16,16,32,64" (test hook: every merge width)

@@ -813,12 +813,11 @@ int materialize_scaled_view(MatView &A, uint64_t iteration_count, Arena &arena) 
     return ORC_OK;
 }
 
-static int bicgstab_dev(const MatView &A_in, const double *b, double *x, uint64_t iteration_count, Arena &arena) {
-    const int64_t n = A_in.P.n;
+// linear_algebra.rs:247-269 on a view whose scalings are final (materialised or carried as s1 / s2)
+static int bicgstab_run(const MatView &A, const double *b, double *x, uint64_t iteration_count, Arena &arena) {
+    const int64_t n = A.P.n;
     if (n == 0) return ORC_OK;
     ArenaScope scope(arena);
-    MatView A = A_in;
-    ORC_TRY(materialize_scaled_view(A, iteration_count, arena));
     BicgWork w;
     ORC_TRY(bicg_alloc(arena, std::max(A.P.ncols, n), w));
     const int guard = ctx().breakdown_guard ? 1 : 0;
@@ -832,6 +831,44 @@ static int bicgstab_dev(const MatView &A_in, const double *b, double *x, uint64_
         ORC_HIP(hipGetLastError());
     }
     return ORC_OK;
+}
+
+static int bicgstab_dev(const MatView &A_in, const double *b, double *x, uint64_t iteration_count, Arena &arena) {
+    if (A_in.P.n == 0) return ORC_OK;
+    ArenaScope scope(arena);
+    MatView A = A_in;
+    ORC_TRY(materialize_scaled_view(A, iteration_count, arena));
+    return bicgstab_run(A, b, x, iteration_count, arena);
+}
+
+int jacobi_scaling_prepare_dev(const MatView &A_in, uint64_t iteration_count, Arena &arena, ScaledOperator &S) {
+    ORC_TRY(ensure_init());
+    const int64_t n = A_in.P.n;
+    S = ScaledOperator();
+    S.A = A_in;
+    S.iterations = iteration_count;
+    double *dinv;
+    ORC_TRY(arena.alloc((size_t)std::max<int64_t>(n, 1), &dinv));
+    if (n) {
+        hipLaunchKernelGGL(diag_inverse_k, dim3(grid_for(n)), dim3(kBlock), 0, ctx().stream, A_in, dinv);
+        ORC_HIP(hipGetLastError());
+    }
+    if (!S.A.s1) S.A.s1 = dinv;
+    else if (!S.A.s2) S.A.s2 = dinv;
+    else return set_error(ORC_ERR_BAD_ARGUMENT, "more than two nested Jacobi scalings");
+    S.dinv = dinv;
+    return materialize_scaled_view(S.A, iteration_count, arena);
+}
+
+int bicgstab_scaled_dev(const ScaledOperator &S, const double *b, double *x, Arena &arena) {
+    const int64_t n = S.A.P.n;
+    if (n == 0) return ORC_OK;
+    ArenaScope scope(arena);
+    double *b_tmp;
+    ORC_TRY(arena.alloc((size_t)n, &b_tmp));
+    hipLaunchKernelGGL(scale_vec_k, dim3(grid_for(n)), dim3(kBlock), 0, ctx().stream, S.dinv, b, b_tmp, n);  // :165
+    ORC_HIP(hipGetLastError());
+    return bicgstab_run(S.A, b_tmp, x, S.iterations, arena);
 }
 
 template <class Fn>
@@ -1339,6 +1376,32 @@ __global__ void guard_event3_k(const double *__restrict__ scal3, int *__restrict
     for (int s = 0; s < 3; ++s)
         if (scal3[SC3(S_FROZEN, s)] != 0. || scal3[SC3(S_FROZEN2, s)] != 0.) ++c;
     if (c) atomicAdd(counter, c);
+}
+
+int jacobi_scaling_prepare3_dev(const MatView3 &A_in, uint64_t iteration_count, Arena &arena, ScaledOperator3 &S) {
+    const int64_t n = A_in.P.n;
+    S = ScaledOperator3();
+    S.A = A_in;
+    S.iterations = iteration_count;
+    if (n == 0) return ORC_OK;
+    double *dinv3;
+    ORC_TRY(arena.alloc((size_t)3 * (size_t)n, &dinv3));
+    ORC_TRY(diag_inverse3_dev(A_in, dinv3));
+    if (!S.A.s1) S.A.s1 = dinv3;
+    else if (!S.A.s2) S.A.s2 = dinv3;
+    else return set_error(ORC_ERR_BAD_ARGUMENT, "more than two nested Jacobi scalings");
+    S.dinv3 = dinv3;
+    return materialize_scaled_view3(S.A, iteration_count, arena);
+}
+
+int bicgstab3_scaled_dev(const ScaledOperator3 &S, const double *b3, double *x3, Arena &arena) {
+    const int64_t n = S.A.P.n;
+    if (n == 0) return ORC_OK;
+    ArenaScope scope(arena);
+    double *bt3;
+    ORC_TRY(arena.alloc((size_t)3 * (size_t)n, &bt3));
+    ORC_TRY(scale_vec_dev(S.dinv3, b3, bt3, 3 * n));  // :165
+    return bicgstab3_dev(S.A, bt3, x3, S.iterations, ORC_PRECOND_NONE, arena);
 }
 
 int bicgstab3_dev(const MatView3 &A_in, const double *b3_in, double *x3, uint64_t iteration_count, int preconditioner, Arena &arena) {

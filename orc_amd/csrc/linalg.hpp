@@ -298,6 +298,25 @@ int bench_inloop_products3_dev(const MatView3 &A, const double *x3, double *y3, 
 int matview_stream_nt(const MatView &A);  // the cache policy launch_spmv picks for this view's matrix streams (MatView::nt)
 int materialize_scaled_view(MatView &A, uint64_t iteration_count, Arena &arena);
 int materialize_scaled_view3(MatView3 &A, uint64_t iteration_count, Arena &arena);
+// A matrix seen through one more Jacobi scaling (linear_algebra.rs:159-166), prepared ONCE for several BiCGSTAB solves on it: the
+// inverse diagonal and, from ORC_MATERIALIZE_SCALING iterations on, the scaled values.  multigrid_solve's two smoothing solves of a
+// level (:87-96, :123-132) scale the same coarse matrix the same way; the second one reuses what the first built — the same
+// kernels on the same numbers, so nothing changes in any bit.  Everything is allocated from `arena` in the CALLER's scope.
+struct ScaledOperator {
+    MatView A;
+    const double *dinv = nullptr;
+    uint64_t iterations = 0;
+};
+struct ScaledOperator3 {
+    MatView3 A;
+    const double *dinv3 = nullptr;
+    uint64_t iterations = 0;
+};
+int jacobi_scaling_prepare_dev(const MatView &A, uint64_t iteration_count, Arena &arena, ScaledOperator &S);
+int jacobi_scaling_prepare3_dev(const MatView3 &A, uint64_t iteration_count, Arena &arena, ScaledOperator3 &S);
+// iterative_solve(A, b, x, S.iterations, BiCGSTAB, Jacobi) on the prepared operator: b is scaled here (:165), the rest is :247-269
+int bicgstab_scaled_dev(const ScaledOperator &S, const double *b, double *x, Arena &arena);
+int bicgstab3_scaled_dev(const ScaledOperator3 &S, const double *b3, double *x3, Arena &arena);
 // is the triple path usable in the calling context (tree reductions; since r04 also on a partitioned mesh)?
 bool triple_supported();
 

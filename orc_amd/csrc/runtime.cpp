@@ -53,6 +53,7 @@ void config_reload() {
     c.amg_da_steps = std::max(1, env_int("ORC_AMG_DA_STEPS", 1 << 22));
     c.amg_da_group = env_int("ORC_AMG_DA_GROUP", 0);
     c.amg_sibling = env_on("ORC_AMG_SIBLING", true);
+    c.amg_shared_scaling = env_on("ORC_AMG_SHARED_SCALING", true);
     c.amg_shared_galerkin = env_on("ORC_AMG_SHARED_GALERKIN", true);
     c.amg_l0_mirror = env_on("ORC_AMG_L0_MIRROR", true);
     c.galerkin_groups = env_str("ORC_GALERKIN_GROUPS");

@@ -238,6 +238,32 @@ def test_cache_policy_of_the_matrix_loads_does_not_change_a_bit(gpu, monkeypatch
         assert np.array_equal(x, y)
 
 
+@pytest.mark.parametrize("triple", ["1", "0"])
+def test_shared_jacobi_scaling_of_a_levels_two_smoothing_solves_does_not_change_a_bit(gpu, monkeypatch, triple):
+    """multigrid_solve's pre- and post-smoothing solves of a level (linear_algebra.rs:87-96, :123-132) scale the same coarse matrix by the
+    same inverse diagonal (:159-166).  [r05] The second reuses the first one's inverse diagonal and scaled values (ScaledOperator,
+    linalg.hpp); ORC_AMG_SHARED_SCALING=0 computes both twice, as r04 did.  Lock-step and per-system momentum solves, window products on
+    the coarse levels (8 iterations: values materialised) and entry-by-entry scaling (3 iterations: not materialised): identical bits."""
+    from orc_amd.mesh import Mesh, hex_channel, set_channel_bcs
+    from orc_amd.settings import NumericalSettings
+    from orc_amd.solver import solve_steady
+    import helpers as H
+    a = set_channel_bcs(hex_channel(40, 24, 16))
+    monkeypatch.setenv("ORC_TRIPLE_MOMENTUM", triple)
+    for iterations in (8, 3):
+        s = NumericalSettings.default(momentum=5, solver_type=MULTIGRID, iterations=iterations, momentum_relaxation=0.1, pressure_relaxation=0.001)
+        out = []
+        for shared in ("1", "0"):
+            monkeypatch.setenv("ORC_AMG_SHARED_SCALING", shared)
+            dm = Mesh(a)
+            u, v, w, p = H.seeded_fields(a, seed=12)
+            solve_steady(dm, u, v, w, p, s, 1000.0, 1e-3, 3)
+            out.append((u, v, w, p))
+        assert np.isfinite(out[0][0]).all()
+        for x, y in zip(*out):
+            assert np.array_equal(x, y)
+
+
 def test_last_slice_dead_lanes_regression(gpu, oracle, mesh_path):
     """Regression (round 2, fix 5d036f6): channel_flow.msh has 1008 = 15 x 64 + 48 cells, so the last slice of every level has
     dead lanes; those lanes once gathered through never-written columns of the device-packed coarse operators and the process
