@@ -1810,8 +1810,13 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
     // Packed mirror + LDS x windows for the levels whose rows are long enough for a window to be re-used (measured at
     // 10.24 M fine rows: 33 entries per row +2 %, 70 entries per row +17 % against the padded product; 15 entries per row
     // -10 %, so that level keeps the padded image).  ORC_SPMV_XWIN_MIN_NNZ < 0 switches the mirror off.
+    // [r05] ... unless the padded image wastes what the windows cost: config 5's level 1 (17 entries per row, rows of a tet / hex / polyhedral mesh paired:
+    // 29 % of its SELL image is padding) 165 -> 126 us with the mirror, the whole iteration 516 -> 479 ms (scripts/gpu_r05_r.sh); the channel's level 1
+    // (5.7 % padding) 198 -> 222 us.  From 15 % padding on, a level of at least half the entries per row takes the mirror too.
     const int xwin_min = cfg().spmv_xwin_min_nnz;
-    const bool mirror = xwin_min >= 0 && packed_total > 0 && packed_total >= (int64_t)xwin_min * nc;
+    const bool long_rows = packed_total >= (int64_t)xwin_min * nc;
+    const bool ragged_rows = 2 * packed_total >= (int64_t)xwin_min * nc && (double)padded >= 1.15 * (double)packed_total;
+    const bool mirror = xwin_min >= 0 && packed_total > 0 && (long_rows || ragged_rows);
     int *pk_col = nullptr;
     double *pk_val = nullptr;
     if (mirror) {
