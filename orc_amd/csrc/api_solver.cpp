@@ -587,7 +587,7 @@ int orc_bench_inloop_products(OrcSolver *s, int reps, double avg_ms[4]) {
     {  // narrow columns, scalings on the fly, non-temporal matrix loads: the last three template arguments of the kernels just timed
         const bool narrow = A.P.col16 != nullptr, scaled = A.s1 || A.s2;
         snprintf(g_inloop_variant, sizeof(g_inloop_variant), "%s, %s, %s", narrow ? "true" : "false", scaled ? "true" : "false",
-                 (narrow && !scaled && matview_stream_nt(A)) ? "true" : "false");
+                 (!scaled && matview_stream_nt(A)) ? "true" : "false");
     }
     float ms[2];
     ORC_TRY(bench_inloop_products_dev(A, t.u.p, y, partials, reps, ms));

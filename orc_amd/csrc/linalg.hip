@@ -230,7 +230,9 @@ int sell_from_csr_host(int64_t n, int64_t ncols, const int64_t *row_ptr, const i
         std::vector<uint16_t> c16((size_t)padded, 0);
         std::vector<int32_t> cbase((size_t)(padded / 64), 0);
         bool all_fit = true;
-        for (int32_t s_ = 0; s_ < n_slices && all_fit; ++s_) {
+        int64_t wide_slices = 0;
+        const bool count_wide = cfg().trace;
+        for (int32_t s_ = 0; s_ < n_slices && (all_fit || count_wide); ++s_) {
             const int64_t sb = slice_ptr[s_], w = (slice_ptr[s_ + 1] - sb) / 64;
             const int64_t r0 = (int64_t)s_ * 64, r1 = std::min<int64_t>(n, r0 + 64);
             bool fits = true;
@@ -244,8 +246,10 @@ int sell_from_csr_host(int64_t n, int64_t ncols, const int64_t *row_ptr, const i
                 for (int64_t r = r0; r < r1; ++r)
                     if (k < row_len[r]) c16[(size_t)(sb + k * 64 + (r - r0))] = (uint16_t)(scol[sb + k * 64 + (r - r0)] - lo);
             }
-            all_fit = fits;
+            all_fit = all_fit && fits;
+            if (!fits) ++wide_slices;
         }
+        if (count_wide && wide_slices) fprintf(stderr, "[orc sell] narrow column image: %lld of %d slices have a depth that spans more than 65 535 columns\n", (long long)wide_slices, n_slices);
         if (all_fit) {  // all or nothing: the product kernels have no per-slice branch (scalar registers, see spmv_uniform_k)
             ORC_TRY(out.col16.upload(c16.data(), c16.size()));
             ORC_TRY(out.colbase.upload(cbase.data(), cbase.size()));
@@ -482,6 +486,7 @@ static int launch_spmv(const MatView &A_in, const double *x, const Epi &epi, dou
         if (narrow && !scaled && A.nt) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_uniform_k<Epi, false, true, true, false, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
         else if (narrow && !scaled) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_uniform_k<Epi, false, true, true, false>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
         else if (narrow) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_uniform_k<Epi, false, true, true, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
+        else if (!scaled && A.nt) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_uniform_k<Epi, false, true, false, false, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
         else if (!scaled) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_uniform_k<Epi, false, true, false, false>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv_uniform_k<Epi, false, true>), dim3(g), dim3(kBlock), 0, ctx().stream, A, x, epi, partials, skip_flags);
     }
@@ -1036,6 +1041,7 @@ static int launch_spmv3(const MatView3 &A_in, const double *x3, const Epi3 &epi,
         if (narrow && !scaled && A.nt) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4, true, true, false, true>), dim3(g_launch), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
         else if (narrow && !scaled) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4, true, true, false>), dim3(g_launch), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
         else if (narrow) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4, true, true, true>), dim3(g_launch), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
+        else if (!scaled && A.nt) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4, true, false, false, true>), dim3(g_launch), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
         else if (!scaled) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4, true, false, false>), dim3(g_launch), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4, true>), dim3(g_launch), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
     } else if (!(A.s1 || A.s2) && A.P.col16 && A.nt) hipLaunchKernelGGL(HIP_KERNEL_NAME(spmv3_uniform_k<Epi3, 4, false, true, false, true>), dim3(g_launch), dim3(kBlock), 0, ctx().stream, A, x3, epi, partials);
