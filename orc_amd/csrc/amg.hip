@@ -2417,6 +2417,10 @@ int multigrid_arm3_dev(const MatView3 &A3, const double *const b[3], double *con
     if (shared) {
         for (int k = 1; k < 3; ++k) shared = shared && H[k]->level[0].n == nc && H[k]->level[0].padded == H[0]->level[0].padded;
     }
+    // [r05] A first coarse level with a packed mirror (ragged rows: config 5) is multiplied by spmv_xwin_k when a system is solved alone — one workgroup per
+    // 256-row block, i.e. another thread -> row map and other partial sums than the SELL walk the lock-step kernels share with spmv_uniform_k: in
+    // lock-step its dot products would round differently from the one-system solve's.  Such a level is solved per system (the lanes below).
+    if (shared && H[0]->level[0].pk.ptr) shared = false;
     if (shared) {  // same pairing and same coarse row lengths => same coarse pattern (the symbolic part of the product depends on nothing else)
         int *diff;
         ORC_TRY(arena.alloc((size_t)1, &diff));

@@ -12,16 +12,16 @@ cp $OUT/kern/*/*kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
 cp $OUT/kern/*/*kernel_trace.csv $OUT/kernel_trace.csv 2>/dev/null
 rm -rf $OUT/kern
 grep "cells\|level" $OUT/kern.log
-GROUPS_BYTES=("FETCH_SIZE" "WRITE_SIZE")
-GROUPS_FULL=("FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"
+PASSES_BYTES=("FETCH_SIZE" "WRITE_SIZE")
+PASSES_FULL=("FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"
          "TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum" "TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum"
          "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum"
          "TCC_HIT_sum TCC_MISS_sum" "TCC_REQ_sum TCC_READ_sum"
          "GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_BUSY_CYCLES SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_ANY"
          "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS" "SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_SALU")
-if [ "$WHAT" = bytes ]; then GROUPS=("${GROUPS_BYTES[@]}"); else GROUPS=("${GROUPS_FULL[@]}"); fi
+if [ "$WHAT" = bytes ]; then PASSES=("${PASSES_BYTES[@]}"); else PASSES=("${PASSES_FULL[@]}"); fi
 i=0
-for G in "${GROUPS[@]}"; do
+for G in "${PASSES[@]}"; do
   i=$((i+1))
   timeout -k 10 300 rocprofv3 --pmc $G -d $OUT/p$i --output-format csv -- python3 scripts/profile_products.py --reps $REPS "$@" > $OUT/p$i.log 2>&1 || { echo "pass $i failed: $G"; grep -m2 -i "error\|invalid" $OUT/p$i.log | cut -c1-200; continue; }
   echo "pass $i ok: $G"

@@ -15,6 +15,7 @@ ap.add_argument("--prefix", default="r05", help="profiles/<prefix>_*.csv / .json
 ap.add_argument("--n", type=int, default=10_240_000)
 ap.add_argument("--nnz", type=int, default=71_372_800)
 ap.add_argument("--workload", default="hex channel 400x160x160, a_u through two Jacobi scalings (scripts/profile_products.py)")
+ap.add_argument("--xwin-levels", default="2,3", help="the levels whose products are spmv_xwin_k launches, in the order profile_products.py runs them")
 args = ap.parse_args()
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 base = os.path.join(root, "gpurun_out", args.tag)
@@ -47,12 +48,17 @@ if os.path.exists(kt):
         trace[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 
 
+XWIN_LEVELS = [int(x) for x in args.xwin_levels.split(",")]
+
+
 def split_levels(k, values):
-    """spmv_xwin_k runs for level 2 and then for level 3 (same kernel name): first half of the dispatches / second half."""
-    if not k.startswith("spmv_xwin_k") or len(values) < 2:
+    """spmv_xwin_k runs for one level after the other under the same kernel name (the hex channel: levels 2 and 3; config 5 since r05: 1, 2, 3):
+    equal shares of the dispatches, in order."""
+    m = len(XWIN_LEVELS)
+    if not k.startswith("spmv_xwin_k") or len(values) < m:
         return {"": values}
-    h = len(values) // 2
-    return {" [level 2]": values[:h], " [level 3]": values[h:]}
+    h = len(values) // m
+    return {" [level %d]" % lv: values[q * h:(q + 1) * h if q + 1 < m else len(values)] for q, lv in enumerate(XWIN_LEVELS)}
 
 
 rows = []
@@ -112,7 +118,8 @@ for r in rows:
     c = r["counters"]
     print("%-52s %3d x %7.1f us  read %8.1f MB  write %7.1f MB  %.2f TB/s   TA busy %4.0f%%  L2 hit %4.0f%%  LDS conflicts/inst %.2f" % (
         r["kernel"][-52:], r["launches"], r["avg_us"], r["hbm_read_bytes"] / 1e6, r["hbm_write_bytes"] / 1e6, r["TB_per_s"],
-        100. * c.get("TA_TA_BUSY_sum", 0.) / max(c.get("GRBM_GUI_ACTIVE", 0.) * 256 * 4, 1.) if c.get("GRBM_GUI_ACTIVE") else float("nan"),
+        # TA_TA_BUSY_sum adds the 256 texture addressers' busy cycles, GRBM_GUI_ACTIVE the 8 XCDs' active cycles: per addresser busy / (active / 8)
+        100. * c.get("TA_TA_BUSY_sum", 0.) / max(c.get("GRBM_GUI_ACTIVE", 0.) * 32, 1.) if c.get("GRBM_GUI_ACTIVE") else float("nan"),
         100. * c.get("TCC_HIT_sum", 0.) / max(c.get("TCC_HIT_sum", 0.) + c.get("TCC_MISS_sum", 0.), 1.),
         c.get("SQ_LDS_BANK_CONFLICT", 0.) / max(c.get("SQ_INSTS_LDS", 0.), 1.)))
 
