@@ -26,6 +26,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PMC_FILE = "r05_spmv_pmc.json"  # written by scripts/pmc_summary.py from the rocprofv3 --pmc passes of scripts/gpu_pmc.sh
+PMC_FILE_CONFIG5 = "r05_config5_spmv_pmc.json"  # the same for --workload config5 (scripts/gpu_pmc.sh ... --workload config5)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy ceiling)
 REF_CELLS = 400 * 160 * 160
 
@@ -528,11 +529,12 @@ def main():
     KERNEL = "spmv_uniform_k<EpiStoreSum, false, true, %s> / <EpiTs, false, true, %s>" % (variant, variant)
     traffic, traffic_source = None, None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
+        pmc_file = PMC_FILE_CONFIG5 if mixed else PMC_FILE
+        pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
         # the counters must be those of THIS kernel on THIS matrix: anything else is not quoted
         if pmc["n"] == n_local and pmc["nnz"] == nnz_local and pmc["kernel"] == KERNEL:
             traffic = pmc["hbm_bytes_per_launch"]
-            traffic_source = "profiles/%s (%s)" % (PMC_FILE, pmc.get("method", "rocprofv3 --pmc"))
+            traffic_source = "profiles/%s (%s)" % (pmc_file, pmc.get("method", "rocprofv3 --pmc"))
     except Exception:
         traffic = None
 
