@@ -1939,11 +1939,27 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
             if (trace_t) fprintf(stderr, "[amg windows n=%lld] LDS share %d entries per workgroup (%d of %lld blocks have larger windows)\n", (long long)nc, cap,
                                  cap < win_cap ? h_over[std::find(kXWinCapSize, kXWinCapSize + kXWinCapSizes, cap) - kXWinCapSize] : 0, (long long)n_blocks);
         }
-        for (int x = 0; x < n_sib; ++x) {  // same structure, own values
+        {   // [r05] scratch of the in-launch fold of this level's products (spmv_xwin_k): two sums per workgroup of a one-workgroup-per-block launch
+            const size_t n_wg = (size_t)((n_blocks + 7) / 8 * 8);
+            double *fs;
+            unsigned *fc;
+            ORC_TRY(arena.alloc(2 * n_wg, &fs));
+            ORC_TRY(arena.alloc((size_t)4, &fc));
+            ORC_HIP(hipMemsetAsync(fc, 0, 4 * sizeof(unsigned), st));
+            L.xw.fold_scratch = fs; L.xw.fold_counter = fc;
+        }
+        for (int x = 0; x < n_sib; ++x) {  // same structure, own values (and scratch of their own: the systems' products run side by side)
             CoarseLevel &Lx = *sib[x].L;
             Lx.pk = L.pk;
             Lx.pk.val = x_pk_val[x];
             Lx.xw = L.xw;
+            const size_t n_wg = (size_t)((n_blocks + 7) / 8 * 8);
+            double *fs;
+            unsigned *fc;
+            ORC_TRY(sib[x].arena->alloc(2 * n_wg, &fs));
+            ORC_TRY(sib[x].arena->alloc((size_t)4, &fc));
+            ORC_HIP(hipMemsetAsync(fc, 0, 4 * sizeof(unsigned), st));
+            Lx.xw.fold_scratch = fs; Lx.xw.fold_counter = fc;
         }
         const bool xwin_stats = cfg().debug_xwin;
         if (xwin_stats) {

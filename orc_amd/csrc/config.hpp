@@ -36,6 +36,7 @@ struct Config {
     int xwin_cap = 0;                   // ORC_XWIN_CAP: window entries per block (test hook: forces the no-window fallback; 0: kXWinCap)
     int xwin_bitwords = 0;              // ORC_XWIN_BITWORDS / ORC_XWIN_SMALL_BITWORDS: bitmap spans of the window build (test hooks; 0: compiled sizes)
     int xwin_small_bitwords = 0;
+    bool xwin_wg_per_block = true;      // ORC_XWIN_WG_PER_BLOCK: window products launch one workgroup per 256-row block and fold their sums inside the launch (0: 2 048 persistent workgroups, r04)
     bool xwin_level_cap = true;         // ORC_XWIN_LEVEL_CAP: a level's products size their LDS window to what the level needs (0: the compiled 40 KB, as until r04)
     // ---- Gauss-Seidel extension (gs.hip)
     bool gs_slotspace = true;           // ORC_GS_SLOTSPACE: GS-preconditioned BiCGSTAB in colour-sorted slot space (0: row space, as partitioned runs use)

@@ -415,8 +415,18 @@ static int launch_spmv(const MatView &A_in, const double *x, const Epi &epi, dou
             return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
         }();
         int64_t gb = ((int64_t)A.P.n_slices + 3) / 4;
-        if (gb > (int64_t)n_cu * per_cu) gb = (int64_t)n_cu * per_cu;
-        gb = clamp_partials_grid(gb);  // whatever the CU count (304 on gfx942) and the switch: the epilogue writes partials[blockIdx.x]
+        // [r05] ONE workgroup per block, dispatched by the hardware as wave slots free up: with 2 048 persistent workgroups of 4-5 (level 2) or 2-3 blocks
+        // (level 3) each, a third of a CU's wave slots stood empty on average (SQ_WAVE_CYCLES / GRBM_GUI_ACTIVE: 13 of 20) — the plain product 230-235 ->
+        // 215-217 us on level 2, 250 -> 243 us on level 3 (scripts/archive/gpu_r05_z.sh).  Products with reductions fold their sums inside the launch
+        // (spmv_xwin_k, XWinDev::fold_scratch): the consumers see one sum per quantity.
+        const bool one_per_block = cfg().xwin_wg_per_block && (Epi::kReductions == 0 || A.xw.fold_scratch != nullptr);
+        if (one_per_block) {
+            gb = (gb + 7) / 8 * 8;
+        } else {
+            A.xw.fold_scratch = nullptr;  // the kernel writes one partial sum per workgroup
+            if (gb > (int64_t)n_cu * per_cu) gb = (int64_t)n_cu * per_cu;
+            gb = clamp_partials_grid(gb);  // whatever the CU count (304 on gfx942) and the switch: the epilogue writes partials[blockIdx.x]
+        }
         if (gb >= 8) gb = (gb / 8) * 8;
         g = (int)std::max<int64_t>(gb, 1);
     }
@@ -466,7 +476,7 @@ static int launch_spmv(const MatView &A_in, const double *x, const Epi &epi, dou
         ctx().halo_overlaps += 1;
         return ORC_OK;
     }
-    if (grid_out) *grid_out = g;
+    if (grid_out) *grid_out = (xwin && Epi::kReductions > 0 && A.xw.fold_scratch) ? 1 : g;  // (folded inside the launch: one sum per quantity)
     if (A.P.n == 0) return ORC_OK;
     if (A.halo) ORC_TRY(A.halo->exchange(const_cast<double *>(x)));  // C1: refresh the ghost entries of x
     if (xwin) {

@@ -72,6 +72,10 @@ struct XWinDev {
     // level's blocks without a window.  The compiled worst case (5 000 entries = 40 KB) held a CU to four workgroups whatever the level needed
     // (the channel's level 2: 2 200 per block); blocks whose window is larger gather from global memory, as blocks without a window always did.
     int32_t cap = kXWinCap;
+    // [r05] one workgroup per block: the workgroups' partial sums (2 x the launch's workgroups) and the arrival counter of the launch in flight — one
+    // product of a level at a time (a level's products follow each other on one stream; sibling systems have scratch of their own)
+    double *fold_scratch = nullptr;
+    unsigned *fold_counter = nullptr;
 };
 
 // Row-contiguous mirror (the Galerkin product's scratch rows, kept alive with their level): entry k of row r sits at

@@ -579,6 +579,46 @@ __global__ __launch_bounds__(kBlock) void spmv_xwin_k(MatView A, const double *_
         }
         __syncthreads();  // the next block overwrites the window
     }
+    if (Epi::kReductions > 0 && A.xw.fold_scratch) {
+        // [r05] One workgroup per block (launch_spmv): more workgroups than a consumer could fold.  Every workgroup leaves its sums in the level's
+        // scratch; the one that arrives LAST — whichever it is — adds them up in index order with a fixed tree, so the result does not depend on the
+        // order of arrival, and leaves ONE sum per quantity in partials[q] (the consumers see a fold count of 1).
+        __shared__ int s_last;
+        const int nwg = (int)gridDim.x;
+        const double t0 = block_sum(r0, lds);
+        const double t1 = Epi::kReductions > 1 ? block_sum(r1, lds) : 0.;
+        // No fences: a device-scope fence writes back / invalidates the XCD's L2 on this chip (10 000 of them per launch cost twice the product).
+        // The sums travel as agent-scope atomic stores and loads (they bypass the XCD-local L2), the ticket is an agent-scope atomic, and a workgroup
+        // takes its ticket only once its stores are acknowledged (s_waitcnt): whoever draws the last ticket finds every sum in place.
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(A.xw.fold_scratch + blockIdx.x, t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (Epi::kReductions > 1) __hip_atomic_store(A.xw.fold_scratch + nwg + blockIdx.x, t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_s_waitcnt(0);
+            s_last = __hip_atomic_fetch_add(A.xw.fold_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nwg - 1);
+        }
+        __syncthreads();
+        if (s_last) {
+            const double *fs = A.xw.fold_scratch;
+#pragma unroll
+            for (int q = 0; q < Epi::kReductions; ++q) {
+                double v = 0.;
+                for (int i0 = threadIdx.x; i0 < nwg; i0 += 8 * kBlock) {  // eight loads in flight per thread, added in index order
+                    double t[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int i = i0 + u * kBlock;
+                        t[u] = i < nwg ? __hip_atomic_load(fs + (size_t)q * nwg + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v += t[u];
+                }
+                v = block_sum(v, lds);
+                if (threadIdx.x == 0) partials[q] = v;
+            }
+            if (threadIdx.x == 0) __hip_atomic_store(A.xw.fold_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (the next launch on this level follows on the same stream)
+        }
+        return;
+    }
     if (Epi::kReductions > 0) {
         double t = block_sum(r0, lds);
         if (threadIdx.x == 0) partials[blockIdx.x] = t;

@@ -66,6 +66,7 @@ void config_reload() {
     c.xwin_cap = env_int("ORC_XWIN_CAP", 0);
     c.xwin_bitwords = env_int("ORC_XWIN_BITWORDS", 0);
     c.xwin_small_bitwords = env_int("ORC_XWIN_SMALL_BITWORDS", 0);
+    c.xwin_wg_per_block = env_on("ORC_XWIN_WG_PER_BLOCK", true);
     c.xwin_level_cap = env_on("ORC_XWIN_LEVEL_CAP", true);
     c.gs_slotspace = env_on("ORC_GS_SLOTSPACE", true);
     c.trace = env_set("ORC_DEBUG_TRACE");
