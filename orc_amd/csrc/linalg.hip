@@ -419,7 +419,11 @@ static int launch_spmv(const MatView &A_in, const double *x, const Epi &epi, dou
         // (level 3) each, a third of a CU's wave slots stood empty on average (SQ_WAVE_CYCLES / GRBM_GUI_ACTIVE: 13 of 20) — the plain product 230-235 ->
         // 215-217 us on level 2, 250 -> 243 us on level 3 (scripts/archive/gpu_r05_z.sh).  Products with reductions fold their sums inside the launch
         // (spmv_xwin_k, XWinDev::fold_scratch): the consumers see one sum per quantity.
-        const bool one_per_block = cfg().xwin_wg_per_block && (Epi::kReductions == 0 || A.xw.fold_scratch != nullptr);
+        // Blocks of short rows (config 5's level 1: 4 350 entries per block) are over before the ticket of the fold has paid for itself (its iteration
+        // +5 ... +10 ms): from 8 000 entries per block on.  Pulling blocks from per-XCD queues with persistent workgroups (one ticket per workgroup
+        // instead of one per block) was measured too: the returning atomic at the head of a wavefront's in-order memory queue holds up its stream —
+        // levels 2-3 0.54 / 0.58, the iteration 768-771 against 736-743 ms.
+        const bool one_per_block = cfg().xwin_wg_per_block && (Epi::kReductions == 0 || A.xw.fold_scratch != nullptr) && A.pk.total >= (int64_t)8000 * gb;
         if (one_per_block) {
             gb = (gb + 7) / 8 * 8;
         } else {

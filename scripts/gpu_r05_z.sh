@@ -11,7 +11,7 @@ for pass in 1:1 0:2 0:3 1:4; do
   ORC_XWIN_WG_PER_BLOCK=$v timeout -k 10 200 python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline > $O/bench_wgpb${v}_$i.json 2> $O/bench_wgpb${v}_$i.err || exit 1
   python3 -c "import json,sys; d=json.load(open('$O/bench_wgpb${v}_$i.json')); print('one wg per block=$v ms_per_step %.1f' % d['ms_per_step'], [round(x) for x in d['step_ms']], [round(l['frac_of_peak'],3) for l in d['amg_levels']])"
 done
-for pass in 1:1 0:2; do
+for pass in 1:1 0:2 0:3 1:4; do
   v=${pass%%:*}; i=${pass##*:}
   ORC_XWIN_WG_PER_BLOCK=$v timeout -k 10 200 python3 bench.py --workload config5 --steps 4 --warmup 1 --no-cpu-baseline > $O/c5_bench_wgpb${v}_$i.json 2> $O/c5_bench_wgpb${v}_$i.err || exit 1
   python3 -c "import json,sys; d=json.load(open('$O/c5_bench_wgpb${v}_$i.json')); print('config5 one wg per block=$v ms_per_step %.1f' % d['ms_per_step'], [round(l['frac_of_peak'],3) for l in d['amg_levels']])"

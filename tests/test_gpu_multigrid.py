@@ -264,6 +264,32 @@ def test_shared_jacobi_scaling_of_a_levels_two_smoothing_solves_does_not_change_
             assert np.array_equal(x, y)
 
 
+def test_in_launch_fold_of_the_window_products_is_reproducible(gpu, monkeypatch):
+    """[r05] Window products of blocks with >= 8 000 entries launch one workgroup per 256-row block; every workgroup leaves its partial sums in the
+    level's scratch and whichever arrives last adds them up in index order (spmv_xwin_k, XWinDev::fold_scratch): the sums must not depend on the
+    order of arrival.  Three default-stack SIMPLE iterations on a channel whose last level has such blocks: identical bits run after run; with
+    ORC_XWIN_WG_PER_BLOCK=0 (2 048 persistent workgroups, one partial sum each: another association of the same dot products) the fields agree
+    to the rounding of those sums."""
+    from orc_amd.mesh import Mesh, hex_channel, set_channel_bcs
+    from orc_amd.settings import NumericalSettings
+    from orc_amd.solver import solve_steady
+    import helpers as H
+    a = set_channel_bcs(hex_channel(48, 32, 20))
+    s = NumericalSettings.default(momentum=5, solver_type=MULTIGRID, iterations=8, momentum_relaxation=0.1, pressure_relaxation=0.001)
+    out = []
+    for mode in ("1", "1", "0"):
+        monkeypatch.setenv("ORC_XWIN_WG_PER_BLOCK", mode)
+        dm = Mesh(a)
+        u, v, w, p = H.seeded_fields(a, seed=13)
+        solve_steady(dm, u, v, w, p, s, 1000.0, 1e-3, 3)
+        out.append((u, v, w, p))
+    assert np.isfinite(out[0][0]).all()
+    for x, y in zip(out[0], out[1]):
+        assert np.array_equal(x, y)
+    for x, y in zip(out[0], out[2]):
+        assert np.linalg.norm(x - y) <= 1e-9 * max(np.linalg.norm(x), 1e-300)
+
+
 def test_last_slice_dead_lanes_regression(gpu, oracle, mesh_path):
     """Regression (round 2, fix 5d036f6): channel_flow.msh has 1008 = 15 x 64 + 48 cells, so the last slice of every level has
     dead lanes; those lanes once gathered through never-written columns of the device-packed coarse operators and the process
