@@ -422,7 +422,8 @@ static int launch_spmv(const MatView &A_in, const double *x, const Epi &epi, dou
         // Blocks of short rows (config 5's level 1: 4 350 entries per block) are over before the ticket of the fold has paid for itself (its iteration
         // +5 ... +10 ms): from 8 000 entries per block on.  Pulling blocks from per-XCD queues with persistent workgroups (one ticket per workgroup
         // instead of one per block) was measured too: the returning atomic at the head of a wavefront's in-order memory queue holds up its stream —
-        // levels 2-3 0.54 / 0.58, the iteration 768-771 against 736-743 ms.
+        // levels 2-3 0.54 / 0.58, the iteration 768-771 against 736-743 ms.  Two to four blocks per workgroup where blocks are short (12 000 / 18 000 / 30 000
+        // entries per workgroup): 727 / 724, 729 / 733, 742 / 735 against 726 / 730 ms; config 5 475 / 472, 478 / 473, 488 / 491 against 478 / 479.
         const bool one_per_block = cfg().xwin_wg_per_block && (Epi::kReductions == 0 || A.xw.fold_scratch != nullptr) && A.pk.total >= (int64_t)8000 * gb;
         if (one_per_block) {
             gb = (gb + 7) / 8 * 8;
