@@ -264,30 +264,28 @@ def test_shared_jacobi_scaling_of_a_levels_two_smoothing_solves_does_not_change_
             assert np.array_equal(x, y)
 
 
-def test_in_launch_fold_of_the_window_products_is_reproducible(gpu, monkeypatch):
+def test_in_launch_fold_of_the_window_products_is_reproducible(gpu, oracle, monkeypatch):
     """[r05] Window products of blocks with >= 8 000 entries launch one workgroup per 256-row block; every workgroup leaves its partial sums in the
     level's scratch and whichever arrives last adds them up in index order (spmv_xwin_k, XWinDev::fold_scratch): the sums must not depend on the
-    order of arrival.  Three default-stack SIMPLE iterations on a channel whose last level has such blocks: identical bits run after run; with
-    ORC_XWIN_WG_PER_BLOCK=0 (2 048 persistent workgroups, one partial sum each: another association of the same dot products) the fields agree
-    to the rounding of those sums."""
-    from orc_amd.mesh import Mesh, hex_channel, set_channel_bcs
-    from orc_amd.settings import NumericalSettings
-    from orc_amd.solver import solve_steady
-    import helpers as H
-    a = set_channel_bcs(hex_channel(48, 32, 20))
-    s = NumericalSettings.default(momentum=5, solver_type=MULTIGRID, iterations=8, momentum_relaxation=0.1, pressure_relaxation=0.001)
+    order of arrival.  The Multigrid arm on a matrix whose levels 2 and 3 have such blocks (8 400 and 18 000 entries per block), five smoother
+    iterations: identical bits run after run, the oracle's result to 1e-8, and with ORC_XWIN_WG_PER_BLOCK=0 (2 048 persistent workgroups, one
+    partial sum each: another association of the same dot products) the same solution to the rounding of those sums."""
+    from orc_amd.linear_algebra import iterative_solve
+    a = fv_like_matrix(64, 40, 12)
+    n = a.shape[0]
+    b = a @ splitmix64_uniform(n, 17)
+    x0 = 0.1 * splitmix64_uniform(n, 18)
     out = []
     for mode in ("1", "1", "0"):
         monkeypatch.setenv("ORC_XWIN_WG_PER_BLOCK", mode)
-        dm = Mesh(a)
-        u, v, w, p = H.seeded_fields(a, seed=13)
-        solve_steady(dm, u, v, w, p, s, 1000.0, 1e-3, 3)
-        out.append((u, v, w, p))
-    assert np.isfinite(out[0][0]).all()
-    for x, y in zip(out[0], out[1]):
-        assert np.array_equal(x, y)
-    for x, y in zip(out[0], out[2]):
-        assert np.linalg.norm(x - y) <= 1e-9 * max(np.linalg.norm(x), 1e-300)
+        x = x0.copy()
+        iterative_solve(a, b, x, 5, MULTIGRID, 0.5, 1e-3, PRE_JACOBI)
+        out.append(x)
+    xo = x0.copy()
+    assert oracle.iterative_solve(oracle.Csr.from_scipy(a), b, xo, 5, MULTIGRID, 0.5, 1e-3, PRE_JACOBI) == 0
+    assert np.array_equal(out[0], out[1])
+    assert rel(out[0], xo) < 1e-8 and rel(out[2], xo) < 1e-8
+    assert rel(out[0], out[2]) < 1e-9
 
 
 def test_last_slice_dead_lanes_regression(gpu, oracle, mesh_path):
