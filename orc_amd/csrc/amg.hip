@@ -1811,7 +1811,7 @@ static int galerkin(const MatView &A, const int *choice, const int *chooser, Are
     // 10.24 M fine rows: 33 entries per row +2 %, 70 entries per row +17 % against the padded product; 15 entries per row
     // -10 %, so that level keeps the padded image).  ORC_SPMV_XWIN_MIN_NNZ < 0 switches the mirror off.
     // [r05] ... unless the padded image wastes what the windows cost: config 5's level 1 (17 entries per row, rows of a tet / hex / polyhedral mesh paired:
-    // 29 % of its SELL image is padding) 165 -> 126 us with the mirror, the whole iteration 516 -> 479 ms (scripts/gpu_r05_r.sh); the channel's level 1
+    // 29 % of its SELL image is padding) 165 -> 126 us with the mirror, the whole iteration 516 -> 479 ms (scripts/archive/gpu_r05_r.sh); the channel's level 1
     // (5.7 % padding) 198 -> 222 us.  From 15 % padding on, a level of at least half the entries per row takes the mirror too.
     const int xwin_min = cfg().spmv_xwin_min_nnz;
     const bool long_rows = packed_total >= (int64_t)xwin_min * nc;

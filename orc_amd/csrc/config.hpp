@@ -48,7 +48,7 @@ struct Config {
     bool debug_xwin = false;            // ORC_DEBUG_XWIN / ORC_XWIN_STATS: window statistics per level
     int debug_sync = 0;                 // ORC_DEBUG_SYNC: bit mask of steps of the lock-step level 1 after which the library stream is drained
     std::string inject_lane_error;      // ORC_DEBUG_INJECT_LANE_ERROR "rank:lane" (test hook: a failing set-up thread)
-    bool keep_priority_classes = false; // ORC_DEBUG_KEEP_PRIORITY_CLASSES: classes although ranks share a card (scripts/gpu_r05_b.sh: reproduces r04's stall)
+    bool keep_priority_classes = false; // ORC_DEBUG_KEEP_PRIORITY_CLASSES: classes although ranks share a card (scripts/archive/gpu_r05_b.sh: reproduces r04's stall)
 };
 
 const Config &cfg();   // the values of the last (re)load

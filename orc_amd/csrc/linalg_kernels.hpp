@@ -436,7 +436,7 @@ struct SpmvSliceMeta {
 // instruction issue as much as by memory (39 vector instructions per entry and wavefront, profiles/r03_pmc_products.csv)
 // kC: entries per lane and chunk of the stream (two chunks in flight): 8 = 92-94 VGPRs, five workgroups per CU where the level's LDS share
 // (XWinDev::cap) allows them.  [r05] measured: 4 (58 VGPRs, up to 24 wavefronts per CU on the level whose windows fit 25 KB) is no faster — 233.1 /
-// 226.6 against 226.2 / 227.5 us on that level, 226.4 / 219.7 against 224.9 / 218.6 on the last (scripts/gpu_r05_j.sh): like the per-level LDS
+// 226.6 against 226.2 / 227.5 us on that level, 226.4 / 219.7 against 224.9 / 218.6 on the last (scripts/archive/gpu_r05_j.sh): like the per-level LDS
 // share itself (16 -> 20 wavefronts per CU: -1 ... -3 %), occupancy is not what holds this product at 4.6-4.8 TB/s
 template <class Epi, bool kScaled = true, bool kNT = false, int kC = 8>
 __global__ __launch_bounds__(kBlock) void spmv_xwin_k(MatView A, const double *__restrict__ x, Epi epi, double *__restrict__ partials,

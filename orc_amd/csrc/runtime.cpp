@@ -94,7 +94,7 @@ const Config &cfg() {
 // events the solve lanes wait for — in the default class BETWEEN them: the lock-step schedule (multigrid_arm3_dev) parks three top-class
 // queues on an event that sits behind some hundred kernels of a LOWER class.  One process per card got away with it; two processes on one
 // card (the host-transport rehearsal) stalled for good: eight parked top-class queues and the command processor never came round to the
-// default-class queue that would release them.  Established by experiment (scripts/gpu_r05_b.sh, gpu_r05_c.sh; 40x26x16 slabs, two ranks):
+// default-class queue that would release them.  Established by experiment (scripts/archive/gpu_r05_b.sh, gpu_r05_c.sh; 40x26x16 slabs, two ranks):
 //   classes as in r04, 4 queues per class: stalls (3 of 3 runs; also with the p' set-up moved) — 3 or 2 queues per class: runs;
 //   set-up class ABOVE the solve class, or classes by lane: runs;  ONE class with 4, 8, 16 queues per process: runs.
 // So it is neither the number of queues nor of streams, it is the DIRECTION of the wait: a higher class parked on a lower one — priority
@@ -122,7 +122,7 @@ int stream_create(hipStream_t *out, int role, int lane, const char *name) {
     // ORC_STREAM_PRIORITIES: 3 (default) = solve streams above set-up streams — since the round-2 set-up rework the solves are the critical
     // path of the momentum phase (0.863-0.879 s per iteration against 0.903-0.909 s with 2 = set-up above solve and 0.926-0.957 s with 0 =
     // no classes, r02); 1 = one class per lane
-    // ORC_DEBUG_KEEP_PRIORITY_CLASSES=1 (scripts/gpu_r05_b.sh only): the r04 behaviour — classes even when ranks share the card — to reproduce the stall
+    // ORC_DEBUG_KEEP_PRIORITY_CLASSES=1 (scripts/archive/gpu_r05_b.sh only): the r04 behaviour — classes even when ranks share the card — to reproduce the stall
     const int prio_mode = (role == kPlainStream || (device_shared_between_ranks() && !cfg().keep_priority_classes)) ? 0 : cfg().stream_priorities;
     int least = 0, greatest = 0, prio = 0;
     bool with_prio = false;
