@@ -420,12 +420,16 @@ static int launch_spmv(const MatView &A_in, const double *x, const Epi &epi, dou
         // 215-217 us on level 2, 250 -> 243 us on level 3 (scripts/archive/gpu_r05_z.sh).  Products with reductions fold their sums inside the launch
         // (spmv_xwin_k, XWinDev::fold_scratch): the consumers see one sum per quantity.
         // Blocks of short rows (config 5's level 1: 4 350 entries per block) are over before the ticket of the fold has paid for itself (its iteration
-        // +5 ... +10 ms): from 8 000 entries per block on.  Pulling blocks from per-XCD queues with persistent workgroups (one ticket per workgroup
+        // +5 ... +10 ms with one block per workgroup): such a level's workgroups take up to four blocks.  Pulling blocks from per-XCD queues with persistent workgroups (one ticket per workgroup
         // instead of one per block) was measured too: the returning atomic at the head of a wavefront's in-order memory queue holds up its stream —
         // levels 2-3 0.54 / 0.58, the iteration 768-771 against 736-743 ms.  Two to four blocks per workgroup where blocks are short (12 000 / 18 000 / 30 000
         // entries per workgroup): 727 / 724, 729 / 733, 742 / 735 against 726 / 730 ms; config 5 475 / 472, 478 / 473, 488 / 491 against 478 / 479.
-        const bool one_per_block = cfg().xwin_wg_per_block && (Epi::kReductions == 0 || A.xw.fold_scratch != nullptr) && A.pk.total >= (int64_t)8000 * gb;
+        const bool one_per_block = cfg().xwin_wg_per_block && (Epi::kReductions == 0 || A.xw.fold_scratch != nullptr) && A.pk.total > 0;
         if (one_per_block) {
+            // about 12 000 entries per workgroup: one block on the channel's levels 2-3 (8 450 / 18 000 entries per block), three on config 5's level 1 (4 350)
+            const int64_t per_block = std::max<int64_t>(1, A.pk.total / std::max<int64_t>(gb, 1));
+            const int64_t blocks_per_wg = std::min<int64_t>(4, std::max<int64_t>(1, (12000 + per_block / 2) / per_block));
+            gb = (gb + blocks_per_wg - 1) / blocks_per_wg;
             gb = (gb + 7) / 8 * 8;
         } else {
             A.xw.fold_scratch = nullptr;  // the kernel writes one partial sum per workgroup

@@ -265,7 +265,7 @@ def test_shared_jacobi_scaling_of_a_levels_two_smoothing_solves_does_not_change_
 
 
 def test_in_launch_fold_of_the_window_products_is_reproducible(gpu, oracle, monkeypatch):
-    """[r05] Window products of blocks with >= 8 000 entries launch one workgroup per 256-row block; every workgroup leaves its partial sums in the
+    """[r05] Window products launch one workgroup per ~12 000 entries (one 256-row block here); every workgroup leaves its partial sums in the
     level's scratch and whichever arrives last adds them up in index order (spmv_xwin_k, XWinDev::fold_scratch): the sums must not depend on the
     order of arrival.  The Multigrid arm on a matrix whose levels 2 and 3 have such blocks (8 400 and 18 000 entries per block), five smoother
     iterations: identical bits run after run, the oracle's result to 1e-8, and with ORC_XWIN_WG_PER_BLOCK=0 (2 048 persistent workgroups, one
